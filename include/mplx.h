@@ -1,0 +1,158 @@
+/*
+ * mplx.h -- C ABI of the MI355X successor-expansion engine (libmplx.so).
+ *
+ * This is the drop-in boundary for ONE path of sikang/motion_primitive_library
+ * (MPL v1.2): MPL::env_map<Dim>::get_succ and everything it evaluates
+ *   (reference include/mpl_planner/env/env_map.h:147-172 and :90-132).
+ * The reference has no FFI: the extension point is the C++ virtual
+ *   env_base<Dim>::get_succ(curr, succ, succ_cost, action_idx)
+ *   (include/mpl_planner/common/env_base.h:358-362),
+ * installed by MapPlanner<Dim>::setMapUtil (src/mpl_planner/map_planner.cpp:14-18).
+ * A reference-side env subclass binds the entry points below; the adapter a
+ * maintainer would add is include/mplx_env_map.hpp and INTEGRATION.md shows it.
+ *
+ * All pointers are plain C pointers; no C++ or torch types cross this line.
+ * Every function returns 0 on success and a negative mplx_status on failure
+ * and never throws; mplx_last_error() gives the text.  There is NO CPU
+ * fallback: without a usable gfx950 device mplx_create fails.
+ *
+ * A context is single-owner and not thread-safe (the reference's env is not
+ * re-entrant either: env_base.h:402-404).  Each context owns one HIP stream;
+ * every *_device call is asynchronous on that stream.
+ */
+#ifndef MPLX_H
+#define MPLX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPLX_ABI_VERSION 1
+
+typedef struct mplx_ctx mplx_ctx;
+
+typedef enum {
+  MPLX_OK = 0,
+  MPLX_ERR_ARG = -1,     /* bad argument / call order                         */
+  MPLX_ERR_HIP = -2,     /* HIP runtime error (text in mplx_last_error)       */
+  MPLX_ERR_NO_DEVICE = -3,
+  MPLX_ERR_STATE = -4    /* map / controls / params not set before expand     */
+} mplx_status;
+
+/* Control::Control bit flags (reference include/mpl_basis/control.h:10-20). */
+enum {
+  MPLX_VEL = 0x01, MPLX_ACC = 0x03, MPLX_JRK = 0x07, MPLX_SNP = 0x0f,
+  MPLX_VELxYAW = 0x11, MPLX_ACCxYAW = 0x13, MPLX_JRKxYAW = 0x17, MPLX_SNPxYAW = 0x1f
+};
+
+/* Per-slot outcome.  The reference emits a successor for FINITE and BLOCKED
+ * (env_map.h:162-170: blocked edges are returned with cost = +inf) and skips
+ * the other two (env_map.h:158-160).                                         */
+enum {
+  MPLX_SLOT_SKIP_SAME = 0, /* successor == current node by lattice hash       */
+  MPLX_SLOT_FINITE = 1,
+  MPLX_SLOT_BLOCKED = 2,
+  MPLX_SLOT_SKIP_DYN = 3   /* validate_primitive rejected it                  */
+};
+
+/* The env parameter block: env_base.h:368-392 and env_map.h:294-296, set in
+ * the reference through PlannerBase::setVmax/... (planner_base.h:179-229).
+ * A limit <= 0 disables that check (primitive.h:485, :506).                  */
+typedef struct {
+  int32_t control;          /* control flag of every node of the search       */
+  int32_t reserved;
+  double dt;                /* env_base.h:392 dt_                             */
+  double w;                 /* env_base.h:370 w_                              */
+  double wyaw;              /* env_base.h:372 wyaw_                           */
+  double v_max, a_max, j_max, yaw_max; /* env_base.h:382-388                  */
+  double potential_weight;  /* env_map.h:294                                  */
+  double gradient_weight;   /* env_map.h:296                                  */
+} mplx_params;
+
+/* Dense successor slots, slot = node * nU + control_index, all arrays of
+ * length n_nodes * nU.  Any pointer may be NULL (that output is skipped).
+ * `state` is field-major with row stride `state_stride` (>= n_slots, in
+ * doubles): rows pos[0..D) vel[0..D) acc[0..D) jrk[0..D) yaw t  = 4D+2 rows,
+ * i.e. the reference Waypoint<Dim> payload (waypoint.h:32-37).  The state and
+ * hash of a skipped slot are still those of the candidate successor.
+ * cost is +inf unless status == MPLX_SLOT_FINITE.                            */
+typedef struct {
+  uint8_t *status;
+  double *cost;
+  uint64_t *hash;          /* waypoint.h:93-125, classic boost::hash_combine  */
+  double *state;
+  int64_t state_stride;
+  int32_t *iters;          /* diagnostic: executed sample-loop iterations     */
+} mplx_succ;
+
+/* ---- lifetime ----------------------------------------------------------- */
+/* dim = 2 or 3 (OccMapUtil / VoxelMapUtil).  device = HIP device ordinal.    */
+int mplx_create(int dim, int device, mplx_ctx **out);
+void mplx_destroy(mplx_ctx *ctx);
+/* Text of the last error of ctx (or of the last failed mplx_create if NULL). */
+const char *mplx_last_error(const mplx_ctx *ctx);
+int mplx_abi_version(void);
+
+/* ---- environment set-up (host pointers; copied to HBM, stream-ordered) --- */
+/* MapUtil<Dim>::setMap, map_util.h:84-90.  cells: int8, x fastest
+ * (getIndex, map_util.h:34-41); dim/origin have `dim` entries.               */
+int mplx_set_map(mplx_ctx *ctx, const int8_t *cells, const int32_t *dim, const double *origin,
+                 double res);
+/* env_map::set_potential_map, env_map.h:181-183.  NULL clears it.  Same size
+ * as the map.                                                                */
+int mplx_set_potential(mplx_ctx *ctx, const int8_t *cells_or_null);
+/* env_base::set_search_region, env_base.h:301-303.  One byte per cell
+ * (non-zero = inside), NULL clears it.                                       */
+int mplx_set_region(mplx_ctx *ctx, const uint8_t *cells_or_null);
+/* env_base setters, env_base.h:237-292.                                      */
+int mplx_set_params(mplx_ctx *ctx, const mplx_params *p);
+/* env_base::set_u, env_base.h:234.  U is [nU][udim] row-major; udim = D, or
+ * D+1 when the control flag carries yaw (last entry = yaw rate).             */
+int mplx_set_controls(mplx_ctx *ctx, const double *U, int32_t nU, int32_t udim);
+
+/* ---- expansion ---------------------------------------------------------- */
+/* Batched get_succ on device-resident buffers, asynchronous on the context
+ * stream.  d_nodes is field-major [4D+2][node_stride] (same rows as `state`),
+ * n_nodes <= node_stride.  All pointers in d_out are device pointers.        */
+int mplx_expand_device(mplx_ctx *ctx, const double *d_nodes, int64_t n_nodes, int64_t node_stride,
+                       const mplx_succ *d_out);
+/* Same with host buffers: H2D, kernel, D2H, synchronised on return.          */
+int mplx_expand(mplx_ctx *ctx, const double *h_nodes, int64_t n_nodes, int64_t node_stride,
+                const mplx_succ *h_out);
+/* Exactly env_base<Dim>::get_succ for one node (env_base.h:358-362): compact
+ * lists in ascending control index.  node: 4D+2 doubles.  succ: [nU][4D+2]
+ * doubles (waypoint-major), cost: [nU], action: [nU]; *n_succ receives the
+ * count.  Blocked successors are returned with cost = +inf, as the reference
+ * does (env_map.h:162-170).                                                  */
+int mplx_get_succ(mplx_ctx *ctx, const double *node, double *succ, double *cost, int32_t *action,
+                  int32_t *n_succ);
+
+/* ---- device memory + stream helpers (so any host language can keep the
+ *      frontier and the successor slots resident in HBM) ------------------- */
+int mplx_device_alloc(mplx_ctx *ctx, size_t bytes, void **dptr);
+int mplx_device_free(mplx_ctx *ctx, void *dptr);
+int mplx_memcpy_h2d(mplx_ctx *ctx, void *dst, const void *src, size_t bytes);
+int mplx_memcpy_d2h(mplx_ctx *ctx, void *dst, const void *src, size_t bytes);
+int mplx_memset(mplx_ctx *ctx, void *dst, int value, size_t bytes);
+int mplx_synchronize(mplx_ctx *ctx);
+/* HIP-event stopwatch on the context stream: begin ... (launches) ... end.
+ * mplx_timer_end synchronises and returns elapsed milliseconds.              */
+int mplx_timer_begin(mplx_ctx *ctx);
+int mplx_timer_end(mplx_ctx *ctx, float *ms);
+
+/* ---- diagnostics -------------------------------------------------------- */
+/* Element-wise device evaluation of the libm-class operations the path uses,
+ * for checking them against the host libm: op 0 a/b, 1 sqrt(a), 2 cos(a),
+ * 3 sin(a), 4 round(a), 5 ceil(a).  Host pointers, n elements.               */
+int mplx_selftest_math(mplx_ctx *ctx, int op, const double *a, const double *b, double *out,
+                       int64_t n);
+/* Fills name (up to cap bytes) with the device name and gcn arch.            */
+int mplx_device_info(mplx_ctx *ctx, char *name, size_t cap, int32_t *compute_units);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,101 @@
+"""ctypes binding of the C ABI in include/mplx.h (csrc/libmplx.so).
+
+There is no fallback: if the shared library is missing or cannot be loaded the
+import of the engine fails with an explicit error, and every compute call
+needs a gfx950 device (mplx_create fails without one).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libmplx.so")
+
+OK = 0
+ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_STATE = -1, -2, -3, -4
+
+# every symbol include/mplx.h declares, in declaration order
+SYMBOLS = [
+    "mplx_create", "mplx_destroy", "mplx_last_error", "mplx_abi_version",
+    "mplx_set_map", "mplx_set_potential", "mplx_set_region", "mplx_set_params", "mplx_set_controls",
+    "mplx_expand_device", "mplx_expand", "mplx_get_succ",
+    "mplx_device_alloc", "mplx_device_free", "mplx_memcpy_h2d", "mplx_memcpy_d2h", "mplx_memset",
+    "mplx_synchronize", "mplx_timer_begin", "mplx_timer_end",
+    "mplx_selftest_math", "mplx_device_info",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("control", C.c_int32), ("reserved", C.c_int32),
+        ("dt", C.c_double), ("w", C.c_double), ("wyaw", C.c_double),
+        ("v_max", C.c_double), ("a_max", C.c_double), ("j_max", C.c_double), ("yaw_max", C.c_double),
+        ("potential_weight", C.c_double), ("gradient_weight", C.c_double),
+    ]
+
+
+class Succ(C.Structure):
+    _fields_ = [
+        ("status", C.c_void_p), ("cost", C.c_void_p), ("hash", C.c_void_p),
+        ("state", C.c_void_p), ("state_stride", C.c_int64), ("iters", C.c_void_p),
+    ]
+
+
+class MplxError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("mplx error %d: %s" % (code, text))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libmplx.so (once).  Fails loudly when the HIP extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "motion_primitive_library_amd: %s is missing. Build it with "
+            "`python -m motion_primitive_library_amd.build` (needs hipcc); there is no CPU fallback."
+            % LIB_PATH)
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64.so not found
+        raise ImportError("motion_primitive_library_amd: cannot load %s: %s" % (LIB_PATH, e))
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    sig = {
+        "mplx_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(vp)]),
+        "mplx_destroy": (None, [vp]),
+        "mplx_last_error": (C.c_char_p, [vp]),
+        "mplx_abi_version": (C.c_int, []),
+        "mplx_set_map": (C.c_int, [vp, vp, vp, vp, dbl]),
+        "mplx_set_potential": (C.c_int, [vp, vp]),
+        "mplx_set_region": (C.c_int, [vp, vp]),
+        "mplx_set_params": (C.c_int, [vp, C.POINTER(Params)]),
+        "mplx_set_controls": (C.c_int, [vp, vp, i32, i32]),
+        "mplx_expand_device": (C.c_int, [vp, vp, i64, i64, C.POINTER(Succ)]),
+        "mplx_expand": (C.c_int, [vp, vp, i64, i64, C.POINTER(Succ)]),
+        "mplx_get_succ": (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(i32)]),
+        "mplx_device_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+        "mplx_device_free": (C.c_int, [vp, vp]),
+        "mplx_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "mplx_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "mplx_memset": (C.c_int, [vp, vp, C.c_int, C.c_size_t]),
+        "mplx_synchronize": (C.c_int, [vp]),
+        "mplx_timer_begin": (C.c_int, [vp]),
+        "mplx_timer_end": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "mplx_selftest_math": (C.c_int, [vp, C.c_int, vp, vp, vp, i64]),
+        "mplx_device_info": (C.c_int, [vp, C.c_char_p, C.c_size_t, C.POINTER(i32)]),
+    }
+    for name in SYMBOLS:
+        fn = getattr(L, name)  # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = sig[name]
+    _lib = L
+    return L
+
+
+def check(ctx, rc):
+    if rc != OK:
+        msg = lib().mplx_last_error(ctx)
+        raise MplxError(rc, msg.decode() if msg else "?")

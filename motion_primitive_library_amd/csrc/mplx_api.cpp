@@ -1,0 +1,455 @@
+// mplx_api.cpp -- the C ABI of libmplx.so (declared in include/mplx.h).
+//
+// Owns the per-context HIP state: one stream, the HBM-resident copies of the
+// map / potential / search-region / control table, staging buffers for the
+// host-pointer convenience calls, and a pair of events used as a stopwatch.
+// There is deliberately no CPU implementation behind this ABI: every compute
+// entry either runs the gfx950 kernels or returns an error.
+#include "../../include/mplx.h"
+#include "mplx_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct mplx_ctx {
+  int dim = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+
+  // environment (device copies)
+  DevBuf map, pot, region_bits, region_bytes, U;
+  bool has_map = false, has_pot = false, has_region = false, has_params = false, has_U = false;
+  int32_t mdim[3] = {1, 1, 1};
+  double origin[3] = {0, 0, 0};
+  double res = 0;
+  int64_t n_cells = 0;
+  mplx_params prm{};
+  int32_t nU = 0, udim = 0;
+
+  // staging for the host-pointer entry points
+  DevBuf s_nodes, s_status, s_cost, s_hash, s_state, s_iters;
+  std::vector<uint8_t> h_status;
+  std::vector<double> h_cost, h_state;
+};
+
+namespace {
+
+int fail(mplx_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                                   \
+  do {                                                                                     \
+    hipError_t e__ = (expr);                                                               \
+    if (e__ != hipSuccess)                                                                 \
+      return fail((c), MPLX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                  __FILE__, __LINE__);                                                     \
+  } while (0)
+
+int bind_device(mplx_ctx *c) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  return MPLX_OK;
+}
+
+int ensure(mplx_ctx *c, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return MPLX_OK;
+  if (b.p) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  HIP_TRY(c, hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return MPLX_OK;
+}
+
+void release(DevBuf &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+bool control_ok(int32_t control) {
+  switch (control) {
+    case MPLX_VEL: case MPLX_ACC: case MPLX_JRK: case MPLX_SNP:
+    case MPLX_VELxYAW: case MPLX_ACCxYAW: case MPLX_JRKxYAW: case MPLX_SNPxYAW:
+      return true;
+    default:
+      return false;
+  }
+}
+
+int ready(mplx_ctx *c) {
+  if (!c->has_map) return fail(c, MPLX_ERR_STATE, "mplx_set_map has not been called");
+  if (!c->has_params) return fail(c, MPLX_ERR_STATE, "mplx_set_params has not been called");
+  if (!c->has_U) return fail(c, MPLX_ERR_STATE, "mplx_set_controls has not been called");
+  const int need = c->dim + ((c->prm.control & 0x10) ? 1 : 0);
+  if (c->udim < need)
+    return fail(c, MPLX_ERR_STATE, "controls have %d entries per row, control flag 0x%x needs %d",
+                c->udim, c->prm.control, need);
+  return MPLX_OK;
+}
+
+mplx::ExpandArgs make_args(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride,
+                           const mplx_succ *o) {
+  mplx::ExpandArgs a{};
+  a.map = (const int8_t *)c->map.p;
+  a.pot = c->has_pot ? (const int8_t *)c->pot.p : nullptr;
+  a.region = c->has_region ? (const uint32_t *)c->region_bits.p : nullptr;
+  a.dim0 = c->mdim[0]; a.dim1 = c->mdim[1]; a.dim2 = c->mdim[2];
+  a.org0 = c->origin[0]; a.org1 = c->origin[1]; a.org2 = c->origin[2];
+  a.res = c->res;
+  a.dt = c->prm.dt; a.w = c->prm.w; a.wyaw = c->prm.wyaw;
+  a.v_max = c->prm.v_max; a.a_max = c->prm.a_max; a.j_max = c->prm.j_max; a.yaw_max = c->prm.yaw_max;
+  a.pot_w = c->prm.potential_weight; a.grad_w = c->prm.gradient_weight;
+  a.U = (const double *)c->U.p;
+  a.nU = c->nU; a.udim = c->udim;
+  a.nodes = d_nodes; a.n_nodes = n_nodes; a.node_stride = node_stride;
+  a.status = o->status; a.cost = o->cost; a.hash = o->hash; a.state = o->state;
+  a.state_stride = o->state_stride; a.iters = o->iters;
+  return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mplx_abi_version(void) { return MPLX_ABI_VERSION; }
+
+const char *mplx_last_error(const mplx_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int mplx_create(int dim, int device, mplx_ctx **out) {
+  if (!out) return fail(nullptr, MPLX_ERR_ARG, "mplx_create: out is NULL");
+  *out = nullptr;
+  if (dim != 2 && dim != 3) return fail(nullptr, MPLX_ERR_ARG, "mplx_create: dim must be 2 or 3, got %d", dim);
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, MPLX_ERR_NO_DEVICE,
+                "mplx_create: no HIP device available (%s); this engine has no CPU fallback",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= count)
+    return fail(nullptr, MPLX_ERR_ARG, "mplx_create: device %d out of range [0,%d)", device, count);
+  mplx_ctx *c = new (std::nothrow) mplx_ctx();
+  if (!c) return fail(nullptr, MPLX_ERR_ARG, "mplx_create: out of host memory");
+  c->dim = dim;
+  c->device = device;
+  e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e != hipSuccess) {
+    fail(nullptr, MPLX_ERR_HIP, "mplx_create: HIP set-up failed: %s", hipGetErrorString(e));
+    mplx_destroy(c);
+    return MPLX_ERR_HIP;
+  }
+  *out = c;
+  return MPLX_OK;
+}
+
+void mplx_destroy(mplx_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (DevBuf *b : {&c->map, &c->pot, &c->region_bits, &c->region_bytes, &c->U, &c->s_nodes, &c->s_status,
+                    &c->s_cost, &c->s_hash, &c->s_state, &c->s_iters})
+    release(*b);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int mplx_set_map(mplx_ctx *c, const int8_t *cells, const int32_t *dim, const double *origin, double res) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!cells || !dim || !origin) return fail(c, MPLX_ERR_ARG, "mplx_set_map: NULL argument");
+  if (!(res > 0)) return fail(c, MPLX_ERR_ARG, "mplx_set_map: resolution must be > 0");
+  int64_t n = 1;
+  for (int i = 0; i < c->dim; i++) {
+    if (dim[i] <= 0) return fail(c, MPLX_ERR_ARG, "mplx_set_map: dim[%d] = %d", i, dim[i]);
+    n *= dim[i];
+  }
+  if (n > 0x7fffffffLL)
+    return fail(c, MPLX_ERR_ARG, "mplx_set_map: %lld cells exceed the reference's int cell index",
+                (long long)n);
+  if (int rc = bind_device(c)) return rc;
+  if (n != c->n_cells) {  // a different grid invalidates potential and region
+    c->has_pot = false;
+    c->has_region = false;
+  }
+  if (int rc = ensure(c, c->map, (size_t)n)) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->map.p, cells, (size_t)n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller may free `cells` on return
+  for (int i = 0; i < 3; i++) {
+    c->mdim[i] = i < c->dim ? dim[i] : 1;
+    c->origin[i] = i < c->dim ? origin[i] : 0.0;
+  }
+  c->res = res;
+  c->n_cells = n;
+  c->has_map = true;
+  return MPLX_OK;
+}
+
+int mplx_set_potential(mplx_ctx *c, const int8_t *cells) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!cells) { c->has_pot = false; return MPLX_OK; }
+  if (!c->has_map) return fail(c, MPLX_ERR_STATE, "mplx_set_potential: set the map first");
+  if (int rc = bind_device(c)) return rc;
+  if (int rc = ensure(c, c->pot, (size_t)c->n_cells)) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->pot.p, cells, (size_t)c->n_cells, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->has_pot = true;
+  return MPLX_OK;
+}
+
+int mplx_set_region(mplx_ctx *c, const uint8_t *cells) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!cells) { c->has_region = false; return MPLX_OK; }
+  if (!c->has_map) return fail(c, MPLX_ERR_STATE, "mplx_set_region: set the map first");
+  if (int rc = bind_device(c)) return rc;
+  const size_t words = (size_t)((c->n_cells + 31) >> 5);
+  if (int rc = ensure(c, c->region_bytes, (size_t)c->n_cells)) return rc;
+  if (int rc = ensure(c, c->region_bits, words * 4)) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->region_bytes.p, cells, (size_t)c->n_cells, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, mplx::launch_pack_region((const uint8_t *)c->region_bytes.p, (uint32_t *)c->region_bits.p,
+                                      c->n_cells, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->has_region = true;
+  return MPLX_OK;
+}
+
+int mplx_set_params(mplx_ctx *c, const mplx_params *p) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!p) return fail(c, MPLX_ERR_ARG, "mplx_set_params: NULL");
+  if (!control_ok(p->control)) return fail(c, MPLX_ERR_ARG, "mplx_set_params: unknown control flag 0x%x", p->control);
+  if (!(p->dt > 0)) return fail(c, MPLX_ERR_ARG, "mplx_set_params: dt must be > 0");
+  c->prm = *p;
+  c->has_params = true;
+  return MPLX_OK;
+}
+
+int mplx_set_controls(mplx_ctx *c, const double *U, int32_t nU, int32_t udim) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!U || nU <= 0 || udim < c->dim || udim > c->dim + 1)
+    return fail(c, MPLX_ERR_ARG, "mplx_set_controls: need U != NULL, nU > 0, udim in {%d,%d}", c->dim, c->dim + 1);
+  if (int rc = bind_device(c)) return rc;
+  const size_t bytes = (size_t)nU * udim * sizeof(double);
+  if (int rc = ensure(c, c->U, bytes)) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->U.p, U, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->nU = nU;
+  c->udim = udim;
+  c->has_U = true;
+  return MPLX_OK;
+}
+
+int mplx_expand_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride,
+                       const mplx_succ *d_out) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!d_out || n_nodes < 0 || node_stride < n_nodes || (!d_nodes && n_nodes > 0))
+    return fail(c, MPLX_ERR_ARG, "mplx_expand_device: bad arguments");
+  if (int rc = ready(c)) return rc;
+  if (n_nodes == 0) return MPLX_OK;
+  const int64_t n_slots = n_nodes * c->nU;
+  if (d_out->state && d_out->state_stride < n_slots)
+    return fail(c, MPLX_ERR_ARG, "mplx_expand_device: state_stride %lld < n_slots %lld",
+                (long long)d_out->state_stride, (long long)n_slots);
+  if (int rc = bind_device(c)) return rc;
+  mplx::ExpandArgs a = make_args(c, d_nodes, n_nodes, node_stride, d_out);
+  HIP_TRY(c, mplx::launch_expand(c->dim, c->prm.control, a, c->stream));
+  return MPLX_OK;
+}
+
+int mplx_expand(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t node_stride,
+                const mplx_succ *h_out) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!h_out || n_nodes < 0 || node_stride < n_nodes || (!h_nodes && n_nodes > 0))
+    return fail(c, MPLX_ERR_ARG, "mplx_expand: bad arguments");
+  if (int rc = ready(c)) return rc;
+  if (n_nodes == 0) return MPLX_OK;
+  if (int rc = bind_device(c)) return rc;
+  const int F = 4 * c->dim + 2;
+  const int64_t n_slots = n_nodes * c->nU;
+  if (h_out->state && h_out->state_stride < n_slots)
+    return fail(c, MPLX_ERR_ARG, "mplx_expand: state_stride < n_slots");
+  // frontier: pack rows to stride n_nodes on the device
+  if (int rc = ensure(c, c->s_nodes, (size_t)F * n_nodes * sizeof(double))) return rc;
+  HIP_TRY(c, hipMemcpy2DAsync(c->s_nodes.p, (size_t)n_nodes * sizeof(double), h_nodes,
+                              (size_t)node_stride * sizeof(double), (size_t)n_nodes * sizeof(double), F,
+                              hipMemcpyHostToDevice, c->stream));
+  mplx_succ d{};
+  if (h_out->status) { if (int rc = ensure(c, c->s_status, (size_t)n_slots)) return rc; d.status = (uint8_t *)c->s_status.p; }
+  if (h_out->cost) { if (int rc = ensure(c, c->s_cost, (size_t)n_slots * 8)) return rc; d.cost = (double *)c->s_cost.p; }
+  if (h_out->hash) { if (int rc = ensure(c, c->s_hash, (size_t)n_slots * 8)) return rc; d.hash = (uint64_t *)c->s_hash.p; }
+  if (h_out->iters) { if (int rc = ensure(c, c->s_iters, (size_t)n_slots * 4)) return rc; d.iters = (int32_t *)c->s_iters.p; }
+  if (h_out->state) {
+    if (int rc = ensure(c, c->s_state, (size_t)F * n_slots * 8)) return rc;
+    d.state = (double *)c->s_state.p;
+    d.state_stride = n_slots;
+  }
+  mplx::ExpandArgs a = make_args(c, (const double *)c->s_nodes.p, n_nodes, n_nodes, &d);
+  HIP_TRY(c, mplx::launch_expand(c->dim, c->prm.control, a, c->stream));
+  if (h_out->status) HIP_TRY(c, hipMemcpyAsync(h_out->status, d.status, (size_t)n_slots, hipMemcpyDeviceToHost, c->stream));
+  if (h_out->cost) HIP_TRY(c, hipMemcpyAsync(h_out->cost, d.cost, (size_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
+  if (h_out->hash) HIP_TRY(c, hipMemcpyAsync(h_out->hash, d.hash, (size_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
+  if (h_out->iters) HIP_TRY(c, hipMemcpyAsync(h_out->iters, d.iters, (size_t)n_slots * 4, hipMemcpyDeviceToHost, c->stream));
+  if (h_out->state)
+    HIP_TRY(c, hipMemcpy2DAsync(h_out->state, (size_t)h_out->state_stride * 8, d.state, (size_t)n_slots * 8,
+                                (size_t)n_slots * 8, F, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MPLX_OK;
+}
+
+int mplx_get_succ(mplx_ctx *c, const double *node, double *succ, double *cost, int32_t *action,
+                  int32_t *n_succ) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!node || !succ || !cost || !action || !n_succ) return fail(c, MPLX_ERR_ARG, "mplx_get_succ: NULL argument");
+  if (int rc = ready(c)) return rc;
+  const int F = 4 * c->dim + 2;
+  const int nU = c->nU;
+  c->h_status.resize((size_t)nU);
+  c->h_cost.resize((size_t)nU);
+  c->h_state.resize((size_t)F * nU);
+  mplx_succ o{};
+  o.status = c->h_status.data();
+  o.cost = c->h_cost.data();
+  o.state = c->h_state.data();
+  o.state_stride = nU;
+  if (int rc = mplx_expand(c, node, 1, 1, &o)) return rc;
+  int32_t m = 0;
+  for (int i = 0; i < nU; i++) {
+    const uint8_t st = c->h_status[(size_t)i];
+    if (st != MPLX_SLOT_FINITE && st != MPLX_SLOT_BLOCKED) continue;
+    for (int f = 0; f < F; f++) succ[(size_t)m * F + f] = c->h_state[(size_t)f * nU + i];
+    cost[m] = c->h_cost[(size_t)i];
+    action[m] = i;
+    m++;
+  }
+  *n_succ = m;
+  return MPLX_OK;
+}
+
+int mplx_device_alloc(mplx_ctx *c, size_t bytes, void **dptr) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!dptr) return fail(c, MPLX_ERR_ARG, "mplx_device_alloc: NULL");
+  *dptr = nullptr;
+  if (int rc = bind_device(c)) return rc;
+  HIP_TRY(c, hipMalloc(dptr, bytes ? bytes : 1));
+  return MPLX_OK;
+}
+
+int mplx_device_free(mplx_ctx *c, void *dptr) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!dptr) return MPLX_OK;
+  if (int rc = bind_device(c)) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipFree(dptr));
+  return MPLX_OK;
+}
+
+int mplx_memcpy_h2d(mplx_ctx *c, void *dst, const void *src, size_t bytes) {
+  if (!c) return MPLX_ERR_ARG;
+  if (int rc = bind_device(c)) return rc;
+  HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MPLX_OK;
+}
+
+int mplx_memcpy_d2h(mplx_ctx *c, void *dst, const void *src, size_t bytes) {
+  if (!c) return MPLX_ERR_ARG;
+  if (int rc = bind_device(c)) return rc;
+  HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MPLX_OK;
+}
+
+int mplx_memset(mplx_ctx *c, void *dst, int value, size_t bytes) {
+  if (!c) return MPLX_ERR_ARG;
+  if (int rc = bind_device(c)) return rc;
+  HIP_TRY(c, hipMemsetAsync(dst, value, bytes, c->stream));
+  return MPLX_OK;
+}
+
+int mplx_synchronize(mplx_ctx *c) {
+  if (!c) return MPLX_ERR_ARG;
+  if (int rc = bind_device(c)) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MPLX_OK;
+}
+
+int mplx_timer_begin(mplx_ctx *c) {
+  if (!c) return MPLX_ERR_ARG;
+  if (int rc = bind_device(c)) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  return MPLX_OK;
+}
+
+int mplx_timer_end(mplx_ctx *c, float *ms) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!ms) return fail(c, MPLX_ERR_ARG, "mplx_timer_end: NULL");
+  if (int rc = bind_device(c)) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(c, hipEventSynchronize(c->ev1));
+  HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return MPLX_OK;
+}
+
+int mplx_selftest_math(mplx_ctx *c, int op, const double *a, const double *b, double *out, int64_t n) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!a || !out || n < 0 || (op == 0 && !b) || op < 0 || op > 5)
+    return fail(c, MPLX_ERR_ARG, "mplx_selftest_math: bad arguments");
+  if (n == 0) return MPLX_OK;
+  if (int rc = bind_device(c)) return rc;
+  void *da = nullptr, *db = nullptr, *dout = nullptr;
+  const size_t bytes = (size_t)n * sizeof(double);
+  HIP_TRY(c, hipMalloc(&da, bytes));
+  HIP_TRY(c, hipMalloc(&db, bytes));
+  HIP_TRY(c, hipMalloc(&dout, bytes));
+  HIP_TRY(c, hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(db, b ? b : a, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, mplx::launch_math_probe(op, (const double *)da, (const double *)db, (double *)dout, n, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(da);
+  (void)hipFree(db);
+  (void)hipFree(dout);
+  return MPLX_OK;
+}
+
+int mplx_device_info(mplx_ctx *c, char *name, size_t cap, int32_t *compute_units) {
+  if (!c) return MPLX_ERR_ARG;
+  hipDeviceProp_t prop;
+  HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+  if (name && cap) snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  return MPLX_OK;
+}
+
+}  // extern "C"

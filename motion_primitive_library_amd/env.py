@@ -1,0 +1,325 @@
+"""Host-side mirror of the reference's env_map<Dim> for the one path this
+package replaces: successor expansion.
+
+Names and argument meaning follow the reference so that code (and tests)
+written against MPL read the same:
+
+    reference                                   here
+    ----------------------------------------    -------------------------------
+    MapUtil<Dim>::setMap       map_util.h:84    EnvMap.setMap(origin, dim, map, res)
+    env_base::set_u            env_base.h:234   EnvMap.set_u(U)
+    env_base::set_v_max ...    env_base.h:237+  EnvMap.set_v_max(v) ...
+    env_base::set_dt/w/wyaw    env_base.h:264+  EnvMap.set_dt / set_w / set_wyaw
+    env_map::set_potential_map env_map.h:181    EnvMap.set_potential_map(map)
+    env_base::set_search_region env_base.h:301  EnvMap.set_search_region(mask)
+    env_map::get_succ          env_map.h:147    EnvMap.get_succ(curr) -> (succ, cost, action)
+
+plus the batched forms that are the point of the engine: EnvMap.expand(nodes)
+(host arrays) and EnvMap.expand_resident(frontier, slots) (HBM-resident).
+
+Everything below the method bodies is the C ABI of include/mplx.h; numpy is
+used only to own host buffers.  No CPU implementation exists here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+# Control::Control (reference include/mpl_basis/control.h:10-20)
+VEL, ACC, JRK, SNP = 0x01, 0x03, 0x07, 0x0F
+VELxYAW, ACCxYAW, JRKxYAW, SNPxYAW = 0x11, 0x13, 0x17, 0x1F
+
+SLOT_SKIP_SAME, SLOT_FINITE, SLOT_BLOCKED, SLOT_SKIP_DYN = 0, 1, 2, 3
+
+
+class Waypoint:
+    """Waypoint<Dim> (reference include/mpl_basis/waypoint.h:23-57)."""
+
+    __slots__ = ("dim", "pos", "vel", "acc", "jrk", "yaw", "t", "control")
+
+    def __init__(self, dim, control=0, pos=None, vel=None, acc=None, jrk=None, yaw=0.0, t=0.0):
+        self.dim = dim
+        self.control = control
+        z = np.zeros(dim)
+        self.pos = z.copy() if pos is None else np.asarray(pos, dtype=np.float64).copy()
+        self.vel = z.copy() if vel is None else np.asarray(vel, dtype=np.float64).copy()
+        self.acc = z.copy() if acc is None else np.asarray(acc, dtype=np.float64).copy()
+        self.jrk = z.copy() if jrk is None else np.asarray(jrk, dtype=np.float64).copy()
+        self.yaw = float(yaw)
+        self.t = float(t)
+
+    def to_row(self):
+        return np.concatenate([self.pos, self.vel, self.acc, self.jrk, [self.yaw, self.t]])
+
+    @classmethod
+    def from_row(cls, dim, control, row):
+        d = dim
+        return cls(dim, control, row[0:d], row[d:2 * d], row[2 * d:3 * d], row[3 * d:4 * d], row[4 * d],
+                   row[4 * d + 1])
+
+    def __repr__(self):
+        return "Waypoint(pos=%s, vel=%s, acc=%s, jrk=%s, yaw=%r, t=%r)" % (
+            self.pos.tolist(), self.vel.tolist(), self.acc.tolist(), self.jrk.tolist(), self.yaw, self.t)
+
+
+class DeviceArray:
+    """An HBM allocation made through the C ABI (mplx_device_alloc)."""
+
+    def __init__(self, env, nbytes):
+        self._env = env
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _abi.check(env._ctx, _abi.lib().mplx_device_alloc(env._ctx, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host)
+        assert host.nbytes <= self.nbytes
+        _abi.check(self._env._ctx, _abi.lib().mplx_memcpy_h2d(self._env._ctx, self.ptr, host.ctypes.data, host.nbytes))
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _abi.check(self._env._ctx, _abi.lib().mplx_memcpy_d2h(self._env._ctx, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr and self._env._ctx:
+            _abi.lib().mplx_device_free(self._env._ctx, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Slots:
+    """HBM-resident dense successor slots for n_nodes x nU pairs."""
+
+    def __init__(self, env, n_nodes, nU, want_state=True, want_iters=False):
+        self.n_nodes, self.nU = int(n_nodes), int(nU)
+        self.n_slots = self.n_nodes * self.nU
+        self.n_fields = env.n_fields
+        n = max(self.n_slots, 1)
+        self.status = DeviceArray(env, n)
+        self.cost = DeviceArray(env, n * 8)
+        self.hash = DeviceArray(env, n * 8)
+        self.state = DeviceArray(env, n * 8 * self.n_fields) if want_state else None
+        self.iters = DeviceArray(env, n * 4) if want_iters else None
+
+    def c_struct(self):
+        s = _abi.Succ()
+        s.status, s.cost, s.hash = self.status.ptr, self.cost.ptr, self.hash.ptr
+        s.state = self.state.ptr if self.state else None
+        s.state_stride = self.n_slots
+        s.iters = self.iters.ptr if self.iters else None
+        return s
+
+    def download(self):
+        out = {
+            "status": self.status.download(np.uint8, (self.n_slots,)),
+            "cost": self.cost.download(np.float64, (self.n_slots,)),
+            "hash": self.hash.download(np.uint64, (self.n_slots,)),
+        }
+        if self.state:
+            out["state"] = self.state.download(np.float64, (self.n_fields, self.n_slots))
+        if self.iters:
+            out["iters"] = self.iters.download(np.int32, (self.n_slots,))
+        return out
+
+    def free(self):
+        for b in (self.status, self.cost, self.hash, self.state, self.iters):
+            if b is not None:
+                b.free()
+
+
+class EnvMap:
+    """env_map<Dim> whose get_succ runs on the MI355X (reference env_map.h)."""
+
+    def __init__(self, dim, device=0):
+        if dim not in (2, 3):
+            raise ValueError("dim must be 2 or 3")
+        self.dim = dim
+        self._ctx = None
+        L = _abi.lib()
+        ctx = C.c_void_p()
+        rc = L.mplx_create(dim, device, C.byref(ctx))
+        if rc != _abi.OK:
+            msg = L.mplx_last_error(None)
+            raise _abi.MplxError(rc, msg.decode() if msg else "?")
+        self._ctx = ctx
+        # env_base.h:368-392 / env_map.h:294-296 defaults
+        self._p = _abi.Params()
+        self._p.control = ACC
+        self._p.dt, self._p.w, self._p.wyaw = 1.0, 10.0, 1.0
+        self._p.v_max = self._p.a_max = self._p.j_max = self._p.yaw_max = -1.0
+        self._p.potential_weight, self._p.gradient_weight = 0.1, 0.0
+        self._dirty = True
+        self.nU = 0
+        self.map_dim = None
+
+    # ---- lifetime
+    def close(self):
+        if self._ctx:
+            _abi.lib().mplx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_fields(self):
+        return 4 * self.dim + 2
+
+    def device_info(self):
+        buf = C.create_string_buffer(256)
+        cus = C.c_int32()
+        _abi.check(self._ctx, _abi.lib().mplx_device_info(self._ctx, buf, 256, C.byref(cus)))
+        return buf.value.decode(), cus.value
+
+    # ---- map (MapUtil<Dim>::setMap, map_util.h:84-90)
+    def setMap(self, origin, dim, cells, res):
+        cells = np.ascontiguousarray(cells, dtype=np.int8).ravel()
+        d = (C.c_int32 * 3)(*([int(x) for x in dim] + [1] * (3 - len(dim))))
+        o = (C.c_double * 3)(*([float(x) for x in origin] + [0.0] * (3 - len(origin))))
+        n = int(np.prod([int(x) for x in dim]))
+        if cells.size != n:
+            raise ValueError("map has %d cells, dim says %d" % (cells.size, n))
+        _abi.check(self._ctx, _abi.lib().mplx_set_map(self._ctx, cells.ctypes.data, d, o, float(res)))
+        self.map_dim = [int(x) for x in dim]
+        self._ncell = n
+
+    # ---- env_base / env_map setters
+    def set_control(self, control):
+        """The control flag of the search (Waypoint::control of the start node)."""
+        self._p.control = int(control)
+        self._dirty = True
+
+    def set_u(self, U):
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        if U.ndim != 2:
+            raise ValueError("U must be [nU][udim]")
+        _abi.check(self._ctx, _abi.lib().mplx_set_controls(self._ctx, U.ctypes.data, U.shape[0], U.shape[1]))
+        self.nU = U.shape[0]
+
+    def _setp(self, name, v):
+        setattr(self._p, name, float(v))
+        self._dirty = True
+
+    def set_v_max(self, v): self._setp("v_max", v)
+    def set_a_max(self, a): self._setp("a_max", a)
+    def set_j_max(self, j): self._setp("j_max", j)
+    def set_yaw_max(self, y): self._setp("yaw_max", y)
+    def set_dt(self, dt): self._setp("dt", dt)
+    def set_w(self, w): self._setp("w", w)
+    def set_wyaw(self, w): self._setp("wyaw", w)
+    def set_potential_weight(self, w): self._setp("potential_weight", w)
+    def set_gradient_weight(self, w): self._setp("gradient_weight", w)
+
+    def set_potential_map(self, cells):
+        if cells is None or len(cells) == 0:
+            _abi.check(self._ctx, _abi.lib().mplx_set_potential(self._ctx, None))
+            return
+        cells = np.ascontiguousarray(cells, dtype=np.int8).ravel()
+        if cells.size != self._ncell:
+            raise ValueError("potential map size mismatch")
+        _abi.check(self._ctx, _abi.lib().mplx_set_potential(self._ctx, cells.ctypes.data))
+
+    def set_search_region(self, mask):
+        if mask is None or len(mask) == 0:
+            _abi.check(self._ctx, _abi.lib().mplx_set_region(self._ctx, None))
+            return
+        mask = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8).ravel()
+        if mask.size != self._ncell:
+            raise ValueError("search region size mismatch")
+        _abi.check(self._ctx, _abi.lib().mplx_set_region(self._ctx, mask.ctypes.data))
+
+    def _flush(self):
+        if self._dirty:
+            _abi.check(self._ctx, _abi.lib().mplx_set_params(self._ctx, C.byref(self._p)))
+            self._dirty = False
+
+    # ---- get_succ, exactly the reference's contract (env_map.h:147-172)
+    def get_succ(self, curr):
+        """Returns (succ, succ_cost, action_idx): successors in ascending control
+        index; blocked ones are included with cost = +inf."""
+        self.set_control(curr.control) if curr.control != self._p.control else None
+        self._flush()
+        F, nU = self.n_fields, self.nU
+        node = np.ascontiguousarray(curr.to_row(), dtype=np.float64)
+        succ = np.empty((nU, F), dtype=np.float64)
+        cost = np.empty(nU, dtype=np.float64)
+        act = np.empty(nU, dtype=np.int32)
+        n = C.c_int32()
+        _abi.check(self._ctx, _abi.lib().mplx_get_succ(self._ctx, node.ctypes.data, succ.ctypes.data,
+                                                        cost.ctypes.data, act.ctypes.data, C.byref(n)))
+        m = n.value
+        return ([Waypoint.from_row(self.dim, curr.control, succ[i]) for i in range(m)],
+                cost[:m].tolist(), act[:m].tolist())
+
+    # ---- batched forms
+    def expand(self, nodes, want_state=True, want_iters=True):
+        """Dense expansion of a host frontier [4D+2][N]; returns host arrays."""
+        self._flush()
+        nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+        if nodes.ndim != 2 or nodes.shape[0] != self.n_fields:
+            raise ValueError("nodes must be [%d][N]" % self.n_fields)
+        n = nodes.shape[1]
+        ns = n * self.nU
+        out = {"status": np.empty(ns, np.uint8), "cost": np.empty(ns, np.float64),
+               "hash": np.empty(ns, np.uint64)}
+        s = _abi.Succ()
+        s.status, s.cost, s.hash = out["status"].ctypes.data, out["cost"].ctypes.data, out["hash"].ctypes.data
+        if want_state:
+            out["state"] = np.empty((self.n_fields, ns), np.float64)
+            s.state, s.state_stride = out["state"].ctypes.data, ns
+        if want_iters:
+            out["iters"] = np.empty(ns, np.int32)
+            s.iters = out["iters"].ctypes.data
+        _abi.check(self._ctx, _abi.lib().mplx_expand(self._ctx, nodes.ctypes.data, n, n, C.byref(s)))
+        return out
+
+    def upload_frontier(self, nodes):
+        nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+        if nodes.ndim != 2 or nodes.shape[0] != self.n_fields:
+            raise ValueError("nodes must be [%d][N]" % self.n_fields)
+        buf = DeviceArray(self, max(nodes.nbytes, 8))
+        buf.upload(nodes)
+        buf.n_nodes = nodes.shape[1]
+        return buf
+
+    def alloc_slots(self, n_nodes, want_state=True, want_iters=False):
+        return Slots(self, n_nodes, self.nU, want_state, want_iters)
+
+    def expand_resident(self, frontier, slots, n_nodes=None, node_offset=0):
+        """Asynchronous launch on HBM-resident buffers (mplx_expand_device)."""
+        self._flush()
+        n = frontier.n_nodes if n_nodes is None else int(n_nodes)
+        s = slots.c_struct()
+        _abi.check(self._ctx, _abi.lib().mplx_expand_device(
+            self._ctx, frontier.ptr + 8 * int(node_offset), n, frontier.n_nodes, C.byref(s)))
+
+    def synchronize(self):
+        _abi.check(self._ctx, _abi.lib().mplx_synchronize(self._ctx))
+
+    def timer_begin(self):
+        _abi.check(self._ctx, _abi.lib().mplx_timer_begin(self._ctx))
+
+    def timer_end(self):
+        ms = C.c_float()
+        _abi.check(self._ctx, _abi.lib().mplx_timer_end(self._ctx, C.byref(ms)))
+        return ms.value
+
+    def selftest_math(self, op, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = a if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        out = np.empty_like(a)
+        _abi.check(self._ctx, _abi.lib().mplx_selftest_math(self._ctx, int(op), a.ctypes.data, b.ctypes.data,
+                                                             out.ctypes.data, a.size))
+        return out

@@ -1,0 +1,202 @@
+"""ctypes front-end of the CPU parity oracle (oracle/libmpl_oracle.so).
+
+TEST INFRASTRUCTURE, NOT PRODUCT: only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module.  The shipped package
+(motion_primitive_library_amd) never does.
+
+The same front-end drives oracle/_ref/libmpl_ref.so (the reference's own
+headers compiled against stand-in Eigen/Boost headers), which exports the same
+C interface (oracle/mpl_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SKIP_SAME, FINITE, BLOCKED, SKIP_DYN = 0, 1, 2, 3
+
+# Control::Control (reference include/mpl_basis/control.h:10-20)
+VEL, ACC, JRK, SNP = 0x01, 0x03, 0x07, 0x0F
+VELxYAW, ACCxYAW, JRKxYAW, SNPxYAW = 0x11, 0x13, 0x17, 0x1F
+
+
+class _Env(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32), ("control", C.c_int32),
+        ("dt", C.c_double), ("w", C.c_double), ("wyaw", C.c_double),
+        ("v_max", C.c_double), ("a_max", C.c_double), ("j_max", C.c_double),
+        ("yaw_max", C.c_double),
+        ("potential_weight", C.c_double), ("gradient_weight", C.c_double),
+        ("map_dim", C.c_int32 * 3), ("origin", C.c_double * 3), ("res", C.c_double),
+        ("map", C.c_void_p), ("potential", C.c_void_p), ("region", C.c_void_p),
+        ("U", C.c_void_p), ("nU", C.c_int32), ("udim", C.c_int32),
+    ]
+
+
+class _Out(C.Structure):
+    _fields_ = [("status", C.c_void_p), ("cost", C.c_void_p), ("hash", C.c_void_p),
+                ("state", C.c_void_p), ("iters", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("pairs", C.c_int64), ("emitted", C.c_int64), ("finite", C.c_int64),
+                ("skip_same", C.c_int64), ("skip_dyn", C.c_int64), ("samples", C.c_int64),
+                ("sum_finite_cost", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build(ref=False):
+    """(Re)build the oracle with its Makefile; returns the library path."""
+    target = ["ref"] if ref else []
+    subprocess.run(["make", "-s", "-C", HERE] + target, check=True)
+    return os.path.join(HERE, "_ref", "libmpl_ref.so") if ref else os.path.join(HERE, "libmpl_oracle.so")
+
+
+def _bind(path):
+    lib = C.CDLL(path)
+    lib.mpl_oracle_expand.restype = C.c_int
+    lib.mpl_oracle_expand.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_int64, C.POINTER(_Out),
+                                      C.c_int, C.POINTER(Stats)]
+    lib.mpl_oracle_time_expand.restype = C.c_double
+    lib.mpl_oracle_time_expand.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                           C.POINTER(Stats)]
+    lib.mpl_oracle_hash.restype = C.c_uint64
+    lib.mpl_oracle_hash.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
+    lib.mpl_oracle_heur.restype = C.c_double
+    lib.mpl_oracle_heur.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    lib.mpl_oracle_loop_count.restype = C.c_int32
+    lib.mpl_oracle_loop_count.argtypes = [C.c_double, C.c_int32]
+    return lib
+
+
+_LIBS = {}
+
+
+def load(ref=False):
+    key = "ref" if ref else "port"
+    if key not in _LIBS:
+        path = (os.path.join(HERE, "_ref", "libmpl_ref.so") if ref
+                else os.path.join(HERE, "libmpl_oracle.so"))
+        if not os.path.exists(path):
+            build(ref=ref)
+        _LIBS[key] = _bind(path)
+    return _LIBS[key]
+
+
+class Env:
+    """Parameters + map of one environment (the oracle-side mirror of the
+    reference's env_map<Dim>: env_base.h:368-404, env_map.h:288-296)."""
+
+    def __init__(self, dim, control, U, map_cells, map_dim, origin, res, dt=1.0, w=10.0, wyaw=1.0,
+                 v_max=-1.0, a_max=-1.0, j_max=-1.0, yaw_max=-1.0, potential=None, region=None,
+                 potential_weight=0.1, gradient_weight=0.0):
+        self.dim, self.control = int(dim), int(control)
+        self.U = np.ascontiguousarray(U, dtype=np.float64)
+        assert self.U.ndim == 2
+        self.map = np.ascontiguousarray(map_cells, dtype=np.int8).ravel()
+        self.map_dim = [int(x) for x in map_dim] + [1] * (3 - len(map_dim))
+        self.origin = [float(x) for x in origin] + [0.0] * (3 - len(origin))
+        self.res = float(res)
+        ncell = int(np.prod(self.map_dim[: self.dim]))
+        assert self.map.size == ncell, (self.map.size, ncell)
+        self.potential = None if potential is None else np.ascontiguousarray(potential, dtype=np.int8).ravel()
+        self.region = None if region is None else np.ascontiguousarray(region, dtype=np.uint8).ravel()
+        self.dt, self.w, self.wyaw = float(dt), float(w), float(wyaw)
+        self.v_max, self.a_max, self.j_max, self.yaw_max = map(float, (v_max, a_max, j_max, yaw_max))
+        self.potential_weight, self.gradient_weight = float(potential_weight), float(gradient_weight)
+
+    @property
+    def n_fields(self):
+        return 4 * self.dim + 2
+
+    def _c(self):
+        e = _Env()
+        e.dim, e.control = self.dim, self.control
+        e.dt, e.w, e.wyaw = self.dt, self.w, self.wyaw
+        e.v_max, e.a_max, e.j_max, e.yaw_max = self.v_max, self.a_max, self.j_max, self.yaw_max
+        e.potential_weight, e.gradient_weight = self.potential_weight, self.gradient_weight
+        for i in range(3):
+            e.map_dim[i] = self.map_dim[i]
+            e.origin[i] = self.origin[i]
+        e.res = self.res
+        e.map = self.map.ctypes.data
+        e.potential = None if self.potential is None else self.potential.ctypes.data
+        e.region = None if self.region is None else self.region.ctypes.data
+        e.U = self.U.ctypes.data
+        e.nU, e.udim = self.U.shape
+        return e
+
+
+def make_nodes(dim, pos, vel=None, acc=None, jrk=None, yaw=None, t=None):
+    """Pack per-node arrays into the field-major [4D+2][N] layout."""
+    pos = np.atleast_2d(np.asarray(pos, dtype=np.float64))
+    n = pos.shape[0]
+    out = np.zeros((4 * dim + 2, n), dtype=np.float64)
+    for k, a in enumerate((pos, vel, acc, jrk)):
+        if a is not None:
+            out[k * dim:(k + 1) * dim, :] = np.atleast_2d(np.asarray(a, dtype=np.float64)).T
+    if yaw is not None:
+        out[4 * dim, :] = np.asarray(yaw, dtype=np.float64)
+    if t is not None:
+        out[4 * dim + 1, :] = np.asarray(t, dtype=np.float64)
+    return out
+
+
+def expand(env, nodes, threads=1, ref=False, want_state=True):
+    """Dense expansion. Returns dict(status, cost, hash, state, iters, stats)."""
+    lib = load(ref=ref)
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+    assert nodes.shape[0] == env.n_fields
+    n = nodes.shape[1]
+    nslots = n * env.U.shape[0]
+    res = {
+        "status": np.zeros(nslots, dtype=np.uint8),
+        "cost": np.zeros(nslots, dtype=np.float64),
+        "hash": np.zeros(nslots, dtype=np.uint64),
+        "state": np.zeros((env.n_fields, nslots), dtype=np.float64) if want_state else None,
+        "iters": np.zeros(nslots, dtype=np.int32),
+    }
+    o = _Out()
+    o.status, o.cost, o.hash = res["status"].ctypes.data, res["cost"].ctypes.data, res["hash"].ctypes.data
+    o.state = res["state"].ctypes.data if want_state else None
+    o.iters = res["iters"].ctypes.data
+    st = Stats()
+    ce = env._c()
+    rc = lib.mpl_oracle_expand(C.byref(ce), nodes.ctypes.data, n, C.byref(o), int(threads), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("mpl_oracle_expand failed: %d" % rc)
+    res["stats"] = st.as_dict()
+    return res
+
+
+def time_expand(env, nodes, threads=1, reps=1, ref=False):
+    lib = load(ref=ref)
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+    st = Stats()
+    ce = env._c()
+    sec = lib.mpl_oracle_time_expand(C.byref(ce), nodes.ctypes.data, nodes.shape[1], int(threads), int(reps),
+                                     C.byref(st))
+    if sec < 0:
+        raise RuntimeError("mpl_oracle_time_expand failed")
+    return sec, st.as_dict()
+
+
+def lattice_hash(dim, control, wp, ref=False):
+    wp = np.ascontiguousarray(wp, dtype=np.float64)
+    assert wp.size == 4 * dim + 2
+    return int(load(ref=ref).mpl_oracle_hash(dim, control, wp.ctypes.data))
+
+
+def heur(dim, control, w, v_max, wp, goal, ref=False):
+    wp = np.ascontiguousarray(wp, dtype=np.float64)
+    goal = np.ascontiguousarray(goal, dtype=np.float64)
+    return float(load(ref=ref).mpl_oracle_heur(dim, control, w, v_max, wp.ctypes.data, goal.ctypes.data))
+
+
+def loop_count(T, n, ref=False):
+    return int(load(ref=ref).mpl_oracle_loop_count(float(T), int(n)))
