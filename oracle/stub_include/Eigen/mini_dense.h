@@ -14,11 +14,14 @@
 #ifndef MPL_ORACLE_MINI_DENSE_H
 #define MPL_ORACLE_MINI_DENSE_H
 
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
+#include <iostream>
+#include <limits>
 #include <memory>
 #include <ostream>
 #include <vector>

@@ -1,0 +1,56 @@
+"""CPU: the C-ABI shared library loads, exports every symbol include/mplx.h
+declares, and fails loudly (no CPU fallback) when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mplx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mplx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_documented_entry_points():
+    syms = _declared_symbols()
+    for s in ("mplx_create", "mplx_destroy", "mplx_set_map", "mplx_set_potential", "mplx_set_region",
+              "mplx_set_params", "mplx_set_controls", "mplx_expand_device", "mplx_expand", "mplx_get_succ",
+              "mplx_last_error"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(engine):
+    lib = C.CDLL(engine._abi.LIB_PATH)
+    for s in _declared_symbols():
+        assert hasattr(lib, s), "libmplx.so does not export %s" % s
+    assert sorted(engine._abi.SYMBOLS) == sorted(set(_declared_symbols()) - {"mplx_status"})
+    assert engine._abi.lib().mplx_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header(engine):
+    # mplx_params: 2 x int32 + 9 doubles; mplx_succ: 4 pointers + int64 + pointer
+    assert C.sizeof(engine._abi.Params) == 8 + 9 * 8
+    assert C.sizeof(engine._abi.Succ) == 6 * 8
+
+
+def test_no_cpu_fallback(engine):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(engine._abi.MplxError) as e:
+        engine.EnvMap(3)
+    assert e.value.code == engine._abi.ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "motion_primitive_library_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "mpl_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f

@@ -213,3 +213,20 @@ def test_device_math_matches_host_libm(engine):
         print("device %s vs host libm: %.4f%% differ, max %.2f ulp" % (f.__name__, 100 * np.mean(d != h), ulp.max()))
         assert ulp.max() <= 2.0
     env.close()
+
+
+# ------------------------------------------- engine vs reference-made golden vectors
+from helpers import engine_env_from_case, golden_cases  # noqa: E402
+
+_GOLDEN = list(golden_cases())
+
+
+@pytest.mark.parametrize("name,case,exp", _GOLDEN, ids=[c[0] for c in _GOLDEN])
+def test_engine_reproduces_reference_golden_vectors(engine, name, case, exp):
+    """The committed fixture was produced by the reference's own get_succ
+    (tests/golden/make_golden.py); the HIP engine must reproduce it directly."""
+    env = engine_env_from_case(engine, case)
+    got = env.expand(case["nodes"])
+    env.close()
+    rtol = YAW_COST_RTOL if case["control"] & 0x10 else 0.0
+    assert_slots_equal(got, exp, cost_rtol=rtol, what=name)
