@@ -143,6 +143,71 @@ int mplx_synchronize(mplx_ctx *ctx);
 int mplx_timer_begin(mplx_ctx *ctx);
 int mplx_timer_end(mplx_ctx *ctx, float *ms);
 
+
+/* ---- host search around the device get_succ (the CALLER of the hot path) --
+ * MapPlanner<Dim>::plan == PlannerBase::plan + GraphSearch::Astar
+ * (reference include/mpl_planner/common/planner_base.h:275-325,
+ *  include/mpl_planner/common/graph_search.h:39-182).  The search itself stays
+ * on the host, as in the reference; only get_succ is served by the engine.
+ * With batch > 1 the planner expands the popped node together with the best
+ * unexpanded OPEN nodes in one launch and serves later pops from that cache;
+ * get_succ is a pure function of the node, so the plan is unchanged.         */
+typedef struct mplx_planner mplx_planner;
+
+/* env_base<Dim>::get_succ as a C hook (env_base.h:358-362): lets any other
+ * env implementation feed the search; same buffers as mplx_get_succ.         */
+typedef int (*mplx_succ_fn)(void *user, const double *node, double *succ, double *cost,
+                            int32_t *action, int32_t *n_succ);
+/* Batched hook: nodes field-major [4D+2][n]; dense slots out (status, cost,
+ * state [4D+2][n*nU]) exactly as mplx_expand fills them.                     */
+typedef int (*mplx_batch_fn)(void *user, const double *nodes, int64_t n, uint8_t *status,
+                             double *cost, double *state);
+
+typedef struct {
+  int32_t control;      /* control flag of start / goal (Waypoint::control)   */
+  int32_t max_expand;   /* PlannerBase::setMaxNum, planner_base.h:251; <=0 off */
+  int32_t batch;        /* nodes per launch; 1 = one-at-a-time like Astar     */
+  int32_t reserved;
+  double dt, w, v_max;  /* used by the heuristic (env_base.h:58-64)           */
+  double epsilon;       /* PlannerBase::setEpsilon, planner_base.h:238        */
+  double tol_pos, tol_vel, tol_acc, tol_yaw; /* setTol, planner_base.h:262    */
+} mplx_planner_config;
+
+typedef struct {
+  int32_t ok;              /* plan() return value                             */
+  int32_t expansions;      /* expand_iteration, graph_search.h:64             */
+  int32_t closed, opened, nodes; /* getCloseSet / getOpenSet sizes, hm_ size  */
+  int32_t device_launches; /* provider calls made                             */
+  int64_t pairs;           /* node x control pairs the provider evaluated     */
+  double cost;             /* traj_cost_ (goal g-value)                       */
+  double total_time;       /* Trajectory::getTotalTime                        */
+  double J[4];             /* Trajectory::J(VEL, ACC, JRK, SNP)               */
+  int32_t segments, reserved;
+} mplx_plan_summary;
+
+int mplx_planner_create(int dim, mplx_planner **out);
+void mplx_planner_destroy(mplx_planner *p);
+/* Product wiring: successors come from this engine context (mplx_get_succ /
+ * mplx_expand).  The context must outlive the planner.                       */
+int mplx_planner_attach_ctx(mplx_planner *p, mplx_ctx *ctx);
+/* Alternative wiring for other env implementations (either hook may be NULL). */
+int mplx_planner_set_provider(mplx_planner *p, mplx_succ_fn single, mplx_batch_fn batched, void *user);
+/* Host copy of the map for the start / goal tests (env_map.h:25-51).         */
+int mplx_planner_set_map(mplx_planner *p, const int8_t *cells, const int32_t *dim,
+                         const double *origin, double res);
+int mplx_planner_set_controls(mplx_planner *p, const double *U, int32_t nU, int32_t udim);
+int mplx_planner_configure(mplx_planner *p, const mplx_planner_config *cfg);
+/* start / goal: 4D+2 doubles each.  Returns 0 when the search ran (see
+ * out->ok for success), negative on provider / argument errors.              */
+int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, mplx_plan_summary *out);
+/* Trajectory of the last successful plan: segment start states [segments][4D+2]
+ * and the control index of each segment (env_base::forward_action).          */
+int mplx_planner_trajectory(mplx_planner *p, double *nodes, int32_t *actions, int32_t cap_segments);
+/* Closed-set positions of the last plan (PlannerBase::getCloseSet): fills up
+ * to cap points of D doubles; *n receives the closed-set size.               */
+int mplx_planner_closed_set(mplx_planner *p, double *pos, int32_t cap, int32_t *n);
+const char *mplx_planner_last_error(const mplx_planner *p);
+
 /* ---- diagnostics -------------------------------------------------------- */
 /* Element-wise device evaluation of the libm-class operations the path uses,
  * for checking them against the host libm: op 0 a/b, 1 sqrt(a), 2 cos(a),

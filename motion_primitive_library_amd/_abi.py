@@ -20,6 +20,9 @@ SYMBOLS = [
     "mplx_expand_device", "mplx_expand", "mplx_get_succ",
     "mplx_device_alloc", "mplx_device_free", "mplx_memcpy_h2d", "mplx_memcpy_d2h", "mplx_memset",
     "mplx_synchronize", "mplx_timer_begin", "mplx_timer_end",
+    "mplx_planner_create", "mplx_planner_destroy", "mplx_planner_attach_ctx", "mplx_planner_set_provider",
+    "mplx_planner_set_map", "mplx_planner_set_controls", "mplx_planner_configure", "mplx_planner_plan",
+    "mplx_planner_trajectory", "mplx_planner_closed_set", "mplx_planner_last_error",
     "mplx_selftest_math", "mplx_device_info",
 ]
 
@@ -37,6 +40,23 @@ class Succ(C.Structure):
     _fields_ = [
         ("status", C.c_void_p), ("cost", C.c_void_p), ("hash", C.c_void_p),
         ("state", C.c_void_p), ("state_stride", C.c_int64), ("iters", C.c_void_p),
+    ]
+
+
+class PlannerConfig(C.Structure):
+    _fields_ = [
+        ("control", C.c_int32), ("max_expand", C.c_int32), ("batch", C.c_int32), ("reserved", C.c_int32),
+        ("dt", C.c_double), ("w", C.c_double), ("v_max", C.c_double), ("epsilon", C.c_double),
+        ("tol_pos", C.c_double), ("tol_vel", C.c_double), ("tol_acc", C.c_double), ("tol_yaw", C.c_double),
+    ]
+
+
+class PlanSummary(C.Structure):
+    _fields_ = [
+        ("ok", C.c_int32), ("expansions", C.c_int32), ("closed", C.c_int32), ("opened", C.c_int32),
+        ("nodes", C.c_int32), ("device_launches", C.c_int32), ("pairs", C.c_int64),
+        ("cost", C.c_double), ("total_time", C.c_double), ("J", C.c_double * 4),
+        ("segments", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -85,6 +105,17 @@ def lib():
         "mplx_synchronize": (C.c_int, [vp]),
         "mplx_timer_begin": (C.c_int, [vp]),
         "mplx_timer_end": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "mplx_planner_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "mplx_planner_destroy": (None, [vp]),
+        "mplx_planner_attach_ctx": (C.c_int, [vp, vp]),
+        "mplx_planner_set_provider": (C.c_int, [vp, vp, vp, vp]),
+        "mplx_planner_set_map": (C.c_int, [vp, vp, vp, vp, dbl]),
+        "mplx_planner_set_controls": (C.c_int, [vp, vp, i32, i32]),
+        "mplx_planner_configure": (C.c_int, [vp, C.POINTER(PlannerConfig)]),
+        "mplx_planner_plan": (C.c_int, [vp, vp, vp, C.POINTER(PlanSummary)]),
+        "mplx_planner_trajectory": (C.c_int, [vp, vp, vp, i32]),
+        "mplx_planner_closed_set": (C.c_int, [vp, vp, i32, C.POINTER(i32)]),
+        "mplx_planner_last_error": (C.c_char_p, [vp]),
         "mplx_selftest_math": (C.c_int, [vp, C.c_int, vp, vp, vp, i64]),
         "mplx_device_info": (C.c_int, [vp, C.c_char_p, C.c_size_t, C.POINTER(i32)]),
     }

@@ -1,0 +1,476 @@
+// host_planner.hpp -- the CALLER of the hot path, kept on the host.
+//
+// A compact restatement of the search side of MPL on plain C++ types (no Eigen,
+// no Boost), so that MapPlanner::plan() exists end to end around the device
+// get_succ:
+//   GraphSearch::Astar / recoverTraj   reference include/mpl_planner/common/graph_search.h:39-182, 369-455
+//   State / StateSpace / compare_pair  reference include/mpl_planner/common/state_space.h:16-104
+//   PlannerBase::plan                  reference include/mpl_planner/common/planner_base.h:275-325
+//   env_map::is_goal / is_free(pt)     reference include/mpl_planner/env/env_map.h:25-51
+//   env_base::get_heur (default)       reference include/mpl_planner/common/env_base.h:46-64
+//   MapUtil::rayTrace / floatToInt     reference include/mpl_collision/map_util.h:103-134
+//   Primitive1D::J (any order)         reference include/mpl_basis/primitive.h:92-122
+// Successors come from a provider with the shape of env_base::get_succ
+// (env_base.h:358-362) -- in the product that is mplx_get_succ / mplx_expand on
+// the GPU; the planner itself never evaluates a primitive against the map.
+//
+// Batched expansion: get_succ is a pure function of the node,
+// so the planner may expand the popped node together with the best not yet
+// expanded OPEN nodes in one device launch and serve later pops from that
+// cache.  The search order, and therefore the plan, is unchanged.
+#ifndef MPLX_HOST_PLANNER_HPP
+#define MPLX_HOST_PLANNER_HPP
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <limits>
+#include <memory>
+#include <unordered_map>
+#include <vector>
+
+namespace mplx {
+namespace host {
+
+constexpr double kInf = std::numeric_limits<double>::infinity();
+
+// ---- lattice hash, identical to the device's (waypoint.h:93-125)
+inline void fold(uint64_t &seed, int id) {
+  seed ^= (uint64_t)(int64_t)id + 0x9e3779b9ULL + (seed << 6) + (seed >> 2);
+}
+inline uint64_t lattice_hash(int dim, int control, const double *w) {
+  uint64_t h = 0;
+  for (int i = 0; i < dim; i++) {
+    if (control & 1) fold(h, (int)std::round(w[0 * dim + i] / 0.01));
+    if (control & 2) fold(h, (int)std::round(w[1 * dim + i] / 0.1));
+    if (control & 4) fold(h, (int)std::round(w[2 * dim + i] / 0.1));
+    if (control & 8) fold(h, (int)std::round(w[3 * dim + i] / 0.1));
+  }
+  if (control & 16) fold(h, (int)std::round(w[4 * dim] / 0.1));
+  return h;
+}
+
+// ---- occupancy grid on the host (start / goal tests only)
+struct Grid {
+  int dim = 0;
+  int n[3] = {1, 1, 1};
+  double origin[3] = {0, 0, 0};
+  double res = 0;
+  std::vector<int8_t> cells;
+
+  void to_cell(const double *pt, int *pn) const {  // map_util.h:103-108
+    for (int i = 0; i < dim; i++) pn[i] = (int)std::round((pt[i] - origin[i]) / res - 0.5);
+  }
+  bool outside(const int *pn) const {
+    for (int i = 0; i < dim; i++)
+      if (pn[i] < 0 || pn[i] >= n[i]) return true;
+    return false;
+  }
+  int64_t index(const int *pn) const {
+    int64_t idx = pn[0] + (int64_t)n[0] * pn[1];
+    if (dim == 3) idx += (int64_t)n[0] * n[1] * pn[2];
+    return idx;
+  }
+  bool is_free(const int *pn) const {  // map_util.h:44,57-62
+    if (outside(pn)) return false;
+    const int8_t v = cells[(size_t)index(pn)];
+    return v < 100 && v >= 0;
+  }
+  bool is_occupied(const int *pn) const {  // map_util.h:48,64-69
+    if (outside(pn)) return false;
+    return cells[(size_t)index(pn)] == 100;
+  }
+  // map_util.h:117-134; returns false as soon as a traced cell is occupied
+  bool ray_clear(const double *p1, const double *p2) const {
+    double diff[3], m = 0;
+    for (int i = 0; i < dim; i++) {
+      diff[i] = p2[i] - p1[i];
+      m = std::max(m, std::abs(diff[i] / res));
+    }
+    const double k = 0.8;
+    const int max_diff = (int)(m / k);
+    const double s = 1.0 / max_diff;
+    double step[3];
+    for (int i = 0; i < dim; i++) step[i] = diff[i] * s;
+    int prev[3] = {-1, -1, -1};
+    for (int q = 1; q < max_diff; q++) {
+      double pt[3];
+      int pn[3];
+      for (int i = 0; i < dim; i++) pt[i] = p1[i] + step[i] * q;
+      to_cell(pt, pn);
+      if (outside(pn)) break;
+      bool differs = false;
+      for (int i = 0; i < dim; i++) differs = differs || pn[i] != prev[i];
+      if (differs && is_occupied(pn)) return false;
+      for (int i = 0; i < dim; i++) prev[i] = pn[i];
+    }
+    return true;
+  }
+};
+
+// ---- provider with the shape of env_base<Dim>::get_succ
+//      node: 4D+2 doubles; succ: [nU][4D+2]; returns 0 on success
+typedef int (*succ_fn)(void *user, const double *node, double *succ, double *cost, int32_t *action,
+                       int32_t *n_succ);
+// batched form: nodes field-major [4D+2][n]; outputs dense slots like mplx_expand
+typedef int (*batch_fn)(void *user, const double *nodes, int64_t n, uint8_t *status, double *cost,
+                        double *state /*[4D+2][n*nU]*/);
+
+struct Node;
+typedef std::shared_ptr<Node> NodePtr;
+
+// state_space.h:37-70 (A* fields)
+struct Node {
+  std::vector<double> coord;  // 4D+2
+  uint64_t key = 0;
+  std::vector<uint64_t> pred_key;
+  std::vector<int> pred_action;
+  std::vector<double> pred_cost;
+  double g = kInf, rhs = kInf, h = kInf;
+  bool opened = false, closed = false;
+  int heap_pos = -1;
+  // successor cache (batched expansion)
+  bool cached = false;
+  std::vector<double> c_succ;
+  std::vector<double> c_cost;
+  std::vector<int32_t> c_act;
+};
+
+// Mutable binary max-heap on compare_pair (state_space.h:16-34): the top is the
+// smallest f, ties go to the smaller min(g, rhs).  Sift rules follow a 2-ary
+// boost::heap::d_ary_heap: sift-up stops at equality, sift-down swaps at
+// equality and prefers the first maximal child.
+class OpenList {
+ public:
+  struct Item { double f; NodePtr n; };
+  bool empty() const { return q_.empty(); }
+  size_t size() const { return q_.size(); }
+  const Item &top() const { return q_.front(); }
+  const std::vector<Item> &items() const { return q_; }
+  void push(double f, const NodePtr &n) {
+    q_.push_back({f, n});
+    n->heap_pos = (int)q_.size() - 1;
+    up((int)q_.size() - 1);
+  }
+  void pop() {
+    q_.front().n->heap_pos = -1;
+    if (q_.size() > 1) {
+      std::swap(q_.front(), q_.back());
+      q_.pop_back();
+      q_.front().n->heap_pos = 0;
+      down(0);
+    } else {
+      q_.pop_back();
+    }
+  }
+  // key became better (smaller f): state_space `increase` (graph_search.h:133)
+  void increase(const NodePtr &n, double f) {
+    q_[(size_t)n->heap_pos].f = f;
+    up(n->heap_pos);
+  }
+
+ private:
+  static bool less(const Item &a, const Item &b) {
+    if (a.f == b.f) return std::min(a.n->g, a.n->rhs) > std::min(b.n->g, b.n->rhs);
+    return a.f > b.f;
+  }
+  void swap_at(int i, int j) {
+    std::swap(q_[(size_t)i], q_[(size_t)j]);
+    q_[(size_t)i].n->heap_pos = i;
+    q_[(size_t)j].n->heap_pos = j;
+  }
+  void up(int i) {
+    while (i > 0) {
+      const int p = (i - 1) / 2;
+      if (less(q_[(size_t)p], q_[(size_t)i])) { swap_at(p, i); i = p; } else return;
+    }
+  }
+  void down(int i) {
+    const int n = (int)q_.size();
+    for (;;) {
+      const int l = 2 * i + 1;
+      if (l >= n) return;
+      int c = l;
+      if (l + 1 < n && less(q_[(size_t)l], q_[(size_t)l + 1])) c = l + 1;
+      if (!less(q_[(size_t)c], q_[(size_t)i])) { swap_at(c, i); i = c; } else return;
+    }
+  }
+  std::vector<Item> q_;
+};
+
+// Primitive1D::J for an arbitrary effort order (primitive.h:92-122), used only
+// to report the trajectory's J(VEL..SNP) like the reference's tests do.
+inline double ipow(double t, int n) { double r = 1; while (n-- > 0) r *= t; return r; }
+inline double effort_1d(const double c[6], double t, int order) {
+  if (order == 1)
+    return c[0] * c[0] / 5184 * ipow(t, 9) + c[0] * c[1] / 576 * ipow(t, 8) +
+           (c[1] * c[1] / 252 + c[0] * c[2] / 168) * ipow(t, 7) + (c[0] * c[3] / 72 + c[1] * c[2] / 36) * ipow(t, 6) +
+           (c[2] * c[2] / 20 + c[0] * c[4] / 60 + c[1] * c[3] / 15) * ipow(t, 5) +
+           (c[2] * c[3] / 4 + c[1] * c[4] / 12) * ipow(t, 4) + (c[3] * c[3] / 3 + c[2] * c[4] / 3) * ipow(t, 3) +
+           c[3] * c[4] * t * t + c[4] * c[4] * t;
+  if (order == 2)
+    return c[0] * c[0] / 252 * ipow(t, 7) + c[0] * c[1] / 36 * ipow(t, 6) +
+           (c[1] * c[1] / 20 + c[0] * c[2] / 15) * ipow(t, 5) + (c[0] * c[3] / 12 + c[1] * c[2] / 4) * ipow(t, 4) +
+           (c[2] * c[2] / 3 + c[1] * c[3] / 3) * ipow(t, 3) + c[2] * c[3] * t * t + c[3] * c[3] * t;
+  if (order == 3)
+    return c[0] * c[0] / 20 * ipow(t, 5) + c[0] * c[1] / 4 * ipow(t, 4) + (c[1] * c[1] + c[0] * c[2]) / 3 * ipow(t, 3) +
+           c[1] * c[2] * t * t + c[2] * c[2] * t;
+  if (order == 4) return c[0] * c[0] / 3 * ipow(t, 3) + c[0] * c[1] * t * t + c[1] * c[1] * t;
+  return 0;
+}
+
+struct PlanResult {
+  bool ok = false;
+  double cost = kInf;
+  int expansions = 0;       // expand_iteration (graph_search.h:64)
+  int closed = 0, opened = 0, nodes = 0;
+  int device_launches = 0;  // provider calls actually made
+  int64_t pairs = 0;        // node x control pairs evaluated by the provider
+  double total_time = 0;
+  double J[4] = {0, 0, 0, 0};  // J(VEL), J(ACC), J(JRK), J(SNP) of the trajectory
+  std::vector<double> traj_nodes;  // [segments][4D+2] start state of each primitive
+  std::vector<int32_t> traj_actions;
+};
+
+class Planner {
+ public:
+  int dim = 2;
+  int control = 0x03;
+  double dt = 1.0, w = 10.0, v_max = -1.0, eps = 1.0;
+  double tol_pos = 0.5, tol_vel = -1, tol_acc = -1, tol_yaw = -1;
+  int max_expand = -1;
+  int batch = 1;  // nodes per provider launch (1 = the reference's one-at-a-time loop)
+  std::vector<double> U;
+  int nU = 0, udim = 0;
+  Grid grid;
+  succ_fn single = nullptr;
+  batch_fn batched = nullptr;
+  void *user = nullptr;
+
+  std::unordered_map<uint64_t, NodePtr> hm;
+  OpenList pq;
+  PlanResult last;
+
+  int F() const { return 4 * dim + 2; }
+
+  double heur(const double *s, const double *goal) const {  // env_base.h:46-64
+    if (lattice_hash(dim, control, s) == lattice_hash(dim, control, goal)) return 0;
+    double m = 0;
+    for (int i = 0; i < dim; i++) m = std::max(m, std::abs(s[i] - goal[i]));
+    return v_max > 0 ? w * m / v_max : w * m;
+  }
+
+  bool is_goal(const double *s, const double *goal) const {  // env_map.h:25-45
+    auto linf = [&](int off) {
+      double m = 0;
+      for (int i = 0; i < dim; i++) m = std::max(m, std::abs(s[off * dim + i] - goal[off * dim + i]));
+      return m;
+    };
+    bool goaled = linf(0) <= tol_pos;
+    if (goaled && tol_vel >= 0) goaled = linf(1) <= tol_vel;
+    if (goaled && tol_acc >= 0) goaled = linf(2) <= tol_acc;
+    if (goaled && tol_yaw >= 0) goaled = std::abs(s[4 * dim] - goal[4 * dim]) <= tol_yaw;
+    if (goaled && !grid.ray_clear(s, goal)) return false;
+    return goaled;
+  }
+
+  // PlannerBase::plan (A*), planner_base.h:275-325 + GraphSearch::Astar
+  int plan(const double *start, const double *goal) {
+    last = PlanResult();
+    hm.clear();
+    pq = OpenList();
+    if (!single && !batched) return -1;
+    int pn[3];
+    grid.to_cell(start, pn);
+    if (!grid.is_free(pn)) return 0;  // "start is not free": plan() == false
+    const int f = F();
+    if (is_goal(start, goal)) { last.ok = true; last.cost = 0; return 0; }
+
+    NodePtr curr = std::make_shared<Node>();
+    curr->coord.assign(start, start + f);
+    curr->key = lattice_hash(dim, control, start);
+    curr->g = 0;
+    curr->h = eps == 0 ? 0 : heur(start, goal);
+    curr->opened = true;
+    pq.push(curr->g + eps * curr->h, curr);
+    hm[curr->key] = curr;
+
+    std::vector<double> succ((size_t)nU * f), cost((size_t)nU);
+    std::vector<int32_t> act((size_t)nU);
+    int expand_iteration = 0;
+    bool reached = false;
+    for (;;) {
+      expand_iteration++;
+      curr = pq.top().n;
+      pq.pop();
+      curr->closed = true;
+      int32_t n_succ = 0;
+      if (int rc = successors(curr, succ.data(), cost.data(), act.data(), &n_succ)) return rc;
+      for (int s = 0; s < n_succ; s++) {
+        if (std::isinf(cost[(size_t)s])) continue;  // graph_search.h:81
+        const double *sc = &succ[(size_t)s * f];
+        const uint64_t key = lattice_hash(dim, control, sc);
+        NodePtr &child = hm[key];
+        if (!child) {
+          child = std::make_shared<Node>();
+          child->coord.assign(sc, sc + f);
+          child->key = key;
+          child->h = eps == 0 ? 0 : heur(sc, goal);
+        }
+        child->pred_key.push_back(curr->key);
+        child->pred_cost.push_back(cost[(size_t)s]);
+        child->pred_action.push_back(act[(size_t)s]);
+        const double tentative = curr->g + cost[(size_t)s];
+        if (tentative < child->g) {
+          child->g = tentative;
+          const double fval = child->g + eps * child->h;
+          if (child->opened && !child->closed) {
+            pq.increase(child, fval);
+          } else {
+            pq.push(fval, child);
+            child->opened = true;
+          }
+        }
+      }
+      if (is_goal(curr->coord.data(), goal)) { reached = true; break; }
+      if (max_expand > 0 && expand_iteration >= max_expand) break;
+      if (pq.empty()) break;
+    }
+    last.expansions = expand_iteration;
+    last.nodes = (int)hm.size();
+    for (const auto &it : hm) {
+      if (it.second->closed) last.closed++;
+      else if (it.second->opened) last.opened++;
+    }
+    if (!reached) return 0;
+    if (recover(curr, start)) { last.ok = true; last.cost = curr->g; }
+    return 0;
+  }
+
+ private:
+  // One get_succ, possibly served from / filling the batch cache.
+  int successors(const NodePtr &curr, double *succ, double *cost, int32_t *act, int32_t *n_succ) {
+    const int f = F();
+    if (batch <= 1 || !batched) {
+      last.device_launches++;
+      last.pairs += nU;
+      if (single) return single(user, curr->coord.data(), succ, cost, act, n_succ);
+      return run_batch({curr}), fetch(curr, succ, cost, act, n_succ);
+    }
+    if (!curr->cached) {
+      // the popped node plus the best open nodes that have no list yet
+      std::vector<NodePtr> group{curr};
+      std::vector<OpenList::Item> cand;
+      for (const auto &it : pq.items())
+        if (!it.n->cached) cand.push_back(it);
+      const size_t want = (size_t)batch - 1;
+      auto better = [](const OpenList::Item &a, const OpenList::Item &b) {
+        if (a.f != b.f) return a.f < b.f;
+        return std::min(a.n->g, a.n->rhs) < std::min(b.n->g, b.n->rhs);
+      };
+      if (cand.size() > want) {
+        std::partial_sort(cand.begin(), cand.begin() + (long)want, cand.end(), better);
+        cand.resize(want);
+      }
+      for (const auto &it : cand) group.push_back(it.n);
+      if (int rc = run_batch(group)) return rc;
+    }
+    (void)f;
+    return fetch(curr, succ, cost, act, n_succ);
+  }
+
+  int run_batch(const std::vector<NodePtr> &group) {
+    const int f = F();
+    const int64_t n = (int64_t)group.size();
+    std::vector<double> nodes((size_t)f * n);
+    for (int64_t k = 0; k < n; k++)
+      for (int r = 0; r < f; r++) nodes[(size_t)r * n + k] = group[(size_t)k]->coord[(size_t)r];
+    const int64_t slots = n * nU;
+    std::vector<uint8_t> st((size_t)slots);
+    std::vector<double> cs((size_t)slots), state((size_t)f * slots);
+    last.device_launches++;
+    last.pairs += slots;
+    if (int rc = batched(user, nodes.data(), n, st.data(), cs.data(), state.data())) return rc;
+    for (int64_t k = 0; k < n; k++) {
+      Node &nd = *group[(size_t)k];
+      nd.c_succ.clear(); nd.c_cost.clear(); nd.c_act.clear();
+      for (int i = 0; i < nU; i++) {
+        const int64_t s = k * nU + i;
+        if (st[(size_t)s] != 1 && st[(size_t)s] != 2) continue;  // emitted: finite or blocked
+        for (int r = 0; r < f; r++) nd.c_succ.push_back(state[(size_t)r * slots + s]);
+        nd.c_cost.push_back(cs[(size_t)s]);
+        nd.c_act.push_back(i);
+      }
+      nd.cached = true;
+    }
+    return 0;
+  }
+
+  int fetch(const NodePtr &n, double *succ, double *cost, int32_t *act, int32_t *n_succ) {
+    if (!n->cached) return -1;
+    std::copy(n->c_succ.begin(), n->c_succ.end(), succ);
+    std::copy(n->c_cost.begin(), n->c_cost.end(), cost);
+    std::copy(n->c_act.begin(), n->c_act.end(), act);
+    *n_succ = (int32_t)n->c_act.size();
+    n->c_succ.clear(); n->c_succ.shrink_to_fit();  // a closed node is never expanded again
+    return 0;
+  }
+
+  // GraphSearch::recoverTraj, graph_search.h:369-455
+  bool recover(NodePtr curr, const double *start) {
+    const int f = F();
+    const uint64_t start_key = lattice_hash(dim, control, start);
+    std::vector<std::vector<double>> from;
+    std::vector<int32_t> acts;
+    bool found = false;
+    while (!curr->pred_key.empty()) {
+      int min_id = -1;
+      double min_rhs = kInf, min_g = kInf;
+      for (size_t i = 0; i < curr->pred_key.size(); i++) {
+        const NodePtr &p = hm[curr->pred_key[i]];
+        const double v = p->g + curr->pred_cost[i];
+        if (min_rhs > v) { min_rhs = v; min_g = p->g; min_id = (int)i; }
+        else if (!std::isinf(curr->pred_cost[i]) && min_rhs == v) {
+          if (min_g < p->g) { min_g = p->g; min_id = (int)i; }
+        }
+      }
+      if (min_id < 0) break;
+      const int a = curr->pred_action[(size_t)min_id];
+      curr = hm[curr->pred_key[(size_t)min_id]];
+      from.push_back(curr->coord);
+      acts.push_back(a);
+      if (curr->key == start_key) { found = true; break; }
+    }
+    if (!found) return false;
+    std::reverse(from.begin(), from.end());
+    std::reverse(acts.begin(), acts.end());
+    // Trajectory(prs): total time and efforts (trajectory.h:52-57, 250-254)
+    const int K = (control & 8) ? 4 : (control & 4) ? 3 : (control & 2) ? 2 : 1;
+    for (size_t s = 0; s < from.size(); s++) {
+      const double *nd = from[s].data();
+      const double *u = &U[(size_t)acts[s] * udim];
+      last.total_time += dt;
+      for (int order = 1; order <= 4; order++) {
+        double j = 0;
+        for (int i = 0; i < dim; i++) {
+          double c[6] = {0, 0, 0, 0, 0, 0};
+          c[5] = nd[i];
+          if (K == 1) c[4] = u[i];
+          if (K == 2) { c[4] = nd[dim + i]; c[3] = u[i]; }
+          if (K == 3) { c[4] = nd[dim + i]; c[3] = nd[2 * dim + i]; c[2] = u[i]; }
+          if (K == 4) { c[4] = nd[dim + i]; c[3] = nd[2 * dim + i]; c[2] = nd[3 * dim + i]; c[1] = u[i]; }
+          j += effort_1d(c, dt, order);
+        }
+        last.J[order - 1] += j;
+      }
+      last.traj_nodes.insert(last.traj_nodes.end(), nd, nd + f);
+      last.traj_actions.push_back(acts[s]);
+    }
+    return true;
+  }
+};
+
+}  // namespace host
+}  // namespace mplx
+#endif

@@ -1,0 +1,165 @@
+// planner_capi.cpp -- C entry points of the host search (include/mplx.h,
+// "host search" section) on top of host_planner.hpp.
+#include "../../include/mplx.h"
+#include "host_planner.hpp"
+
+#include <new>
+#include <string>
+
+struct mplx_planner {
+  mplx::host::Planner pl;
+  mplx_ctx *ctx = nullptr;
+  std::string err;
+};
+
+namespace {
+
+// engine-backed providers
+int engine_single(void *user, const double *node, double *succ, double *cost, int32_t *action, int32_t *n) {
+  mplx_planner *p = (mplx_planner *)user;
+  return mplx_get_succ(p->ctx, node, succ, cost, action, n);
+}
+int engine_batch(void *user, const double *nodes, int64_t n, uint8_t *status, double *cost, double *state) {
+  mplx_planner *p = (mplx_planner *)user;
+  mplx_succ o{};
+  o.status = status;
+  o.cost = cost;
+  o.state = state;
+  o.state_stride = n * p->pl.nU;
+  return mplx_expand(p->ctx, nodes, n, n, &o);
+}
+
+int fail(mplx_planner *p, int code, const char *msg) {
+  if (p) p->err = msg;
+  return code;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mplx_planner_create(int dim, mplx_planner **out) {
+  if (!out || (dim != 2 && dim != 3)) return MPLX_ERR_ARG;
+  mplx_planner *p = new (std::nothrow) mplx_planner();
+  if (!p) return MPLX_ERR_ARG;
+  p->pl.dim = dim;
+  p->pl.grid.dim = dim;
+  *out = p;
+  return MPLX_OK;
+}
+
+void mplx_planner_destroy(mplx_planner *p) { delete p; }
+
+const char *mplx_planner_last_error(const mplx_planner *p) { return p ? p->err.c_str() : ""; }
+
+int mplx_planner_attach_ctx(mplx_planner *p, mplx_ctx *ctx) {
+  if (!p || !ctx) return MPLX_ERR_ARG;
+  p->ctx = ctx;
+  p->pl.single = engine_single;
+  p->pl.batched = engine_batch;
+  p->pl.user = p;
+  return MPLX_OK;
+}
+
+int mplx_planner_set_provider(mplx_planner *p, mplx_succ_fn single, mplx_batch_fn batched, void *user) {
+  if (!p || (!single && !batched)) return MPLX_ERR_ARG;
+  p->ctx = nullptr;
+  p->pl.single = single;
+  p->pl.batched = batched;
+  p->pl.user = user;
+  return MPLX_OK;
+}
+
+int mplx_planner_set_map(mplx_planner *p, const int8_t *cells, const int32_t *dim, const double *origin,
+                         double res) {
+  if (!p || !cells || !dim || !origin || !(res > 0)) return fail(p, MPLX_ERR_ARG, "mplx_planner_set_map: bad arguments");
+  size_t n = 1;
+  for (int i = 0; i < p->pl.dim; i++) {
+    if (dim[i] <= 0) return fail(p, MPLX_ERR_ARG, "mplx_planner_set_map: bad dim");
+    p->pl.grid.n[i] = dim[i];
+    p->pl.grid.origin[i] = origin[i];
+    n *= (size_t)dim[i];
+  }
+  p->pl.grid.res = res;
+  p->pl.grid.cells.assign(cells, cells + n);
+  return MPLX_OK;
+}
+
+int mplx_planner_set_controls(mplx_planner *p, const double *U, int32_t nU, int32_t udim) {
+  if (!p || !U || nU <= 0 || udim < p->pl.dim) return fail(p, MPLX_ERR_ARG, "mplx_planner_set_controls: bad arguments");
+  p->pl.U.assign(U, U + (size_t)nU * udim);
+  p->pl.nU = nU;
+  p->pl.udim = udim;
+  return MPLX_OK;
+}
+
+int mplx_planner_configure(mplx_planner *p, const mplx_planner_config *c) {
+  if (!p || !c) return MPLX_ERR_ARG;
+  p->pl.control = c->control;
+  p->pl.max_expand = c->max_expand;
+  p->pl.batch = c->batch < 1 ? 1 : c->batch;
+  p->pl.dt = c->dt;
+  p->pl.w = c->w;
+  p->pl.v_max = c->v_max;
+  p->pl.eps = c->epsilon;
+  p->pl.tol_pos = c->tol_pos;
+  p->pl.tol_vel = c->tol_vel;
+  p->pl.tol_acc = c->tol_acc;
+  p->pl.tol_yaw = c->tol_yaw;
+  return MPLX_OK;
+}
+
+int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, mplx_plan_summary *out) {
+  if (!p || !start || !goal || !out) return MPLX_ERR_ARG;
+  if (p->pl.grid.cells.empty()) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: map not set");
+  if (p->pl.nU <= 0) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: controls not set");
+  if (!p->pl.single && !p->pl.batched) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: no successor provider attached");
+  const int rc = p->pl.plan(start, goal);
+  if (rc != 0) {
+    p->err = "successor provider failed";
+    if (p->ctx) p->err += std::string(": ") + mplx_last_error(p->ctx);
+    return rc < 0 ? rc : MPLX_ERR_HIP;
+  }
+  const mplx::host::PlanResult &r = p->pl.last;
+  out->ok = r.ok ? 1 : 0;
+  out->expansions = r.expansions;
+  out->closed = r.closed;
+  out->opened = r.opened;
+  out->nodes = r.nodes;
+  out->device_launches = r.device_launches;
+  out->pairs = r.pairs;
+  out->cost = r.cost;
+  out->total_time = r.total_time;
+  for (int i = 0; i < 4; i++) out->J[i] = r.J[i];
+  out->segments = (int32_t)r.traj_actions.size();
+  out->reserved = 0;
+  return MPLX_OK;
+}
+
+int mplx_planner_trajectory(mplx_planner *p, double *nodes, int32_t *actions, int32_t cap) {
+  if (!p || !nodes || !actions) return MPLX_ERR_ARG;
+  const mplx::host::PlanResult &r = p->pl.last;
+  const int f = p->pl.F();
+  const int32_t n = (int32_t)r.traj_actions.size();
+  if (cap < n) return fail(p, MPLX_ERR_ARG, "mplx_planner_trajectory: capacity too small");
+  for (int32_t s = 0; s < n; s++) {
+    for (int k = 0; k < f; k++) nodes[(size_t)s * f + k] = r.traj_nodes[(size_t)s * f + k];
+    actions[s] = r.traj_actions[(size_t)s];
+  }
+  return MPLX_OK;
+}
+
+int mplx_planner_closed_set(mplx_planner *p, double *pos, int32_t cap, int32_t *n) {
+  if (!p || !n) return MPLX_ERR_ARG;
+  int32_t m = 0;
+  for (const auto &it : p->pl.hm) {
+    if (!it.second->closed) continue;
+    if (pos && m < cap)
+      for (int i = 0; i < p->pl.dim; i++) pos[(size_t)m * p->pl.dim + i] = it.second->coord[(size_t)i];
+    m++;
+  }
+  *n = m;
+  return MPLX_OK;
+}
+
+}  // extern "C"

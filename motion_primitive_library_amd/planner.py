@@ -1,0 +1,165 @@
+"""Host-side mirror of the reference's MapPlanner<Dim> (the caller of the hot
+path): same method names and argument meaning as
+
+    PlannerBase  reference include/mpl_planner/common/planner_base.h:170-325
+    MapPlanner   reference include/mpl_planner/planner/map_planner.h,
+                 src/mpl_planner/map_planner.cpp:14-18 (setMapUtil)
+
+The A* itself is the C++ host search inside libmplx.so (csrc/host_planner.hpp);
+successors come from the engine context (get_succ on the MI355X).  Tests may
+plug another provider through set_provider() -- that is how the CPU oracle is
+run under the very same search to pin config C1.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from .env import EnvMap, Waypoint
+
+
+class MapUtil:
+    """MapUtil<Dim> as far as the planner needs it (map_util.h:84-90)."""
+
+    def __init__(self, dim):
+        self.dim = dim
+        self.origin = self.map_dim = self.cells = self.res = None
+
+    def setMap(self, origin, dim, cells, res):
+        self.origin = [float(x) for x in origin]
+        self.map_dim = [int(x) for x in dim]
+        self.cells = np.ascontiguousarray(cells, dtype=np.int8).ravel()
+        self.res = float(res)
+        assert self.cells.size == int(np.prod(self.map_dim))
+
+
+class Trajectory:
+    """What the reference's tests read off Trajectory<Dim> (trajectory.h)."""
+
+    def __init__(self, total_time, J, nodes, actions, cost):
+        self._T, self._J, self.nodes, self.actions, self.cost = total_time, J, nodes, actions, cost
+
+    def getTotalTime(self):
+        return self._T
+
+    def J(self, control):
+        order = {0x01: 0, 0x03: 1, 0x07: 2, 0x0F: 3}[control & 0x0F]
+        return self._J[order]
+
+
+class MapPlanner:
+    def __init__(self, dim, device=0, verbose=False, provider=None):
+        """provider=None: successors from the HIP engine on `device` (the product
+        path; needs a GPU).  provider=(single_fn_ptr, batch_fn_ptr, user_ptr):
+        raw C hooks of another env implementation (tests: the CPU oracle)."""
+        self.dim = dim
+        self._L = _abi.lib()
+        p = C.c_void_p()
+        rc = self._L.mplx_planner_create(dim, C.byref(p))
+        if rc != 0:
+            raise _abi.MplxError(rc, "mplx_planner_create failed")
+        self._p = p
+        self._cfg = _abi.PlannerConfig()
+        self._cfg.control, self._cfg.max_expand, self._cfg.batch = 0x03, -1, 1
+        self._cfg.dt, self._cfg.w, self._cfg.v_max, self._cfg.epsilon = 1.0, 10.0, -1.0, 1.0
+        self._cfg.tol_pos, self._cfg.tol_vel, self._cfg.tol_acc, self._cfg.tol_yaw = 0.5, -1.0, -1.0, -1.0
+        self.env = None
+        self._keep = provider
+        if provider is None:
+            self.env = EnvMap(dim, device)
+            self._check(self._L.mplx_planner_attach_ctx(self._p, self.env._ctx))
+        else:
+            single, batched, user = provider
+            self._check(self._L.mplx_planner_set_provider(self._p, single, batched, user))
+        self._summary = None
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._L.mplx_planner_last_error(self._p)
+            raise _abi.MplxError(rc, msg.decode() if msg else "?")
+
+    def close(self):
+        if self._p:
+            self._L.mplx_planner_destroy(self._p)
+            self._p = None
+        if self.env is not None:
+            self.env.close()
+            self.env = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- MapPlanner / PlannerBase setters (same names as the reference)
+    def setMapUtil(self, map_util):
+        d = (C.c_int32 * 3)(*(map_util.map_dim + [1] * (3 - len(map_util.map_dim))))
+        o = (C.c_double * 3)(*(map_util.origin + [0.0] * (3 - len(map_util.origin))))
+        self._check(self._L.mplx_planner_set_map(self._p, map_util.cells.ctypes.data, d, o, map_util.res))
+        if self.env is not None:
+            self.env.setMap(map_util.origin, map_util.map_dim, map_util.cells, map_util.res)
+
+    def setU(self, U):
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        self._check(self._L.mplx_planner_set_controls(self._p, U.ctypes.data, U.shape[0], U.shape[1]))
+        if self.env is not None:
+            self.env.set_u(U)
+
+    def _env(self, name, v):
+        if self.env is not None:
+            getattr(self.env, name)(v)
+
+    def setVmax(self, v): self._cfg.v_max = float(v); self._env("set_v_max", v)
+    def setAmax(self, a): self._env("set_a_max", a)
+    def setJmax(self, j): self._env("set_j_max", j)
+    def setYawmax(self, y): self._env("set_yaw_max", y)
+    def setDt(self, dt): self._cfg.dt = float(dt); self._env("set_dt", dt)
+    def setW(self, w): self._cfg.w = float(w); self._env("set_w", w)
+    def setWyaw(self, w): self._env("set_wyaw", w)
+    def setEpsilon(self, eps): self._cfg.epsilon = float(eps)
+    def setMaxNum(self, n): self._cfg.max_expand = int(n)
+
+    def setTol(self, tol_pos, tol_vel=-1.0, tol_acc=-1.0):
+        self._cfg.tol_pos, self._cfg.tol_vel, self._cfg.tol_acc = float(tol_pos), float(tol_vel), float(tol_acc)
+
+    def setBatch(self, n):
+        """Nodes per device launch (1 = the reference's one-node-at-a-time loop)."""
+        self._cfg.batch = int(n)
+
+    # ---- PlannerBase::plan
+    def plan(self, start, goal):
+        self._cfg.control = int(start.control)
+        if self.env is not None:
+            self.env.set_control(start.control)
+            self.env._flush()
+        self._check(self._L.mplx_planner_configure(self._p, C.byref(self._cfg)))
+        s = np.ascontiguousarray(start.to_row(), dtype=np.float64)
+        g = np.ascontiguousarray(goal.to_row(), dtype=np.float64)
+        out = _abi.PlanSummary()
+        self._check(self._L.mplx_planner_plan(self._p, s.ctypes.data, g.ctypes.data, C.byref(out)))
+        self._summary = out
+        return bool(out.ok)
+
+    def summary(self):
+        o = self._summary
+        return {k: getattr(o, k) for k in ("ok", "expansions", "closed", "opened", "nodes", "device_launches",
+                                           "pairs", "cost", "total_time", "segments")} | {"J": list(o.J)}
+
+    def getCloseSet(self):
+        n = C.c_int32()
+        self._check(self._L.mplx_planner_closed_set(self._p, None, 0, C.byref(n)))
+        pts = np.empty((n.value, self.dim), dtype=np.float64)
+        self._check(self._L.mplx_planner_closed_set(self._p, pts.ctypes.data, n.value, C.byref(n)))
+        return pts
+
+    def getTraj(self):
+        o = self._summary
+        f = 4 * self.dim + 2
+        nodes = np.empty((max(o.segments, 1), f), dtype=np.float64)
+        acts = np.empty(max(o.segments, 1), dtype=np.int32)
+        self._check(self._L.mplx_planner_trajectory(self._p, nodes.ctypes.data, acts.ctypes.data, max(o.segments, 1)))
+        return Trajectory(o.total_time, list(o.J), nodes[:o.segments], acts[:o.segments], o.cost)
+
+    def getTrajCost(self):
+        return self._summary.cost

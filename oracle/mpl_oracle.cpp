@@ -609,6 +609,48 @@ double mpl_oracle_time_expand(const mpl_oracle_env *env, const double *nodes, in
   return best;
 }
 
+}  // extern "C"
+
+template <int D>
+static int get_succ_lists(const mpl_oracle_env *e, const double *node, double *succ, double *cost,
+                          int32_t *action, int32_t *n_succ) {
+  Env<D> env{e, {}, {}};
+  std::vector<State<D>> s;
+  std::vector<double> c;
+  std::vector<int> a;
+  env.expand_node(load_state<D>(node, 1, 0, e->control), s, c, a, nullptr);
+  const int F = 4 * D + 2;
+  for (size_t m = 0; m < s.size(); m++) {
+    double *o = succ + m * F;
+    for (int i = 0; i < D; i++) {
+      o[0 * D + i] = s[m].pos[i]; o[1 * D + i] = s[m].vel[i];
+      o[2 * D + i] = s[m].acc[i]; o[3 * D + i] = s[m].jrk[i];
+    }
+    o[4 * D] = s[m].yaw;
+    o[4 * D + 1] = s[m].t;
+    cost[m] = c[m];
+    action[m] = a[m];
+  }
+  *n_succ = (int32_t)s.size();
+  return 0;
+}
+
+extern "C" {
+
+int mpl_oracle_get_succ(void *user, const double *node, double *succ, double *cost, int32_t *action,
+                        int32_t *n_succ) {
+  const mpl_oracle_env *e = (const mpl_oracle_env *)user;
+  if (!env_ok(e) || !node || !succ || !cost || !action || !n_succ) return -1;
+  return e->dim == 2 ? get_succ_lists<2>(e, node, succ, cost, action, n_succ)
+                     : get_succ_lists<3>(e, node, succ, cost, action, n_succ);
+}
+
+int mpl_oracle_batch(void *user, const double *nodes, int64_t n, uint8_t *status, double *cost,
+                     double *state) {
+  mpl_oracle_out o = {status, cost, nullptr, state, nullptr};
+  return mpl_oracle_expand((const mpl_oracle_env *)user, nodes, n, &o, 1, nullptr);
+}
+
 uint64_t mpl_oracle_hash(int32_t dim, int32_t control, const double *wp) {
   if (dim == 2) return lattice_hash(load_state<2>(wp, 1, 0, control));
   return lattice_hash(load_state<3>(wp, 1, 0, control));

@@ -77,6 +77,17 @@ double mpl_oracle_time_expand(const mpl_oracle_env *env, const double *nodes,
                               int64_t n_nodes, int threads, int reps,
                               mpl_oracle_stats *stats);
 
+/* env_base<Dim>::get_succ for one node in the reference's own list form
+ * (env_map.h:147-172): successors in ascending control index, blocked ones
+ * included with cost = +inf.  `user` is a const mpl_oracle_env*.  node: 4D+2
+ * doubles; succ: [nU][4D+2].  Signature = mplx_succ_fn of include/mplx.h so a
+ * test can plug the oracle into the host search.                             */
+int mpl_oracle_get_succ(void *user, const double *node, double *succ, double *cost,
+                        int32_t *action, int32_t *n_succ);
+/* Batched dense form with the signature of mplx_batch_fn.                    */
+int mpl_oracle_batch(void *user, const double *nodes, int64_t n, uint8_t *status, double *cost,
+                     double *state);
+
 /* Lattice hash of one waypoint given as 4D+2 doubles (waypoint.h:93-125).   */
 uint64_t mpl_oracle_hash(int32_t dim, int32_t control, const double *wp);
 

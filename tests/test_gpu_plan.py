@@ -1,0 +1,46 @@
+"""GPU: BASELINE config C1 end to end on the engine -- MapPlanner.plan() with
+get_succ served by the MI355X -- against the README pins and the oracle run."""
+import time
+
+import numpy as np
+import pytest
+
+from test_plan_known_answer import corridor, run_c1
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan_on_gpu(m, batch):
+    c = corridor()
+    U = m.workloads.grid_controls([-0.5, 0.0, 0.5], 2)
+    planner = m.MapPlanner(2, device=0)
+    mu = m.MapUtil(2)
+    mu.setMap(c["origin"], c["dim"], c["cells"], c["res"])
+    planner.setMapUtil(mu)
+    planner.setVmax(1.0)
+    planner.setAmax(1.0)
+    planner.setDt(1.0)
+    planner.setU(U)
+    planner.setBatch(batch)
+    start = m.Waypoint(2, m.ACC, pos=c["start"])
+    goal = m.Waypoint(2, m.ACC, pos=c["goal"])
+    planner.plan(start, goal)  # warm-up (first launch loads the code object)
+    t0 = time.perf_counter()
+    ok = planner.plan(start, goal)
+    dt = time.perf_counter() - t0
+    s, traj, closed = planner.summary(), planner.getTraj(), planner.getCloseSet()
+    planner.close()
+    return ok, s, traj, closed, dt
+
+
+@pytest.mark.parametrize("batch", [1, 64, 256])
+def test_c1_plan_on_engine_matches_reference_pins(engine, batch):
+    ok, s, traj, closed, dt = _plan_on_gpu(engine, batch)
+    print("C1 plan() on MI355X, batch=%d: %.2f ms, %d launches, %d pairs" % (batch, dt * 1e3, s["device_launches"], s["pairs"]))
+    assert ok and s["closed"] == 615 and closed.shape == (615, 2)
+    assert traj.getTotalTime() == 35.0 and traj.J(engine.VEL) == 36.75 and traj.J(engine.ACC) == 1.5
+    assert s["cost"] == 351.5
+    # identical trajectory to the oracle-driven search
+    ok_o, s_o, traj_o, _ = run_c1(engine, batch=1)
+    assert np.array_equal(traj.actions, traj_o.actions) and np.array_equal(traj.nodes, traj_o.nodes)
+    assert s["expansions"] == s_o["expansions"] and s["nodes"] == s_o["nodes"]

@@ -1,0 +1,103 @@
+"""CPU: BASELINE config C1 -- test_planner_2d on data/corridor.yaml, Control::ACC,
+|U| = 9 -- run through the host search of libmplx.so with the CPU ORACLE plugged
+in as the successor provider (plumbing, no GPU).
+
+Pins (reference README.md:199-202, the console transcript of test_planner_2d):
+    "MPL Planner expanded states: 615"     -> closed set size
+    "Total time T: 35.000000"              -> trajectory duration
+    "Total J:  J(VEL) = 36.750000, J(ACC) = 1.500000, J(JRK) = 0, J(SNP) = 0"
+This is the one result the reference itself publishes for this path; the
+oracle (and, when present, the reference's own get_succ from oracle/_ref) must
+reproduce it under the restated A*.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "corridor_map.npz")
+
+
+def corridor():
+    z = np.load(GOLD)
+    n = int(z["n_cells"])
+    occ = np.unpackbits(z["occupied_bits"])[:n].astype(bool)
+    cells = np.where(occ, 100, 0).astype(np.int8)  # read_map.hpp:42-45: data > 0 -> 100 else 0
+    return dict(cells=cells, dim=[int(x) for x in z["dim"]], origin=[float(x) for x in z["origin"]],
+                res=float(z["resolution"]), start=z["start"], goal=z["goal"], raw_counts=z["raw_counts"])
+
+
+def provider_from_oracle(oenv, ref=False):
+    lib = O.load(ref=ref)
+    ce = oenv._c()
+    single = C.cast(lib.mpl_oracle_get_succ, C.c_void_p)
+    batched = C.cast(lib.mpl_oracle_batch, C.c_void_p)
+    user = C.cast(C.pointer(ce), C.c_void_p)
+    return (single, batched, user), ce  # keep `ce` alive as long as the planner
+
+
+def run_c1(engine, ref=False, batch=1):
+    m = engine
+    c = corridor()
+    U = m.workloads.grid_controls([-0.5, 0.0, 0.5], 2)  # test_planner_2d.cpp:49-53
+    oenv = O.Env(2, O.ACC, U, c["cells"], c["dim"], c["origin"], c["res"], v_max=1.0, a_max=1.0, dt=1.0)
+    prov, keep = provider_from_oracle(oenv, ref=ref)
+    planner = m.MapPlanner(2, provider=prov)
+    mu = m.MapUtil(2)
+    mu.setMap(c["origin"], c["dim"], c["cells"], c["res"])
+    planner.setMapUtil(mu)
+    planner.setVmax(1.0)
+    planner.setAmax(1.0)
+    planner.setDt(1.0)
+    planner.setU(U)
+    planner.setBatch(batch)
+    start = m.Waypoint(2, m.ACC, pos=c["start"])
+    goal = m.Waypoint(2, m.ACC, pos=c["goal"])
+    ok = planner.plan(start, goal)
+    s = planner.summary()
+    traj = planner.getTraj()
+    closed = planner.getCloseSet()
+    planner.close()
+    del keep
+    return ok, s, traj, closed
+
+
+def test_fixture_matches_the_reference_file():
+    c = corridor()
+    assert c["dim"] == [799, 199] and c["res"] == 0.05 and c["origin"] == [0.0, -5.0]
+    assert c["start"].tolist() == [2.5, -3.5] and c["goal"].tolist() == [37.0, 2.5]
+    assert c["raw_counts"].tolist() == [123934, 0, 35067]  # raw values {-1, 100}
+    assert int((c["cells"] == 100).sum()) == 35067
+
+
+def test_c1_known_answer_with_oracle(engine):
+    ok, s, traj, closed = run_c1(engine)
+    assert ok
+    assert s["closed"] == 615 and closed.shape == (615, 2)   # README.md:200
+    assert traj.getTotalTime() == 35.0                        # README.md:201
+    assert traj.J(engine.VEL) == 36.75 and traj.J(engine.ACC) == 1.5  # README.md:202
+    assert traj.J(engine.JRK) == 0.0 and traj.J(engine.SNP) == 0.0
+    assert s["cost"] == 351.5 and s["segments"] == 35         # g = w*T + J(ACC) = 10*35 + 1.5
+    assert s["device_launches"] == s["expansions"] and s["pairs"] == 9 * s["expansions"]
+
+
+def test_c1_batched_expansion_gives_the_same_plan(engine):
+    ok1, s1, t1, c1 = run_c1(engine, batch=1)
+    ok2, s2, t2, c2 = run_c1(engine, batch=64)
+    assert ok1 and ok2
+    for k in ("closed", "expansions", "cost", "total_time", "segments", "nodes", "opened"):
+        assert s1[k] == s2[k], k
+    assert np.array_equal(t1.actions, t2.actions) and np.array_equal(t1.nodes, t2.nodes)
+    assert s2["device_launches"] < s1["device_launches"] / 5  # far fewer provider launches
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(O.HERE, "_ref", "libmpl_ref.so")),
+                    reason="oracle/_ref not built")
+def test_c1_known_answer_with_reference_get_succ(engine):
+    """Same search, successors from the reference's own env_map::get_succ."""
+    ok, s, traj, _ = run_c1(engine, ref=True)
+    assert ok and s["closed"] == 615 and traj.getTotalTime() == 35.0
+    assert traj.J(engine.VEL) == 36.75 and traj.J(engine.ACC) == 1.5 and s["cost"] == 351.5
