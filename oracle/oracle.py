@@ -200,3 +200,36 @@ def heur(dim, control, w, v_max, wp, goal, ref=False):
 
 def loop_count(T, n, ref=False):
     return int(load(ref=ref).mpl_oracle_loop_count(float(T), int(n)))
+
+
+# ---- the reference's own MapPlanner::plan (oracle/_ref/libmpl_ref_planner.so)
+class RefPlanOut(C.Structure):
+    _fields_ = [("ok", C.c_int32), ("closed", C.c_int32), ("opened", C.c_int32), ("expansions", C.c_int32),
+                ("segments", C.c_int32), ("hm_size", C.c_int32), ("cost", C.c_double), ("total_time", C.c_double),
+                ("J", C.c_double * 4), ("wall_ms", C.c_double)]
+
+
+REF_PLANNER_SO = os.path.join(HERE, "_ref", "libmpl_ref_planner.so")
+
+
+def ref_plan(env, start_row, goal_row, use_gpu=False, epsilon=1.0, reps=1):
+    """Runs the reference's unmodified MapPlanner<Dim>::plan (A*).  use_gpu=True
+    swaps in MPL::GpuMapPlanner from include/mplx_env_map.hpp (the drop-in
+    adapter over libmplx.so) -- needs a GPU."""
+    if "ref_planner" not in _LIBS:
+        lib = C.CDLL(REF_PLANNER_SO)
+        lib.mpl_ref_plan.restype = C.c_int
+        lib.mpl_ref_plan.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int,
+                                     C.POINTER(RefPlanOut)]
+        _LIBS["ref_planner"] = lib
+    s = np.ascontiguousarray(start_row, dtype=np.float64)
+    g = np.ascontiguousarray(goal_row, dtype=np.float64)
+    out = RefPlanOut()
+    ce = env._c()
+    rc = _LIBS["ref_planner"].mpl_ref_plan(C.byref(ce), s.ctypes.data, g.ctypes.data, int(bool(use_gpu)),
+                                            float(epsilon), int(reps), C.byref(out))
+    if rc != 0:
+        raise RuntimeError("mpl_ref_plan failed: %d" % rc)
+    return {"ok": bool(out.ok), "closed": out.closed, "opened": out.opened, "expansions": out.expansions,
+            "segments": out.segments, "cost": out.cost, "total_time": out.total_time, "J": list(out.J),
+            "wall_ms": out.wall_ms}

@@ -44,3 +44,25 @@ def test_c1_plan_on_engine_matches_reference_pins(engine, batch):
     ok_o, s_o, traj_o, _ = run_c1(engine, batch=1)
     assert np.array_equal(traj.actions, traj_o.actions) and np.array_equal(traj.nodes, traj_o.nodes)
     assert s["expansions"] == s_o["expansions"] and s["nodes"] == s_o["nodes"]
+
+
+def test_c1_reference_planner_with_dropin_adapter(engine):
+    """THE drop-in test: the reference's own MapPlanner / GraphSearch / StateSpace
+    code, with only env_map::get_succ replaced by include/mplx_env_map.hpp over
+    libmplx.so (oracle/_ref/libmpl_ref_planner.so, prebuilt where the reference
+    tree exists).  Must reproduce README.md:199-202."""
+    import os
+    from oracle import oracle as O
+    if not os.path.exists(O.REF_PLANNER_SO):
+        pytest.skip("oracle/_ref/libmpl_ref_planner.so not built")
+    c = corridor()
+    U = engine.workloads.grid_controls([-0.5, 0.0, 0.5], 2)
+    oenv = O.Env(2, O.ACC, U, c["cells"], c["dim"], c["origin"], c["res"], v_max=1.0, a_max=1.0, dt=1.0)
+    start = engine.Waypoint(2, engine.ACC, pos=c["start"]).to_row()
+    goal = engine.Waypoint(2, engine.ACC, pos=c["goal"]).to_row()
+    gpu = O.ref_plan(oenv, start, goal, use_gpu=True, reps=2)
+    cpu = O.ref_plan(oenv, start, goal, use_gpu=False, reps=2)
+    print("reference MapPlanner::plan C1: CPU env_map %.2f ms, GpuMapPlanner adapter %.2f ms" % (cpu["wall_ms"], gpu["wall_ms"]))
+    for k in ("ok", "closed", "opened", "expansions", "segments", "cost", "total_time", "J"):
+        assert gpu[k] == cpu[k], k
+    assert gpu["closed"] == 615 and gpu["total_time"] == 35.0 and gpu["J"][:2] == [36.75, 1.5]

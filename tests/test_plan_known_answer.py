@@ -101,3 +101,20 @@ def test_c1_known_answer_with_reference_get_succ(engine):
     ok, s, traj, _ = run_c1(engine, ref=True)
     assert ok and s["closed"] == 615 and traj.getTotalTime() == 35.0
     assert traj.J(engine.VEL) == 36.75 and traj.J(engine.ACC) == 1.5 and s["cost"] == 351.5
+
+
+@pytest.mark.skipif(not os.path.exists(O.REF_PLANNER_SO), reason="oracle/_ref/libmpl_ref_planner.so not built")
+def test_c1_reference_planner_itself_and_host_search_agree(engine):
+    """The reference's unmodified MapPlanner::plan (its own A*, StateSpace and
+    get_succ, compiled against the stand-in Eigen/Boost) on config C1: hits the
+    README pins, and our restated host search expands exactly as many nodes."""
+    c = corridor()
+    U = engine.workloads.grid_controls([-0.5, 0.0, 0.5], 2)
+    oenv = O.Env(2, O.ACC, U, c["cells"], c["dim"], c["origin"], c["res"], v_max=1.0, a_max=1.0, dt=1.0)
+    start = engine.Waypoint(2, engine.ACC, pos=c["start"]).to_row()
+    goal = engine.Waypoint(2, engine.ACC, pos=c["goal"]).to_row()
+    r = O.ref_plan(oenv, start, goal, use_gpu=False)
+    assert r["ok"] and r["closed"] == 615 and r["total_time"] == 35.0
+    assert r["J"] == [36.75, 1.5, 0.0, 0.0] and r["cost"] == 351.5
+    ok, s, traj, _ = run_c1(engine)
+    assert s["expansions"] == r["expansions"] and s["opened"] == r["opened"] and s["segments"] == r["segments"]
