@@ -80,8 +80,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="map edge scale (debug only; invalidates the metric)")
     ap.add_argument("--nodes", type=int, default=None, help="frontier size override (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--compact", action="store_true",
-                    help="write only status/cost/hash (17 B/slot) instead of the full Waypoint record")
+    ap.add_argument("--output", default="lists", choices=["lists", "dense", "dense-compact"],
+                    help="lists: per-node successor lists, the reference's output shape (count, action, cost, hash, "
+                         "full Waypoint) -- default; dense: one 129-B slot per pair; dense-compact: status+cost+hash only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,7 +118,12 @@ def main():
     env = m.EnvMap(wl.dim, local_rank)
     wl.apply(env)
     frontier = env.upload_frontier(wl.nodes)
-    slots = env.alloc_slots(wl.n_nodes, want_state=not args.compact, want_iters=False)
+    if args.output == "lists":
+        slots = env.alloc_lists(wl.n_nodes, want_state=True, want_iters=False)
+        launch = lambda: env.expand_lists_resident(frontier, slots)
+    else:
+        slots = env.alloc_slots(wl.n_nodes, want_state=(args.output == "dense"), want_iters=False)
+        launch = lambda: env.expand_resident(frontier, slots)
     dev_name, cus = env.device_info()
 
     # ---- one untimed verification launch: counts for the algorithmic bytes
@@ -137,12 +143,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        env.expand_resident(frontier, slots)
+        launch()
     barrier()
     t0 = time.perf_counter()
     env.timer_begin()
     for _ in range(args.steps):
-        env.expand_resident(frontier, slots)
+        launch()
     kernel_ms_total = env.timer_end()  # HIP events on the engine's own stream
     barrier()
     elapsed = time.perf_counter() - t0
@@ -177,7 +183,9 @@ def main():
                                                            " [DEBUG scale=%g nodes=%s]" % (args.scale, args.nodes)),
                 "frontier_nodes_per_gpu": wl.n_nodes, "controls": int(wl.U.shape[0]), "dim": wl.dim,
                 "pairs_per_step_per_gpu": wl.n_pairs, "map_cells": int(wl.grid.size),
-                "output": "status+cost+hash" if args.compact else "status+cost+hash+full Waypoint (4D+2 doubles)",
+                "output": {"lists": "per-node successor lists: count + action + cost + hash + full Waypoint (4D+2 doubles), emitted successors only",
+                           "dense": "dense slots: status + cost + hash + full Waypoint for every pair",
+                           "dense-compact": "dense slots: status + cost + hash"}[args.output],
                 "sharding": "frontier nodes block-partitioned over ranks, map replicated, no collective",
                 "device": dev_name, "compute_units": cus,
             },

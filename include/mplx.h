@@ -130,6 +130,33 @@ int mplx_expand(mplx_ctx *ctx, const double *h_nodes, int64_t n_nodes, int64_t n
 int mplx_get_succ(mplx_ctx *ctx, const double *node, double *succ, double *cost, int32_t *action,
                   int32_t *n_succ);
 
+/* Per-node successor LISTS -- the reference's own output shape (succ,
+ * succ_cost, action_idx of env_base.h:358-362) for a whole frontier.  Node k
+ * owns the entries [k*nU, k*nU + count[k]) of every array, in ascending control
+ * index; blocked successors are included with cost = +inf (env_map.h:162-170),
+ * skipped ones are not.  Only emitted successors are written, so this is the
+ * bandwidth-lean output (SURVEY.md 8d counts exactly these bytes).  Any pointer
+ * but `count` may be NULL.  `state` as in mplx_succ (row stride state_stride >=
+ * n_nodes*nU doubles).                                                       */
+typedef struct {
+  int32_t *count;          /* [n_nodes]                                       */
+  int32_t *action;         /* [n_nodes*nU] control index of each successor    */
+  double *cost;            /* [n_nodes*nU]                                    */
+  uint64_t *hash;          /* [n_nodes*nU]                                    */
+  double *state;           /* [4D+2][state_stride]                            */
+  int64_t state_stride;
+  int32_t *iters;          /* diagnostic: executed sample-loop iterations     */
+} mplx_succ_lists;
+
+/* Batched get_succ producing lists; device pointers, asynchronous on the
+ * context stream.  Uses the tiled kernel (expand_tile_kernel.hip) where it
+ * applies and otherwise the dense kernel followed by an on-device compaction. */
+int mplx_expand_lists_device(mplx_ctx *ctx, const double *d_nodes, int64_t n_nodes, int64_t node_stride,
+                             const mplx_succ_lists *d_out);
+/* Same with host buffers (H2D, kernels, D2H of the used prefix, synchronised). */
+int mplx_expand_lists(mplx_ctx *ctx, const double *h_nodes, int64_t n_nodes, int64_t node_stride,
+                      const mplx_succ_lists *h_out);
+
 /* ---- device memory + stream helpers (so any host language can keep the
  *      frontier and the successor slots resident in HBM) ------------------- */
 int mplx_device_alloc(mplx_ctx *ctx, size_t bytes, void **dptr);

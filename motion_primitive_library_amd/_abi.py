@@ -17,7 +17,7 @@ ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_STATE = -1, -2, -3, -4
 SYMBOLS = [
     "mplx_create", "mplx_destroy", "mplx_last_error", "mplx_abi_version",
     "mplx_set_map", "mplx_set_potential", "mplx_set_region", "mplx_set_params", "mplx_set_controls",
-    "mplx_expand_device", "mplx_expand", "mplx_get_succ",
+    "mplx_expand_device", "mplx_expand", "mplx_expand_lists_device", "mplx_expand_lists", "mplx_get_succ",
     "mplx_device_alloc", "mplx_device_free", "mplx_memcpy_h2d", "mplx_memcpy_d2h", "mplx_memset",
     "mplx_synchronize", "mplx_timer_begin", "mplx_timer_end",
     "mplx_planner_create", "mplx_planner_destroy", "mplx_planner_attach_ctx", "mplx_planner_set_provider",
@@ -39,6 +39,13 @@ class Params(C.Structure):
 class Succ(C.Structure):
     _fields_ = [
         ("status", C.c_void_p), ("cost", C.c_void_p), ("hash", C.c_void_p),
+        ("state", C.c_void_p), ("state_stride", C.c_int64), ("iters", C.c_void_p),
+    ]
+
+
+class SuccLists(C.Structure):
+    _fields_ = [
+        ("count", C.c_void_p), ("action", C.c_void_p), ("cost", C.c_void_p), ("hash", C.c_void_p),
         ("state", C.c_void_p), ("state_stride", C.c_int64), ("iters", C.c_void_p),
     ]
 
@@ -96,6 +103,8 @@ def lib():
         "mplx_set_controls": (C.c_int, [vp, vp, i32, i32]),
         "mplx_expand_device": (C.c_int, [vp, vp, i64, i64, C.POINTER(Succ)]),
         "mplx_expand": (C.c_int, [vp, vp, i64, i64, C.POINTER(Succ)]),
+        "mplx_expand_lists_device": (C.c_int, [vp, vp, i64, i64, C.POINTER(SuccLists)]),
+        "mplx_expand_lists": (C.c_int, [vp, vp, i64, i64, C.POINTER(SuccLists)]),
         "mplx_get_succ": (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(i32)]),
         "mplx_device_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
         "mplx_device_free": (C.c_int, [vp, vp]),

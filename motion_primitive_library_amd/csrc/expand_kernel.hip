@@ -437,7 +437,47 @@ __global__ void pack_region_kernel(const uint8_t *bytes, uint32_t *bits, int64_t
   bits[wordi] = w;
 }
 
+// One workgroup per node: ordered compaction of the emitted slots (status 1/2).
+__global__ __launch_bounds__(256) void compact_lists_kernel(const CompactArgs A) {
+  __shared__ int s_wsum[4];
+  const int64_t nl = blockIdx.x;
+  const int64_t node = A.node_offset + nl;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int emitted = 0;
+  for (int base = 0; base < A.nU; base += 256) {
+    const int ci = base + tid;
+    const int64_t slot = nl * A.nU + ci;
+    uint8_t st = 0;
+    if (ci < A.nU) st = A.status[slot];
+    const bool emit = (st == 1 || st == 2);
+    const unsigned long long m = __ballot(emit);
+    const int within = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wsum[wv] = __popcll(m);
+    __syncthreads();
+    int pre = 0, tot = 0;
+    for (int i = 0; i < 4; i++) { const int c = s_wsum[i]; if (i < wv) pre += c; tot += c; }
+    __syncthreads();
+    if (emit) {
+      const int64_t idx = node * A.nU + emitted + pre + within;
+      if (A.l_action) A.l_action[idx] = ci;
+      if (A.l_cost) A.l_cost[idx] = A.cost[slot];
+      if (A.l_hash) A.l_hash[idx] = A.hash[slot];
+      if (A.l_iters && A.iters) A.l_iters[idx] = A.iters[slot];
+      if (A.l_state)
+        for (int f = 0; f < A.n_fields; f++) A.l_state[(int64_t)f * A.l_stride + idx] = A.state[(int64_t)f * A.chunk_slots + slot];
+    }
+    emitted += tot;
+  }
+  if (tid == 0 && A.l_count) A.l_count[node] = emitted;
+}
+
 }  // namespace
+
+hipError_t launch_compact_lists(const CompactArgs &a, hipStream_t stream) {
+  if (a.n_nodes_chunk <= 0) return hipSuccess;
+  hipLaunchKernelGGL(compact_lists_kernel, dim3((unsigned)a.n_nodes_chunk), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
 
 hipError_t launch_expand(int dim, int control, const ExpandArgs &args, hipStream_t stream) {
   if (dim == 2) return launch_dim<2>(control, args, stream);

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -43,9 +44,18 @@ struct mplx_ctx {
   int64_t n_cells = 0;
   mplx_params prm{};
   int32_t nU = 0, udim = 0;
+  double u_absmax = 0;  // max |u| over the spatial control entries
+  int n_cus = 256;
 
+  // tables of the tiled kernel (sample times, loop counts, reciprocals)
+  DevBuf tables;
+  bool tables_ok = false;
+  double tab_dt = 0, tab_res = 0;
+  double recips[3] = {0, 0, 0};
+  // scratch for the dense -> lists route
+  DevBuf d_status, d_cost, d_hash, d_state, d_iters;
   // staging for the host-pointer entry points
-  DevBuf s_nodes, s_status, s_cost, s_hash, s_state, s_iters;
+  DevBuf s_nodes, s_status, s_cost, s_hash, s_state, s_iters, s_count, s_action;
   std::vector<uint8_t> h_status;
   std::vector<double> h_cost, h_state;
 };
@@ -170,6 +180,11 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
     mplx_destroy(c);
     return MPLX_ERR_HIP;
   }
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+      c->n_cus = prop.multiProcessorCount;
+  }
   *out = c;
   return MPLX_OK;
 }
@@ -179,7 +194,8 @@ void mplx_destroy(mplx_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->map, &c->pot, &c->region_bits, &c->region_bytes, &c->U, &c->s_nodes, &c->s_status,
-                    &c->s_cost, &c->s_hash, &c->s_state, &c->s_iters})
+                    &c->s_cost, &c->s_hash, &c->s_state, &c->s_iters, &c->s_count, &c->s_action, &c->tables,
+                    &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters})
     release(*b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -266,6 +282,12 @@ int mplx_set_controls(mplx_ctx *c, const double *U, int32_t nU, int32_t udim) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->nU = nU;
   c->udim = udim;
+  c->u_absmax = 0;
+  for (int32_t i = 0; i < nU; i++)
+    for (int k = 0; k < c->dim; k++) {
+      const double a = std::fabs(U[(size_t)i * udim + k]);
+      if (a > c->u_absmax) c->u_absmax = a;
+    }
   c->has_U = true;
   return MPLX_OK;
 }
@@ -327,6 +349,207 @@ int mplx_expand(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t nod
   return MPLX_OK;
 }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------- lists route
+namespace {
+
+struct TilePlan {
+  bool ok = false;
+  int npb = 1, tile_pairs = 0, wl_cap = 0, n_max = 0, u_offset = 0, grid = 0;
+};
+
+// Decide whether the tiled kernel covers the current configuration and how to
+// tile it.  The work-list capacity needs a bound on the per-pair sample count:
+// a valid pair has max_v <= v_max (primitive.h:483-496), and for plain VEL
+// control max_v = max |u|.
+TilePlan plan_tile(const mplx_ctx *c) {
+  TilePlan t;
+  const mplx_params &p = c->prm;
+  if (p.control & 0x10) return t;              // yaw: per-sample costs, dense kernel
+  if (c->has_pot) return t;                    // potential: per-sample costs, dense kernel
+  if (c->nU > 1024 || c->nU < 1) return t;
+  double vbound;
+  if ((p.control & 0x0f) == MPLX_VEL) vbound = c->u_absmax;
+  else if (p.v_max > 0) vbound = p.v_max;
+  else return t;                               // unbounded sample count
+  const double nf = std::ceil(vbound * p.dt / c->res) + 1.0;  // +1: slack for the last rounding
+  if (!(nf <= 63.0)) return t;
+  int n_max = (int)nf;
+  if (n_max < 5) n_max = 5;
+  const int cnt_max = n_max + 1;               // the loop runs n or n+1 times
+  int npb = 1024 / c->nU;
+  if (npb < 1) npb = 1;
+  if (npb > 32) npb = 32;
+  for (; npb >= 1; npb--) {
+    const int tp = npb * c->nU;
+    int uoff = 0;
+    const size_t lds = mplx::tile_lds_bytes(tp, npb, tp * cnt_max, n_max, 4 * c->dim + 2, c->nU * c->udim, &uoff);
+    if (lds <= 80 * 1024 || npb == 1) {   // at least two 512-thread workgroups per CU (160 KiB LDS)
+      if (lds > 160 * 1024) return t;
+      t.ok = true;
+      t.npb = npb;
+      t.tile_pairs = tp;
+      t.wl_cap = tp * cnt_max;
+      t.n_max = n_max;
+      t.u_offset = uoff;
+      t.grid = c->n_cus * (lds <= 53 * 1024 ? 3 : lds <= 80 * 1024 ? 2 : 1);
+      return t;
+    }
+  }
+  return t;
+}
+
+int ensure_tables(mplx_ctx *c) {
+  if (c->tables_ok && c->tab_dt == c->prm.dt && c->tab_res == c->res) return MPLX_OK;
+  const size_t bytes = 64 * 64 * 8 + 64 + 64;  // ttab, tcnt, 3 reciprocals (8-byte aligned tail)
+  if (int rc = ensure(c, c->tables, bytes)) return rc;
+  double *ttab = (double *)c->tables.p;
+  unsigned char *tcnt = (unsigned char *)c->tables.p + 64 * 64 * 8;
+  double *rec = (double *)((unsigned char *)c->tables.p + 64 * 64 * 8 + 64);
+  HIP_TRY(c, hipMemsetAsync(c->tables.p, 0, bytes, c->stream));
+  HIP_TRY(c, mplx::launch_make_tables(c->prm.dt, c->res, ttab, tcnt, rec, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->recips, rec, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->tab_dt = c->prm.dt;
+  c->tab_res = c->res;
+  c->tables_ok = true;
+  return MPLX_OK;
+}
+
+int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride,
+                 const mplx_succ_lists *o) {
+  const int F = 4 * c->dim + 2;
+  const TilePlan tp = plan_tile(c);
+  if (tp.ok) {
+    if (int rc = ensure_tables(c)) return rc;
+    mplx::TileArgs a{};
+    a.map = (const int8_t *)c->map.p;
+    a.region = c->has_region ? (const uint32_t *)c->region_bits.p : nullptr;
+    a.dim0 = c->mdim[0]; a.dim1 = c->mdim[1]; a.dim2 = c->mdim[2];
+    a.org0 = c->origin[0]; a.org1 = c->origin[1]; a.org2 = c->origin[2];
+    a.res = c->res;
+    a.dt = c->prm.dt; a.w = c->prm.w;
+    a.v_max = c->prm.v_max; a.a_max = c->prm.a_max; a.j_max = c->prm.j_max;
+    a.U = (const double *)c->U.p;
+    a.nU = c->nU; a.udim = c->udim;
+    a.inv_nU = 1.0f / (float)c->nU;
+    a.nodes = d_nodes; a.n_nodes = n_nodes; a.node_stride = node_stride;
+    a.npb = tp.npb; a.tile_pairs = tp.tile_pairs; a.wl_cap = tp.wl_cap; a.n_max = tp.n_max;
+    a.lds_u_offset = tp.u_offset; a.grid_limit = tp.grid;
+    if (const char *dbg = getenv("MPLX_TILE_DBG")) a.dbg = atoi(dbg);  // timing ablations, never set in production
+    a.ttab = (const double *)c->tables.p;
+    a.tcnt = (const unsigned char *)c->tables.p + 64 * 64 * 8;
+    a.Rres = c->recips[0]; a.R001 = c->recips[1]; a.R01 = c->recips[2];
+    a.l_count = o->count; a.l_action = o->action; a.l_cost = o->cost; a.l_hash = o->hash;
+    a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
+    HIP_TRY(c, mplx::launch_expand_tile(c->dim, c->prm.control, a, c->stream));
+    return MPLX_OK;
+  }
+  // dense kernel into scratch, chunk by chunk, then ordered compaction on the device
+  const int64_t max_chunk_slots = (int64_t)(256u << 20) / (F * 8 + 21);  // ~256 MiB of scratch
+  int64_t chunk_nodes = max_chunk_slots / c->nU;
+  if (chunk_nodes < 1) chunk_nodes = 1;
+  if (chunk_nodes > n_nodes) chunk_nodes = n_nodes;
+  const int64_t cs = chunk_nodes * c->nU;
+  if (int rc = ensure(c, c->d_status, (size_t)cs)) return rc;
+  if (int rc = ensure(c, c->d_cost, (size_t)cs * 8)) return rc;
+  if (int rc = ensure(c, c->d_hash, (size_t)cs * 8)) return rc;
+  if (int rc = ensure(c, c->d_state, (size_t)cs * 8 * F)) return rc;
+  if (int rc = ensure(c, c->d_iters, (size_t)cs * 4)) return rc;
+  for (int64_t k0 = 0; k0 < n_nodes; k0 += chunk_nodes) {
+    const int64_t nk = (n_nodes - k0) < chunk_nodes ? (n_nodes - k0) : chunk_nodes;
+    mplx_succ d{};
+    d.status = (uint8_t *)c->d_status.p;
+    d.cost = (double *)c->d_cost.p;
+    d.hash = (uint64_t *)c->d_hash.p;
+    d.state = o->state ? (double *)c->d_state.p : nullptr;
+    d.state_stride = cs;
+    d.iters = o->iters ? (int32_t *)c->d_iters.p : nullptr;
+    mplx::ExpandArgs a = make_args(c, d_nodes + k0, nk, node_stride, &d);
+    HIP_TRY(c, mplx::launch_expand(c->dim, c->prm.control, a, c->stream));
+    mplx::CompactArgs ca{};
+    ca.status = d.status; ca.cost = d.cost; ca.hash = d.hash; ca.state = d.state; ca.iters = d.iters;
+    ca.chunk_slots = cs; ca.nU = c->nU; ca.n_fields = F;
+    ca.node_offset = k0; ca.n_nodes_chunk = nk;
+    ca.l_count = o->count; ca.l_action = o->action; ca.l_cost = o->cost; ca.l_hash = o->hash;
+    ca.l_state = o->state; ca.l_stride = o->state_stride; ca.l_iters = o->iters;
+    HIP_TRY(c, mplx::launch_compact_lists(ca, c->stream));
+  }
+  return MPLX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mplx_expand_lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride,
+                             const mplx_succ_lists *d_out) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!d_out || !d_out->count || n_nodes < 0 || node_stride < n_nodes || (!d_nodes && n_nodes > 0))
+    return fail(c, MPLX_ERR_ARG, "mplx_expand_lists_device: bad arguments");
+  if (int rc = ready(c)) return rc;
+  if (n_nodes == 0) return MPLX_OK;
+  if (d_out->state && d_out->state_stride < n_nodes * c->nU)
+    return fail(c, MPLX_ERR_ARG, "mplx_expand_lists_device: state_stride < n_nodes*nU");
+  if (int rc = bind_device(c)) return rc;
+  return lists_device(c, d_nodes, n_nodes, node_stride, d_out);
+}
+
+int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t node_stride,
+                      const mplx_succ_lists *h_out) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!h_out || !h_out->count || n_nodes < 0 || node_stride < n_nodes || (!h_nodes && n_nodes > 0))
+    return fail(c, MPLX_ERR_ARG, "mplx_expand_lists: bad arguments");
+  if (int rc = ready(c)) return rc;
+  if (n_nodes == 0) return MPLX_OK;
+  if (int rc = bind_device(c)) return rc;
+  const int F = 4 * c->dim + 2;
+  const int64_t n_slots = n_nodes * c->nU;
+  if (h_out->state && h_out->state_stride < n_slots)
+    return fail(c, MPLX_ERR_ARG, "mplx_expand_lists: state_stride < n_nodes*nU");
+  if (int rc = ensure(c, c->s_nodes, (size_t)F * n_nodes * sizeof(double))) return rc;
+  HIP_TRY(c, hipMemcpy2DAsync(c->s_nodes.p, (size_t)n_nodes * sizeof(double), h_nodes,
+                              (size_t)node_stride * sizeof(double), (size_t)n_nodes * sizeof(double), F,
+                              hipMemcpyHostToDevice, c->stream));
+  mplx_succ_lists d{};
+  if (int rc = ensure(c, c->s_count, (size_t)n_nodes * 4)) return rc;
+  d.count = (int32_t *)c->s_count.p;
+  if (h_out->action) { if (int rc = ensure(c, c->s_action, (size_t)n_slots * 4)) return rc; d.action = (int32_t *)c->s_action.p; }
+  if (h_out->cost) { if (int rc = ensure(c, c->s_cost, (size_t)n_slots * 8)) return rc; d.cost = (double *)c->s_cost.p; }
+  if (h_out->hash) { if (int rc = ensure(c, c->s_hash, (size_t)n_slots * 8)) return rc; d.hash = (uint64_t *)c->s_hash.p; }
+  if (h_out->iters) { if (int rc = ensure(c, c->s_iters, (size_t)n_slots * 4)) return rc; d.iters = (int32_t *)c->s_iters.p; }
+  if (h_out->state) {
+    if (int rc = ensure(c, c->s_state, (size_t)F * n_slots * 8)) return rc;
+    d.state = (double *)c->s_state.p;
+    d.state_stride = n_slots;
+  }
+  if (int rc = lists_device(c, (const double *)c->s_nodes.p, n_nodes, n_nodes, &d)) return rc;
+  HIP_TRY(c, hipMemcpyAsync(h_out->count, d.count, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, c->stream));
+  if (n_nodes == 1) {
+    // the get_succ case: copy back only the used prefix
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t m = (size_t)h_out->count[0];
+    if (h_out->action && m) HIP_TRY(c, hipMemcpyAsync(h_out->action, d.action, m * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_out->cost && m) HIP_TRY(c, hipMemcpyAsync(h_out->cost, d.cost, m * 8, hipMemcpyDeviceToHost, c->stream));
+    if (h_out->hash && m) HIP_TRY(c, hipMemcpyAsync(h_out->hash, d.hash, m * 8, hipMemcpyDeviceToHost, c->stream));
+    if (h_out->iters && m) HIP_TRY(c, hipMemcpyAsync(h_out->iters, d.iters, m * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_out->state && m)
+      HIP_TRY(c, hipMemcpy2DAsync(h_out->state, (size_t)h_out->state_stride * 8, d.state, (size_t)n_slots * 8, m * 8, F,
+                                  hipMemcpyDeviceToHost, c->stream));
+  } else {
+    if (h_out->action) HIP_TRY(c, hipMemcpyAsync(h_out->action, d.action, (size_t)n_slots * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_out->cost) HIP_TRY(c, hipMemcpyAsync(h_out->cost, d.cost, (size_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
+    if (h_out->hash) HIP_TRY(c, hipMemcpyAsync(h_out->hash, d.hash, (size_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
+    if (h_out->iters) HIP_TRY(c, hipMemcpyAsync(h_out->iters, d.iters, (size_t)n_slots * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_out->state)
+      HIP_TRY(c, hipMemcpy2DAsync(h_out->state, (size_t)h_out->state_stride * 8, d.state, (size_t)n_slots * 8,
+                                  (size_t)n_slots * 8, F, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MPLX_OK;
+}
+
 int mplx_get_succ(mplx_ctx *c, const double *node, double *succ, double *cost, int32_t *action,
                   int32_t *n_succ) {
   if (!c) return MPLX_ERR_ARG;
@@ -334,25 +557,18 @@ int mplx_get_succ(mplx_ctx *c, const double *node, double *succ, double *cost, i
   if (int rc = ready(c)) return rc;
   const int F = 4 * c->dim + 2;
   const int nU = c->nU;
-  c->h_status.resize((size_t)nU);
-  c->h_cost.resize((size_t)nU);
   c->h_state.resize((size_t)F * nU);
-  mplx_succ o{};
-  o.status = c->h_status.data();
-  o.cost = c->h_cost.data();
+  int32_t count = 0;
+  mplx_succ_lists o{};
+  o.count = &count;
+  o.action = action;
+  o.cost = cost;
   o.state = c->h_state.data();
   o.state_stride = nU;
-  if (int rc = mplx_expand(c, node, 1, 1, &o)) return rc;
-  int32_t m = 0;
-  for (int i = 0; i < nU; i++) {
-    const uint8_t st = c->h_status[(size_t)i];
-    if (st != MPLX_SLOT_FINITE && st != MPLX_SLOT_BLOCKED) continue;
-    for (int f = 0; f < F; f++) succ[(size_t)m * F + f] = c->h_state[(size_t)f * nU + i];
-    cost[m] = c->h_cost[(size_t)i];
-    action[m] = i;
-    m++;
-  }
-  *n_succ = m;
+  if (int rc = mplx_expand_lists(c, node, 1, 1, &o)) return rc;
+  for (int m = 0; m < count; m++)
+    for (int f = 0; f < F; f++) succ[(size_t)m * F + f] = c->h_state[(size_t)f * nU + m];
+  *n_succ = count;
   return MPLX_OK;
 }
 

@@ -39,6 +39,69 @@ struct ExpandArgs {
   int32_t *iters;
 };
 
+// Arguments of the tiled, list-producing kernel (expand_tile_kernel.hip).
+struct TileArgs {
+  const int8_t *map;
+  const uint32_t *region;
+  int32_t dim0, dim1, dim2;
+  double org0, org1, org2;
+  double res;
+  double dt, w;
+  double v_max, a_max, j_max;
+  const double *U;
+  int32_t nU, udim;
+  float inv_nU;
+  const double *nodes;
+  int64_t n_nodes, node_stride;
+  // tiling
+  int32_t npb;         // whole nodes per workgroup
+  int32_t tile_pairs;  // npb * nU  (<= 1024)
+  int32_t wl_cap;      // work-list capacity in samples
+  int32_t n_max;       // largest sample count n served by the work list (<= 63)
+  int32_t dbg;         // timing ablations (env MPLX_TILE_DBG); 0 in production
+  int32_t lds_u_offset;  // byte offset of the control table inside the dynamic LDS
+  int32_t grid_limit;  // persistent workgroups to launch (CUs x workgroups per CU)
+  // tables made by launch_make_tables
+  const double *ttab;          // [64][64] accumulated sample times
+  const unsigned char *tcnt;   // [64] loop iteration counts
+  double Rres, R001, R01;      // refined reciprocals of res, 0.01, 0.1
+  // per-node successor lists: node k owns entries [k*nU, k*nU + l_count[k])
+  int32_t *l_count;
+  int32_t *l_action;
+  double *l_cost;
+  uint64_t *l_hash;
+  double *l_state;
+  int64_t l_stride;
+  int32_t *l_iters;
+};
+
+size_t tile_lds_bytes(int tile_pairs, int npb, int wl_cap, int n_max, int n_fields, int u_doubles,
+                      int *u_offset);
+hipError_t launch_make_tables(double T, double res, double *ttab, unsigned char *tcnt, double *recips,
+                              hipStream_t stream);
+hipError_t launch_expand_tile(int dim, int control, const TileArgs &args, hipStream_t stream);
+
+// Dense slots of a chunk of nodes -> per-node successor lists (used for the
+// configurations the tiled kernel does not cover).
+struct CompactArgs {
+  const uint8_t *status;
+  const double *cost;
+  const uint64_t *hash;
+  const double *state;   // [F][chunk_slots]
+  const int32_t *iters;
+  int64_t chunk_slots;
+  int32_t nU, n_fields;
+  int64_t node_offset, n_nodes_chunk;
+  int32_t *l_count;
+  int32_t *l_action;
+  double *l_cost;
+  uint64_t *l_hash;
+  double *l_state;
+  int64_t l_stride;
+  int32_t *l_iters;
+};
+hipError_t launch_compact_lists(const CompactArgs &args, hipStream_t stream);
+
 // Launches the successor-expansion kernel specialised for (dim, control) on
 // `stream`.  Returns hipSuccess or the launch error.
 hipError_t launch_expand(int dim, int control, const ExpandArgs &args, hipStream_t stream);

@@ -136,6 +136,76 @@ class Slots:
                 b.free()
 
 
+class Lists:
+    """HBM-resident per-node successor lists (mplx_succ_lists)."""
+
+    def __init__(self, env, n_nodes, nU, want_state=True, want_iters=False, want_hash=True):
+        self.n_nodes, self.nU = int(n_nodes), int(nU)
+        self.n_slots = self.n_nodes * self.nU
+        self.n_fields = env.n_fields
+        n = max(self.n_slots, 1)
+        self.count = DeviceArray(env, max(self.n_nodes, 1) * 4)
+        self.action = DeviceArray(env, n * 4)
+        self.cost = DeviceArray(env, n * 8)
+        self.hash = DeviceArray(env, n * 8) if want_hash else None
+        self.state = DeviceArray(env, n * 8 * self.n_fields) if want_state else None
+        self.iters = DeviceArray(env, n * 4) if want_iters else None
+
+    def c_struct(self):
+        s = _abi.SuccLists()
+        s.count, s.action, s.cost = self.count.ptr, self.action.ptr, self.cost.ptr
+        s.hash = self.hash.ptr if self.hash else None
+        s.state = self.state.ptr if self.state else None
+        s.state_stride = self.n_slots
+        s.iters = self.iters.ptr if self.iters else None
+        return s
+
+    def download(self):
+        out = {
+            "count": self.count.download(np.int32, (self.n_nodes,)),
+            "action": self.action.download(np.int32, (self.n_slots,)),
+            "cost": self.cost.download(np.float64, (self.n_slots,)),
+        }
+        if self.hash:
+            out["hash"] = self.hash.download(np.uint64, (self.n_slots,))
+        if self.state:
+            out["state"] = self.state.download(np.float64, (self.n_fields, self.n_slots))
+        if self.iters:
+            out["iters"] = self.iters.download(np.int32, (self.n_slots,))
+        return out
+
+    def free(self):
+        for b in (self.count, self.action, self.cost, self.hash, self.state, self.iters):
+            if b is not None:
+                b.free()
+
+
+def lists_from_dense(dense, n_nodes, nU):
+    """Dense slots -> the per-node list layout of mplx_succ_lists (host-side
+    helper for tests and examples).  Unused tail entries are left as zeros."""
+    st = dense["status"].reshape(n_nodes, nU)
+    emit = (st == 1) | (st == 2)
+    count = emit.sum(axis=1).astype(np.int32)
+    out = {"count": count, "action": np.zeros(n_nodes * nU, np.int32), "cost": np.zeros(n_nodes * nU, np.float64),
+           "hash": np.zeros(n_nodes * nU, np.uint64)}
+    if dense.get("state") is not None:
+        out["state"] = np.zeros_like(dense["state"])
+    if dense.get("iters") is not None:
+        out["iters"] = np.zeros(n_nodes * nU, np.int32)
+    for k in range(n_nodes):
+        ci = np.nonzero(emit[k])[0]
+        src = k * nU + ci
+        dst = k * nU + np.arange(ci.size)
+        out["action"][dst] = ci
+        out["cost"][dst] = dense["cost"][src]
+        out["hash"][dst] = dense["hash"][src]
+        if "state" in out:
+            out["state"][:, dst] = dense["state"][:, src]
+        if "iters" in out:
+            out["iters"][dst] = dense["iters"][src]
+    return out
+
+
 class EnvMap:
     """env_map<Dim> whose get_succ runs on the MI355X (reference env_map.h)."""
 
@@ -284,6 +354,39 @@ class EnvMap:
             s.iters = out["iters"].ctypes.data
         _abi.check(self._ctx, _abi.lib().mplx_expand(self._ctx, nodes.ctypes.data, n, n, C.byref(s)))
         return out
+
+    def expand_lists(self, nodes, want_state=True, want_iters=True):
+        """Per-node successor lists of a host frontier [4D+2][N] (mplx_expand_lists)."""
+        self._flush()
+        nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+        if nodes.ndim != 2 or nodes.shape[0] != self.n_fields:
+            raise ValueError("nodes must be [%d][N]" % self.n_fields)
+        n = nodes.shape[1]
+        ns = n * self.nU
+        out = {"count": np.zeros(n, np.int32), "action": np.zeros(ns, np.int32), "cost": np.zeros(ns, np.float64),
+               "hash": np.zeros(ns, np.uint64)}
+        s = _abi.SuccLists()
+        s.count, s.action = out["count"].ctypes.data, out["action"].ctypes.data
+        s.cost, s.hash = out["cost"].ctypes.data, out["hash"].ctypes.data
+        if want_state:
+            out["state"] = np.zeros((self.n_fields, ns), np.float64)
+            s.state, s.state_stride = out["state"].ctypes.data, ns
+        if want_iters:
+            out["iters"] = np.zeros(ns, np.int32)
+            s.iters = out["iters"].ctypes.data
+        _abi.check(self._ctx, _abi.lib().mplx_expand_lists(self._ctx, nodes.ctypes.data, n, n, C.byref(s)))
+        return out
+
+    def alloc_lists(self, n_nodes, want_state=True, want_iters=False, want_hash=True):
+        return Lists(self, n_nodes, self.nU, want_state, want_iters, want_hash)
+
+    def expand_lists_resident(self, frontier, lists, n_nodes=None):
+        """Asynchronous launch on HBM-resident buffers (mplx_expand_lists_device)."""
+        self._flush()
+        n = frontier.n_nodes if n_nodes is None else int(n_nodes)
+        s = lists.c_struct()
+        _abi.check(self._ctx, _abi.lib().mplx_expand_lists_device(self._ctx, frontier.ptr, n, frontier.n_nodes,
+                                                                  C.byref(s)))
 
     def upload_frontier(self, nodes):
         nodes = np.ascontiguousarray(nodes, dtype=np.float64)
