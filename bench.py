@@ -188,6 +188,9 @@ def main():
                            "dense-compact": "dense slots: status + cost + hash"}[args.output],
                 "sharding": "frontier nodes block-partitioned over ranks, map replicated, no collective",
                 "device": dev_name, "compute_units": cus,
+                "kernel": {"grid": "expand_grid_kernel (per-axis factorised tables in LDS)",
+                           "tile": "expand_tile_kernel", "dense": "expand_kernel + compact_lists_kernel",
+                           "none": "expand_kernel"}[env.last_lists_route()],
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -241,6 +241,17 @@ const char *mplx_planner_last_error(const mplx_planner *p);
  * 3 sin(a), 4 round(a), 5 ceil(a).  Host pointers, n elements.               */
 int mplx_selftest_math(mplx_ctx *ctx, int op, const double *a, const double *b, double *out,
                        int64_t n);
+/* Which kernel serves mplx_expand_lists*: AUTO picks the fastest one that
+ * covers the configuration (GRID: controls with <= 16 distinct values per axis,
+ * no yaw, no potential, bounded velocity; TILE: any control table, otherwise the
+ * same scope; DENSE: everything, dense kernel + on-device compaction).  All
+ * three produce identical lists; forcing a route that does not cover the
+ * configuration makes the expand call fail with MPLX_ERR_STATE.  Used by the
+ * parity tests to cross-check the kernels.                                    */
+enum { MPLX_ROUTE_AUTO = 0, MPLX_ROUTE_DENSE = 1, MPLX_ROUTE_TILE = 2, MPLX_ROUTE_GRID = 3 };
+int mplx_set_lists_route(mplx_ctx *ctx, int route);
+/* Route taken by the last mplx_expand_lists* call (MPLX_ROUTE_*).            */
+int mplx_last_lists_route(const mplx_ctx *ctx);
 /* Fills name (up to cap bytes) with the device name and gcn arch.            */
 int mplx_device_info(mplx_ctx *ctx, char *name, size_t cap, int32_t *compute_units);
 

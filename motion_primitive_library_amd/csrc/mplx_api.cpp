@@ -45,6 +45,12 @@ struct mplx_ctx {
   mplx_params prm{};
   int32_t nU = 0, udim = 0;
   double u_absmax = 0;  // max |u| over the spatial control entries
+  // per-axis factorisation of the control table (expand_grid_kernel.hip)
+  DevBuf uvals, uidx;
+  bool u_factored = false;
+  int32_t u_nd[3] = {0, 0, 0};
+  int lists_route = MPLX_ROUTE_AUTO;
+  int last_route = MPLX_ROUTE_AUTO;
   int n_cus = 256;
 
   // tables of the tiled kernel (sample times, loop counts, reciprocals)
@@ -195,7 +201,7 @@ void mplx_destroy(mplx_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->map, &c->pot, &c->region_bits, &c->region_bytes, &c->U, &c->s_nodes, &c->s_status,
                     &c->s_cost, &c->s_hash, &c->s_state, &c->s_iters, &c->s_count, &c->s_action, &c->tables,
-                    &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters})
+                    &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx})
     release(*b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -288,6 +294,33 @@ int mplx_set_controls(mplx_ctx *c, const double *U, int32_t nU, int32_t udim) {
       const double a = std::fabs(U[(size_t)i * udim + k]);
       if (a > c->u_absmax) c->u_absmax = a;
     }
+  // distinct values per spatial axis (compared bit-for-bit so that signed zeros stay apart)
+  c->u_factored = true;
+  double vals[3][16];
+  std::vector<uint32_t> packed((size_t)nU, 0u);
+  for (int k = 0; k < c->dim && c->u_factored; k++) {
+    int n = 0;
+    for (int32_t i = 0; i < nU; i++) {
+      const double x = U[(size_t)i * udim + k];
+      int j = 0;
+      for (; j < n; j++)
+        if (std::memcmp(&vals[k][j], &x, sizeof x) == 0) break;
+      if (j == n) {
+        if (n == 16) { c->u_factored = false; break; }
+        vals[k][n++] = x;
+      }
+      packed[(size_t)i] |= (uint32_t)j << (8 * k);
+    }
+    c->u_nd[k] = n;
+  }
+  if (c->u_factored) {
+    for (int k = c->dim; k < 3; k++) c->u_nd[k] = 0;
+    if (int rc = ensure(c, c->uvals, sizeof vals)) return rc;
+    if (int rc = ensure(c, c->uidx, (size_t)nU * 4)) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->uvals.p, vals, sizeof vals, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->uidx.p, packed.data(), (size_t)nU * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
   c->has_U = true;
   return MPLX_OK;
 }
@@ -400,6 +433,55 @@ TilePlan plan_tile(const mplx_ctx *c) {
   return t;
 }
 
+struct GridPlan {
+  bool ok = false;
+  int npb = 1, ndp = 1, n_max = 0, wl_cap = 0, grid = 0;
+};
+
+// Does the factorised kernel cover the current configuration, and how is it tiled?
+GridPlan plan_grid(const mplx_ctx *c) {
+  GridPlan g;
+  const mplx_params &p = c->prm;
+  if (p.control & 0x10) return g;
+  if (c->has_pot) return g;
+  if (!c->u_factored || c->nU > 1024 || c->nU < 1) return g;
+  for (int i = 0; i < c->dim; i++)
+    if (c->mdim[i] > 32767) return g;           // int16 cell tables
+  double vbound;
+  if ((p.control & 0x0f) == MPLX_VEL) vbound = c->u_absmax;
+  else if (p.v_max > 0) vbound = p.v_max;
+  else return g;
+  const double nf = std::ceil(vbound * p.dt / c->res) + 1.0;
+  if (!(nf <= 62.0)) return g;
+  int n_max = (int)nf;
+  if (n_max < 5) n_max = 5;
+  int ndp = 1;
+  for (int i = 0; i < c->dim; i++) ndp = c->u_nd[i] > ndp ? c->u_nd[i] : ndp;
+  const int tts = n_max + 1;
+  int npb = 1024 / c->nU;
+  if (npb < 1) npb = 1;
+  if (npb > 32) npb = 32;
+  for (; npb >= 1; npb--) {
+    const int pairs = npb * c->nU;
+    // work list: about half the pairs emitted with a full sample row each, at least one full chunk of 128 pairs
+    int chunk = pairs / 2 < 128 ? 128 : pairs / 2;
+    if (chunk > pairs) chunk = pairs;
+    const int wl_cap = chunk * tts;
+    const size_t lds = mplx::grid_lds_bytes(c->dim, npb, c->nU, ndp, n_max, wl_cap);
+    if (lds <= 53 * 1024 || npb == 1) {
+      if (lds > 160 * 1024) return g;
+      g.ok = true;
+      g.npb = npb;
+      g.ndp = ndp;
+      g.n_max = n_max;
+      g.wl_cap = wl_cap;
+      g.grid = c->n_cus * (lds <= 53 * 1024 ? 3 : lds <= 80 * 1024 ? 2 : 1);
+      return g;
+    }
+  }
+  return g;
+}
+
 int ensure_tables(mplx_ctx *c) {
   if (c->tables_ok && c->tab_dt == c->prm.dt && c->tab_res == c->res) return MPLX_OK;
   const size_t bytes = 64 * 64 * 8 + 64 + 64;  // ttab, tcnt, 3 reciprocals (8-byte aligned tail)
@@ -420,7 +502,41 @@ int ensure_tables(mplx_ctx *c) {
 int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride,
                  const mplx_succ_lists *o) {
   const int F = 4 * c->dim + 2;
-  const TilePlan tp = plan_tile(c);
+  const int route = c->lists_route;
+  const GridPlan gp = (route == MPLX_ROUTE_AUTO || route == MPLX_ROUTE_GRID) ? plan_grid(c) : GridPlan();
+  if (route == MPLX_ROUTE_GRID && !gp.ok)
+    return fail(c, MPLX_ERR_STATE, "lists route GRID does not cover this configuration");
+  if (gp.ok) {
+    if (int rc = ensure_tables(c)) return rc;
+    mplx::GridArgs a{};
+    a.map = (const int8_t *)c->map.p;
+    a.region = c->has_region ? (const uint32_t *)c->region_bits.p : nullptr;
+    a.dim0 = c->mdim[0]; a.dim1 = c->mdim[1]; a.dim2 = c->mdim[2];
+    a.org0 = c->origin[0]; a.org1 = c->origin[1]; a.org2 = c->origin[2];
+    a.res = c->res;
+    a.dt = c->prm.dt; a.w = c->prm.w;
+    a.v_max = c->prm.v_max; a.a_max = c->prm.a_max; a.j_max = c->prm.j_max;
+    a.uvals = (const double *)c->uvals.p;
+    a.uidx = (const uint32_t *)c->uidx.p;
+    a.nd0 = c->u_nd[0]; a.nd1 = c->u_nd[1]; a.nd2 = c->u_nd[2];
+    a.ndp = gp.ndp;
+    a.nU = c->nU;
+    a.inv_nU = 1.0f / (float)c->nU;
+    a.nodes = d_nodes; a.n_nodes = n_nodes; a.node_stride = node_stride;
+    a.npb = gp.npb; a.n_max = gp.n_max; a.wl_cap = gp.wl_cap; a.grid_limit = gp.grid;
+    if (const char *dbg = getenv("MPLX_TILE_DBG")) a.dbg = atoi(dbg);  // timing ablations, never set in production
+    a.ttab = (const double *)c->tables.p;
+    a.tcnt = (const unsigned char *)c->tables.p + 64 * 64 * 8;
+    a.Rres = c->recips[0]; a.R001 = c->recips[1]; a.R01 = c->recips[2];
+    a.l_count = o->count; a.l_action = o->action; a.l_cost = o->cost; a.l_hash = o->hash;
+    a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
+    HIP_TRY(c, mplx::launch_expand_grid(c->dim, c->prm.control, a, c->stream));
+    c->last_route = MPLX_ROUTE_GRID;
+    return MPLX_OK;
+  }
+  const TilePlan tp = (route == MPLX_ROUTE_AUTO || route == MPLX_ROUTE_TILE) ? plan_tile(c) : TilePlan();
+  if (route == MPLX_ROUTE_TILE && !tp.ok)
+    return fail(c, MPLX_ERR_STATE, "lists route TILE does not cover this configuration");
   if (tp.ok) {
     if (int rc = ensure_tables(c)) return rc;
     mplx::TileArgs a{};
@@ -444,6 +560,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.l_count = o->count; a.l_action = o->action; a.l_cost = o->cost; a.l_hash = o->hash;
     a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
     HIP_TRY(c, mplx::launch_expand_tile(c->dim, c->prm.control, a, c->stream));
+    c->last_route = MPLX_ROUTE_TILE;
     return MPLX_OK;
   }
   // dense kernel into scratch, chunk by chunk, then ordered compaction on the device
@@ -476,6 +593,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     ca.l_state = o->state; ca.l_stride = o->state_stride; ca.l_iters = o->iters;
     HIP_TRY(c, mplx::launch_compact_lists(ca, c->stream));
   }
+  c->last_route = MPLX_ROUTE_DENSE;
   return MPLX_OK;
 }
 
@@ -658,6 +776,15 @@ int mplx_selftest_math(mplx_ctx *c, int op, const double *a, const double *b, do
   (void)hipFree(dout);
   return MPLX_OK;
 }
+
+int mplx_set_lists_route(mplx_ctx *c, int route) {
+  if (!c) return MPLX_ERR_ARG;
+  if (route < MPLX_ROUTE_AUTO || route > MPLX_ROUTE_GRID) return fail(c, MPLX_ERR_ARG, "mplx_set_lists_route: unknown route %d", route);
+  c->lists_route = route;
+  return MPLX_OK;
+}
+
+int mplx_last_lists_route(const mplx_ctx *c) { return c ? c->last_route : MPLX_ERR_ARG; }
 
 int mplx_device_info(mplx_ctx *c, char *name, size_t cap, int32_t *compute_units) {
   if (!c) return MPLX_ERR_ARG;

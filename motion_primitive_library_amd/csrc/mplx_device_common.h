@@ -1,0 +1,166 @@
+// mplx_device_common.h -- device helpers shared by the list-producing kernels
+// (expand_tile_kernel.hip, expand_grid_kernel.hip): the hoisted exact division,
+// the lattice hash (reference include/mpl_basis/waypoint.h:93-125) and the
+// per-axis polynomial of a forward primitive (reference
+// include/mpl_basis/primitive.h:34-50,128-145,353-394).  Derivations of every
+// expression are in expand_kernel.hip.  Compile with -ffp-contract=off; the only
+// fused operations are the explicit fma's of the division tail.
+#ifndef MPLX_DEVICE_COMMON_H
+#define MPLX_DEVICE_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace mplx {
+namespace dev {
+
+// ------------------------------------------------------------------ division
+// q = y / d given R = refined reciprocal of d (see make_tables_kernel).
+__device__ __forceinline__ double div_by(double y, double d, double R) {
+  const double q0 = y * R;
+  const double rem = __builtin_fma(-d, q0, y);
+  return __builtin_fma(rem, R, q0);
+}
+// the reciprocal exactly as hipcc's f64 division refines it
+__device__ __forceinline__ double refined_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+
+__device__ __forceinline__ void fold(uint64_t &seed, int id) {
+  seed ^= (uint64_t)(int64_t)id + 0x9e3779b9ULL + (seed << 6) + (seed >> 2);
+}
+// `int id = std::round(x / q)` (waypoint.h:95-112), division by a constant
+__device__ __forceinline__ int quantise(double x, double q, double Rq) {
+  return (int)round(div_by(x, q, Rq));
+}
+
+template <int D, int K>
+__device__ __forceinline__ uint64_t lattice_hash(const double *pos, const double *vel, const double *acc,
+                                                 const double *jrk, double R001, double R01) {
+  uint64_t h = 0;
+#pragma unroll
+  for (int i = 0; i < D; i++) {
+    fold(h, quantise(pos[i], 0.01, R001));
+    if (K >= 2) fold(h, quantise(vel[i], 0.1, R01));
+    if (K >= 3) fold(h, quantise(acc[i], 0.1, R01));
+    if (K >= 4) fold(h, quantise(jrk[i], 0.1, R01));
+  }
+  return h;
+}
+
+// Per-axis polynomial of a forward primitive, see expand_kernel.hip for the
+// derivation of every expression (primitive.h:128-145, 353-394).
+template <int K>
+struct Ax {
+  double c1, c2, c3, c4, c5;
+  __device__ __forceinline__ void init(double p, double v, double a, double j, double u) {
+    c1 = c2 = c3 = c4 = 0.0;
+    c5 = p;
+    if (K == 1) { c4 = u; }
+    if (K == 2) { c4 = v; c3 = u; }
+    if (K == 3) { c4 = v; c3 = a; c2 = u; }
+    if (K == 4) { c4 = v; c3 = a; c2 = j; c1 = u; }
+  }
+  template <bool EXACT>
+  __device__ __forceinline__ double pos(double t) const {
+    double s;
+    if (K == 1) { s = c4 * t; if (EXACT) s = 0.0 + s; return s + c5; }
+    if (K == 2) { s = ((c3 / 2) * t) * t; if (EXACT) s = 0.0 + s; return (s + c4 * t) + c5; }
+    if (K == 3) {
+      s = (c2 / 6) * ((t * t) * t);
+      if (EXACT) s = 0.0 + s;
+      return ((s + ((c3 / 2) * t) * t) + c4 * t) + c5;
+    }
+    const double t3 = (t * t) * t;
+    s = (c1 / 24) * (t3 * t);
+    if (EXACT) s = 0.0 + s;
+    return (((s + (c2 / 6) * t3) + ((c3 / 2) * t) * t) + c4 * t) + c5;
+  }
+  template <bool EXACT>
+  __device__ __forceinline__ double vel(double t) const {
+    double s;
+    if (K == 1) { return EXACT ? 0.0 + c4 : c4; }
+    if (K == 2) { s = c3 * t; if (EXACT) s = 0.0 + s; return s + c4; }
+    if (K == 3) { s = ((c2 / 2) * t) * t; if (EXACT) s = 0.0 + s; return (s + c3 * t) + c4; }
+    s = (c1 / 6) * ((t * t) * t);
+    if (EXACT) s = 0.0 + s;
+    return ((s + ((c2 / 2) * t) * t) + c3 * t) + c4;
+  }
+  template <bool EXACT>
+  __device__ __forceinline__ double acc(double t) const {
+    double s;
+    if (K == 1) return 0.0;
+    if (K == 2) { return EXACT ? 0.0 + c3 : c3; }
+    if (K == 3) { s = c2 * t; if (EXACT) s = 0.0 + s; return s + c3; }
+    s = ((c1 / 2) * t) * t;
+    if (EXACT) s = 0.0 + s;
+    return (s + c2 * t) + c3;
+  }
+  template <bool EXACT>
+  __device__ __forceinline__ double jrk(double t) const {
+    double s;
+    if (K <= 2) return 0.0;
+    if (K == 3) { return EXACT ? 0.0 + c2 : c2; }
+    s = c1 * t;
+    if (EXACT) s = 0.0 + s;
+    return s + c2;
+  }
+  __device__ __forceinline__ double max_vel(double T) const {
+    const double v0 = fabs(c4), vT = fabs(vel<false>(T));
+    double m = (v0 < vT) ? vT : v0;
+    if (K == 3) {
+      if (c2 != 0) {
+        const double r = -c3 / c2;
+        if (r > 0 && r < T) { const double v = fabs(vel<false>(r)); m = v > m ? v : m; }
+      }
+    }
+    if (K == 4) {
+      const double b = c1 / 2;
+      if (b != 0) {
+        const double disc = c2 * c2 - 4 * b * c3;
+        if (!(disc < 0)) {
+          const double sq = sqrt(disc);
+          const double r1 = (-c2 - sq) / (2 * b);
+          const double r2 = (-c2 + sq) / (2 * b);
+          bool go_on = true;
+          if (r1 > 0 && r1 < T) { const double v = fabs(vel<false>(r1)); m = v > m ? v : m; }
+          else if (r1 >= T) go_on = false;
+          if (go_on && r2 > 0 && r2 < T) { const double v = fabs(vel<false>(r2)); m = v > m ? v : m; }
+        }
+      } else if (c2 != 0) {
+        const double r = -c3 / c2;
+        if (r > 0 && r < T) { const double v = fabs(vel<false>(r)); m = v > m ? v : m; }
+      }
+    }
+    return m;
+  }
+  __device__ __forceinline__ double max_acc(double T) const {
+    const double a0 = fabs(c3), aT = fabs(acc<false>(T));
+    double m = (a0 < aT) ? aT : a0;
+    if (K == 4) {
+      if (c1 != 0) {
+        const double r = -c2 / c1;
+        if (r > 0 && r < T) { const double a = fabs(acc<false>(r)); m = a > m ? a : m; }
+      }
+    }
+    return m;
+  }
+  __device__ __forceinline__ double max_jrk(double T) const {
+    const double j0 = fabs(c2), jT = fabs(jrk<false>(T));
+    return (j0 < jT) ? jT : j0;
+  }
+  __device__ __forceinline__ double effort(double T) const {
+    const double u = (K == 1) ? c4 : (K == 2) ? c3 : (K == 3) ? c2 : c1;
+    return u * u * T;
+  }
+};
+
+}  // namespace dev
+}  // namespace mplx
+#endif

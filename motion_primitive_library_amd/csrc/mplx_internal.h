@@ -81,6 +81,44 @@ hipError_t launch_make_tables(double T, double res, double *ttab, unsigned char 
                               hipStream_t stream);
 hipError_t launch_expand_tile(int dim, int control, const TileArgs &args, hipStream_t stream);
 
+// Arguments of the factorised list-producing kernel (expand_grid_kernel.hip):
+// the control table is given per axis as its distinct values plus, per control,
+// the packed indices of its entries (j0 | j1 << 8 | j2 << 16).
+struct GridArgs {
+  const int8_t *map;
+  const uint32_t *region;
+  int32_t dim0, dim1, dim2;
+  double org0, org1, org2;
+  double res;
+  double dt, w;
+  double v_max, a_max, j_max;
+  const double *uvals;   // [3][16] distinct control values of each axis
+  const uint32_t *uidx;  // [nU] packed per-axis value indices
+  int32_t nd0, nd1, nd2; // number of distinct values per axis
+  int32_t ndp;           // table stride over values (max nd)
+  int32_t nU;
+  float inv_nU;
+  const double *nodes;
+  int64_t n_nodes, node_stride;
+  int32_t npb;           // whole nodes per workgroup
+  int32_t n_max;         // largest sample count n (<= 62); cell-table rows n = 5 .. n_max
+  int32_t wl_cap;        // work-list capacity in samples (multiple of n_max + 1)
+  int32_t dbg;           // timing ablations (env MPLX_TILE_DBG); 0 in production
+  int32_t grid_limit;    // persistent workgroups to launch
+  const double *ttab;    // tables of launch_make_tables
+  const unsigned char *tcnt;
+  double Rres, R001, R01;
+  int32_t *l_count;
+  int32_t *l_action;
+  double *l_cost;
+  uint64_t *l_hash;
+  double *l_state;
+  int64_t l_stride;
+  int32_t *l_iters;
+};
+size_t grid_lds_bytes(int dim, int npb, int nU, int ndp, int n_max, int wl_cap);
+hipError_t launch_expand_grid(int dim, int control, const GridArgs &args, hipStream_t stream);
+
 // Dense slots of a chunk of nodes -> per-node successor lists (used for the
 // configurations the tiled kernel does not cover).
 struct CompactArgs {

@@ -419,6 +419,17 @@ class EnvMap:
         _abi.check(self._ctx, _abi.lib().mplx_timer_end(self._ctx, C.byref(ms)))
         return ms.value
 
+    def set_lists_route(self, route):
+        """Force the kernel behind expand_lists* ("auto", "dense", "tile", "grid"); diagnostic."""
+        code = {"auto": _abi.ROUTE_AUTO, "dense": _abi.ROUTE_DENSE, "tile": _abi.ROUTE_TILE,
+                "grid": _abi.ROUTE_GRID}[route] if isinstance(route, str) else int(route)
+        _abi.check(self._ctx, _abi.lib().mplx_set_lists_route(self._ctx, code))
+
+    def last_lists_route(self):
+        code = _abi.lib().mplx_last_lists_route(self._ctx)
+        return {_abi.ROUTE_AUTO: "none", _abi.ROUTE_DENSE: "dense", _abi.ROUTE_TILE: "tile",
+                _abi.ROUTE_GRID: "grid"}[code]
+
     def selftest_math(self, op, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float64)
         b = a if b is None else np.ascontiguousarray(b, dtype=np.float64)

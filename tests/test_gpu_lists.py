@@ -1,5 +1,6 @@
-"""GPU: the list-producing entry points (mplx_expand_lists*, the tiled kernel
-expand_tile_kernel.hip and the dense+compaction route) against the oracle."""
+"""GPU: the list-producing entry points (mplx_expand_lists*: the factorised kernel
+expand_grid_kernel.hip, the general tiled kernel expand_tile_kernel.hip and the
+dense+compaction route) against the oracle."""
 import numpy as np
 import pytest
 
@@ -49,6 +50,69 @@ def test_lists_reproduce_reference_golden_vectors(engine, name, case, exp):
     env.close()
     rtol = YAW_COST_RTOL if case["control"] & 0x10 else 0.0
     assert_lists_equal(got, exp, case["nodes"].shape[1], case["U"].shape[0], cost_rtol=rtol, what="lists " + name)
+
+
+def _random_controls(dim, n, seed, n_distinct):
+    """A control table that is NOT a Cartesian grid: n rows drawn from n_distinct values per axis."""
+    rng = np.random.default_rng(seed)
+    vals = np.linspace(-1.0, 1.0, n_distinct) if n_distinct <= 9 else rng.uniform(-1.0, 1.0, size=n_distinct)
+    U = rng.choice(vals, size=(n, dim))
+    if n >= n_distinct:
+        U[:n_distinct, 0] = vals  # every value in use on the first axis
+    return U
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("control", [0x01, 0x03, 0x07, 0x0F])
+@pytest.mark.parametrize("variant", ["plain", "region"])
+def test_lists_routes_agree(engine, oracle_lib, dim, control, variant):
+    """The three kernels behind mplx_expand_lists (factorised GRID, general TILE,
+    DENSE + compaction) against the oracle on the same inputs."""
+    wl = _small_world(engine, dim, control, seed=900 * dim + control, region=(variant == "region"), n_nodes=75)
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+    env = engine_env(engine, wl)
+    for route in ("grid", "tile", "dense"):
+        env.set_lists_route(route)
+        got = env.expand_lists(wl.nodes)
+        assert env.last_lists_route() == route
+        assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="route %s dim%d ctrl0x%x %s" % (
+            route, dim, control, variant))
+    env.set_lists_route("auto")
+    env.expand_lists(wl.nodes)
+    assert env.last_lists_route() == "grid"
+    env.close()
+
+
+@pytest.mark.parametrize("dim,n_controls,n_distinct,expect", [(3, 200, 7, "grid"), (3, 200, 40, "tile"),
+                                                             (2, 37, 16, "grid"), (2, 37, 17, "tile"),
+                                                             (3, 1000, 12, "grid"), (3, 1, 1, "grid")])
+def test_lists_irregular_control_tables(engine, oracle_lib, dim, n_controls, n_distinct, expect):
+    """Control tables that are not Cartesian products: up to 16 distinct values per
+    axis are factorised, more fall back to the general tiled kernel; duplicates
+    and a single control are legal."""
+    wl = _small_world(engine, dim, 0x03, seed=1234 + n_controls, n_nodes=90)
+    wl.U = _random_controls(dim, n_controls, 4321 + n_distinct, n_distinct)
+    if n_distinct > 1:
+        assert max(np.unique(wl.U[:, i]).size for i in range(dim)) == n_distinct
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+    env = engine_env(engine, wl)
+    got = env.expand_lists(wl.nodes)
+    assert env.last_lists_route() == expect
+    env.close()
+    assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="irregular U %dx%d" % (n_controls, n_distinct))
+
+
+def test_forcing_a_route_outside_its_scope_fails_loudly(engine):
+    wl = _small_world(engine, 2, 0x13, seed=5, n_nodes=8)  # yaw: only the dense kernel covers it
+    env = engine_env(engine, wl)
+    env.set_lists_route("grid")
+    with pytest.raises(engine._abi.MplxError) as e:
+        env.expand_lists(wl.nodes)
+    assert e.value.code == engine._abi.ERR_STATE
+    env.set_lists_route("auto")
+    env.expand_lists(wl.nodes)
+    assert env.last_lists_route() == "dense"
+    env.close()
 
 
 def test_lists_ragged_tiles_and_resident_buffers(engine, oracle_lib):
