@@ -46,7 +46,8 @@ struct mplx_ctx {
   int32_t nU = 0, udim = 0;
   double u_absmax = 0;  // max |u| over the spatial control entries
   // per-axis factorisation of the control table (expand_grid_kernel.hip)
-  DevBuf uvals, uidx;
+  DevBuf uvals, uidx, blk;
+  bool blk_ok = false;   // blocked-bit map matches the current map + region
   bool u_factored = false;
   int32_t u_nd[3] = {0, 0, 0};
   int lists_route = MPLX_ROUTE_AUTO;
@@ -201,7 +202,7 @@ void mplx_destroy(mplx_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->map, &c->pot, &c->region_bits, &c->region_bytes, &c->U, &c->s_nodes, &c->s_status,
                     &c->s_cost, &c->s_hash, &c->s_state, &c->s_iters, &c->s_count, &c->s_action, &c->tables,
-                    &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx})
+                    &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx, &c->blk})
     release(*b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -236,6 +237,7 @@ int mplx_set_map(mplx_ctx *c, const int8_t *cells, const int32_t *dim, const dou
   c->res = res;
   c->n_cells = n;
   c->has_map = true;
+  c->blk_ok = false;
   return MPLX_OK;
 }
 
@@ -253,7 +255,7 @@ int mplx_set_potential(mplx_ctx *c, const int8_t *cells) {
 
 int mplx_set_region(mplx_ctx *c, const uint8_t *cells) {
   if (!c) return MPLX_ERR_ARG;
-  if (!cells) { c->has_region = false; return MPLX_OK; }
+  if (!cells) { c->blk_ok = c->blk_ok && !c->has_region; c->has_region = false; return MPLX_OK; }
   if (!c->has_map) return fail(c, MPLX_ERR_STATE, "mplx_set_region: set the map first");
   if (int rc = bind_device(c)) return rc;
   const size_t words = (size_t)((c->n_cells + 31) >> 5);
@@ -264,6 +266,7 @@ int mplx_set_region(mplx_ctx *c, const uint8_t *cells) {
                                       c->n_cells, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->has_region = true;
+  c->blk_ok = false;
   return MPLX_OK;
 }
 
@@ -435,51 +438,63 @@ TilePlan plan_tile(const mplx_ctx *c) {
 
 struct GridPlan {
   bool ok = false;
-  int npb = 1, ndp = 1, n_max = 0, wl_cap = 0, grid = 0;
+  int ndp = 1, n_max = 0, rmax = 0, grid = 0;
 };
 
-// Does the factorised kernel cover the current configuration, and how is it tiled?
+// Does the factorised kernel cover the current configuration, and how is it sized?
 GridPlan plan_grid(const mplx_ctx *c) {
   GridPlan g;
   const mplx_params &p = c->prm;
   if (p.control & 0x10) return g;
   if (c->has_pot) return g;
   if (!c->u_factored || c->nU > 1024 || c->nU < 1) return g;
-  for (int i = 0; i < c->dim; i++)
-    if (c->mdim[i] > 32767) return g;           // int16 cell tables
+  {
+    int nbx, nby;
+    int64_t nd;
+    mplx::blocked_bits_geometry(c->dim, c->mdim, &nbx, &nby, &nd);
+    if (nd > (1 << 24)) return g;               // word address + bit must stay below 2^29
+  }
   double vbound;
   if ((p.control & 0x0f) == MPLX_VEL) vbound = c->u_absmax;
   else if (p.v_max > 0) vbound = p.v_max;
   else return g;
   const double nf = std::ceil(vbound * p.dt / c->res) + 1.0;
-  if (!(nf <= 62.0)) return g;
+  if (!(nf <= 61.0)) return g;
   int n_max = (int)nf;
   if (n_max < 5) n_max = 5;
   int ndp = 1;
   for (int i = 0; i < c->dim; i++) ndp = c->u_nd[i] > ndp ? c->u_nd[i] : ndp;
-  const int tts = n_max + 1;
-  int npb = 1024 / c->nU;
-  if (npb < 1) npb = 1;
-  if (npb > 32) npb = 32;
-  for (; npb >= 1; npb--) {
-    const int pairs = npb * c->nU;
-    // work list: about half the pairs emitted with a full sample row each, at least one full chunk of 128 pairs
-    int chunk = pairs / 2 < 128 ? 128 : pairs / 2;
-    if (chunk > pairs) chunk = pairs;
-    const int wl_cap = chunk * tts;
-    const size_t lds = mplx::grid_lds_bytes(c->dim, npb, c->nU, ndp, n_max, wl_cap);
-    if (lds <= 53 * 1024 || npb == 1) {
-      if (lds > 160 * 1024) return g;
-      g.ok = true;
-      g.npb = npb;
-      g.ndp = ndp;
-      g.n_max = n_max;
-      g.wl_cap = wl_cap;
-      g.grid = c->n_cus * (lds <= 53 * 1024 ? 3 : lds <= 80 * 1024 ? 2 : 1);
-      return g;
-    }
+  // rows of the per-wave cell-row cache: as many as keep five workgroups on a CU, at least 2
+  int rmax = 0;
+  if (const char *e = getenv("MPLX_GRID_RMAX")) rmax = atoi(e);  // tuning only
+  if (rmax < 1) {
+    for (rmax = 6; rmax > 2; rmax--)
+      if (mplx::grid_lds_bytes(c->dim, c->nU, ndp, n_max, rmax) <= 32 * 1024) break;
   }
+  const size_t lds = mplx::grid_lds_bytes(c->dim, c->nU, ndp, n_max, rmax);
+  if (lds > 160 * 1024) return g;
+  int per_cu = (int)((160 * 1024) / lds);
+  const int wpb = mplx::grid_waves_per_block();
+  if (per_cu * wpb > 32) per_cu = 32 / wpb;
+  g.ok = true;
+  g.ndp = ndp;
+  g.n_max = n_max;
+  g.rmax = rmax;
+  g.grid = c->n_cus * per_cu;
   return g;
+}
+
+int ensure_blocked_bits(mplx_ctx *c) {
+  if (c->blk_ok) return MPLX_OK;
+  int nbx, nby;
+  int64_t nd;
+  mplx::blocked_bits_geometry(c->dim, c->mdim, &nbx, &nby, &nd);
+  if (int rc = ensure(c, c->blk, (size_t)nd * 4)) return rc;
+  HIP_TRY(c, mplx::launch_build_blocked_bits(c->dim, (const int8_t *)c->map.p,
+                                             c->has_region ? (const uint32_t *)c->region_bits.p : nullptr, c->mdim,
+                                             (uint32_t *)c->blk.p, c->stream));
+  c->blk_ok = true;
+  return MPLX_OK;
 }
 
 int ensure_tables(mplx_ctx *c) {
@@ -509,8 +524,12 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
   if (gp.ok) {
     if (int rc = ensure_tables(c)) return rc;
     mplx::GridArgs a{};
-    a.map = (const int8_t *)c->map.p;
-    a.region = c->has_region ? (const uint32_t *)c->region_bits.p : nullptr;
+    if (int rc = ensure_blocked_bits(c)) return rc;
+    a.blk = (const uint32_t *)c->blk.p;
+    {
+      int64_t nd;
+      mplx::blocked_bits_geometry(c->dim, c->mdim, &a.nbx, &a.nby, &nd);
+    }
     a.dim0 = c->mdim[0]; a.dim1 = c->mdim[1]; a.dim2 = c->mdim[2];
     a.org0 = c->origin[0]; a.org1 = c->origin[1]; a.org2 = c->origin[2];
     a.res = c->res;
@@ -521,9 +540,8 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.nd0 = c->u_nd[0]; a.nd1 = c->u_nd[1]; a.nd2 = c->u_nd[2];
     a.ndp = gp.ndp;
     a.nU = c->nU;
-    a.inv_nU = 1.0f / (float)c->nU;
     a.nodes = d_nodes; a.n_nodes = n_nodes; a.node_stride = node_stride;
-    a.npb = gp.npb; a.n_max = gp.n_max; a.wl_cap = gp.wl_cap; a.grid_limit = gp.grid;
+    a.n_max = gp.n_max; a.rmax = gp.rmax; a.grid_limit = gp.grid;
     if (const char *dbg = getenv("MPLX_TILE_DBG")) a.dbg = atoi(dbg);  // timing ablations, never set in production
     a.ttab = (const double *)c->tables.p;
     a.tcnt = (const unsigned char *)c->tables.p + 64 * 64 * 8;

@@ -85,8 +85,8 @@ hipError_t launch_expand_tile(int dim, int control, const TileArgs &args, hipStr
 // the control table is given per axis as its distinct values plus, per control,
 // the packed indices of its entries (j0 | j1 << 8 | j2 << 16).
 struct GridArgs {
-  const int8_t *map;
-  const uint32_t *region;
+  const uint32_t *blk;   // blocked-bit map in bricks (launch_build_blocked_bits)
+  int32_t nbx, nby;      // bricks along x and y
   int32_t dim0, dim1, dim2;
   double org0, org1, org2;
   double res;
@@ -97,12 +97,10 @@ struct GridArgs {
   int32_t nd0, nd1, nd2; // number of distinct values per axis
   int32_t ndp;           // table stride over values (max nd)
   int32_t nU;
-  float inv_nU;
   const double *nodes;
   int64_t n_nodes, node_stride;
-  int32_t npb;           // whole nodes per workgroup
-  int32_t n_max;         // largest sample count n (<= 62); cell-table rows n = 5 .. n_max
-  int32_t wl_cap;        // work-list capacity in samples (multiple of n_max + 1)
+  int32_t n_max;         // largest sample count n (<= 61)
+  int32_t rmax;          // rows of the per-wave cell-row cache
   int32_t dbg;           // timing ablations (env MPLX_TILE_DBG); 0 in production
   int32_t grid_limit;    // persistent workgroups to launch
   const double *ttab;    // tables of launch_make_tables
@@ -116,8 +114,14 @@ struct GridArgs {
   int64_t l_stride;
   int32_t *l_iters;
 };
-size_t grid_lds_bytes(int dim, int npb, int nU, int ndp, int n_max, int wl_cap);
+size_t grid_lds_bytes(int dim, int nU, int ndp, int n_max, int rmax);
+int grid_waves_per_block();
 hipError_t launch_expand_grid(int dim, int control, const GridArgs &args, hipStream_t stream);
+// Blocked-bit map: 1 bit per cell (occupied, outside the search region, or
+// padding), bricks of 8x8x8 cells (2D: 32x16) of 16 dwords each.
+void blocked_bits_geometry(int dim, const int32_t *mdim, int *nbx, int *nby, int64_t *n_dwords);
+hipError_t launch_build_blocked_bits(int dim, const int8_t *map, const uint32_t *region, const int32_t *mdim,
+                                     uint32_t *out, hipStream_t stream);
 
 // Dense slots of a chunk of nodes -> per-node successor lists (used for the
 // configurations the tiled kernel does not cover).
