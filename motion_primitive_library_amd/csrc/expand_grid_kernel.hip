@@ -20,32 +20,38 @@
 // (mplx_set_controls); tables with more than 16 distinct values on an axis run
 // expand_tile_kernel.hip instead.
 //
-// What the first version of this kernel taught (profiles/README.md): with the
-// arithmetic gone the time was barrier / latency bound -- eight waves marching
-// through ten phases in lock step.  Here a wave never waits for another wave:
-// all phases are wave-synchronous (LDS is in-order per wave), a workgroup is
-// only a container for kWPB independent waves that share the read-only tables.
+// What the earlier versions taught (profiles/README.md): (1) with the f64
+// arithmetic factorised away the workgroup-wide version was barrier / latency
+// bound, so here a wave never waits for another wave: all phases are
+// wave-synchronous (LDS is in-order per wave) and a workgroup is only a
+// container for kWPB independent waves; (2) the wave-per-node version was VALU
+// ISSUE bound (a wave64 VALU instruction occupies the SIMD for 4 cycles whatever
+// it computes) with ~60 instructions per map sample, most of them address
+// arithmetic of the global look-up, so here the occupancy bits of the node's
+// reachable box are staged into LDS once per node and a sample is 3 byte
+// look-ups + 1 word look-up.
 //
 // Per node (one wave):
 //   T1  axis entries (axis, value): limits, n_axis, end state, lattice integers,
-//       u*u*T; prefix tables over the first D-1 axes (partial hash, flags); the
-//       address LUT of the node's neighbourhood in the blocked-bit map
+//       u*u*T; prefix tables over the first D-1 axes (partial hash, flags)
 //   A   64 pairs per step: valid = AND of flags, n = max n_axis, hash = prefix
 //       hash folded with the last axis, emit = valid && hash != hash(node)
-//       (env_map.h:158); emitted pairs are appended, in order, to an LDS queue
-//   D   whenever 64 pairs are queued (dense lanes): action / hash / Waypoint
-//       written to the node's list; the sample loop of traverse_primitive, lane
-//       = pair, k sequential, four samples in flight: the cell offsets of
-//       p(t_k) come from per-(axis entry, n) rows kept in a small LDS row cache
-//       (built on demand; t_k = the reference's accumulated `t += T/n` times,
-//       env_map.h:97-99), the LUT turns three offsets into one word address +
-//       bit of the blocked-bit map; cost = J + w*dt or +inf (env_map.h:162-169)
+//       (env_map.h:158); the control indices of the emitted pairs are appended,
+//       in order, to an LDS list; the set of sample counts n in use
+//   R   per round of up to `rmax` sample counts: the rows of cell-offset codes of
+//       every axis entry at the reference's accumulated sample times t_k
+//       (`for (t = 0; t < T; t += T/n)`, env_map.h:97-99); the bounding box of
+//       the codes of the entries that pass the limits; the blocked bits of that
+//       box copied from the blocked-bit map into LDS (one row of x per (y, z))
+//   D   the list, 64 dense lanes at a time: action / hash / Waypoint written to
+//       the node's successor list; the sample loop of traverse_primitive with
+//       lane = pair, eight samples per step; cost = J + w*dt or +inf
+//       (env_map.h:162-169)
 // The blocked-bit map (built on the device from the map and the search region
-// whenever they change) stores 1 bit per cell, blocked = occupied or outside the
-// region (env_map.h:104-119), in bricks of 8x8x8 cells (2D: 32x16) = one 64-byte
-// line, so the 64 lanes of a sample step -- 64 controls of ONE node at the same
-// t_k, i.e. positions within +-u_max t^2/2 of each other -- touch a handful of
-// lines instead of 64, and a 512^3 map is 16 MiB instead of 128.
+// whenever they change) has 1 bit per cell, x fastest like the map itself:
+// blocked = occupied or outside the region (env_map.h:104-119).  A box that does
+// not fit the LDS budget (possible only for far larger per-step displacements
+// than the BASELINE configurations have) is sampled straight from that map.
 //
 // Bit-exactness: n = max(5, ceil(max_v*T/res)) with max_v = max over axes equals
 // the max over axes of the per-axis counts because *, / by a positive constant
@@ -53,7 +59,7 @@
 // other kernels, evaluated once instead of once per pair.
 //
 // Scope: controls without yaw, no potential map, v_max > 0 (or VEL), Dim 2/3,
-// K = 1..4, n_max <= 61, padded map <= 2^29 cells.
+// K = 1..4, n_max <= 61.
 #include "mplx_internal.h"
 #include "mplx_device_common.h"
 
@@ -62,19 +68,17 @@ namespace mplx {
 // LDS carve-up, shared by host (size) and device (offsets).
 struct GridLds {
   // shared by the workgroup (read-only after set-up)
-  int o_tt, o_uval, o_uidx, o_tc, o_wave0;
+  int o_uval, o_uidx, o_tc, o_wave0;
   // per wave, relative to the wave's block
-  int w_hcur, w_node, w_est, w_eJ, w_hp, w_eq, w_eflag, w_fp, w_lut, w_queue, w_misc, w_rowmap, w_cell, wave_bytes;
+  int w_hcur, w_node, w_est, w_eJ, w_hp, w_eq, w_eflag, w_fp, w_box, w_misc, w_rowmap, w_list, w_cell, wave_bytes;
   int total;
-  int F, EN, PN, LUTN, tts;
-  __host__ __device__ GridLds(int D, int waves, int nU, int ndp, int n_max, int rmax) {
+  int F, EN, PN, tts;
+  __host__ __device__ GridLds(int D, int K, int waves, int nU, int ndp, int n_max, int rmax, int boxcap) {
     F = 4 * D + 2;
     EN = D * ndp;
     PN = (D == 3) ? ndp * ndp : ndp;
-    LUTN = 2 * (n_max + 2) + 1;
     tts = n_max + 1;
     int b = 0;
-    o_tt = b; b += (n_max + 1) * tts * 8;
     o_uval = b; b += EN * 8;
     o_uidx = b; b += nU * 4;
     o_tc = b; b += 64;
@@ -83,18 +87,20 @@ struct GridLds {
     int w = 0;
     w_hcur = w; w += 8;
     w_node = w; w += F * 8;
-    w_est = w; w += EN * 4 * 8;
+    w_est = w; w += EN * K * 8;  // end-state fields of order < K (the rest follow from u)
     w_eJ = w; w += EN * 8;
     w_hp = w; w += PN * 8;
     w = (w + 15) & ~15;
     w_eq = w; w += EN * 4 * 4;
     w_eflag = w; w += EN * 4;
     w_fp = w; w += PN * 4;
-    w_lut = w; w += D * LUTN * 4;
-    w_queue = w; w += 128 * 4;
-    w_misc = w; w += 8 * 4;
+    w = (w + 7) & ~7;
+    w_box = w; w += (boxcap * 4 > rmax * tts * 8) ? boxcap * 4 : rmax * tts * 8;  // also the sample times while rows are built
+    w = (w + 15) & ~15;
+    w_misc = w; w += 24 * 4;
     w_rowmap = w; w += 64;
-    w_cell = w; w += EN * rmax * tts;
+    w_list = w; w += ((nU + 1) & ~1) * 2;
+    w_cell = w; w += EN * rmax * tts + 8;  // + 8: the sample loop reads up to 7 codes past a row
     wave_bytes = (w + 15) & ~15;
     total = o_wave0 + waves * wave_bytes;
   }
@@ -107,8 +113,7 @@ using namespace dev;
 constexpr int kWPB = 4;         // waves (= nodes in flight) per workgroup
 constexpr int kBT = 64 * kWPB;
 constexpr int kTabStride = 64;  // row stride of the global time table (launch_make_tables)
-constexpr int kUB = 8;          // samples in flight per lane
-constexpr unsigned kOut = 1u << 29;
+constexpr int kUB = 8;          // samples per step of the sample loop
 
 // Orders this wave's LDS traffic: LDS executes a wave's instructions in order, so
 // only the compiler has to be kept from moving accesses across the point.
@@ -117,15 +122,17 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// misc words of a wave
+enum { M_BASE = 0, M_NMASK = 4, M_LO = 6, M_HI = 9, M_NODEQ = 12 };  // NODEQ: [D][4]
+
 template <int D, int K>
 __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int F = 4 * D + 2;
   const int nU = A.nU, ndp = A.ndp, RM = A.rmax;
-  const GridLds L(D, kWPB, nU, ndp, A.n_max, RM);
+  const GridLds L(D, K, kWPB, nU, ndp, A.n_max, RM, A.boxcap);
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const double *s_tt = (const double *)(smem + L.o_tt);
   const double *s_uval = (const double *)(smem + L.o_uval);
   const unsigned int *s_uidx = (const unsigned int *)(smem + L.o_uidx);
   const unsigned char *s_tc = smem + L.o_tc;
@@ -138,14 +145,16 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   int *s_eq = (int *)(wb + L.w_eq);
   int *s_eflag = (int *)(wb + L.w_eflag);
   int *s_fp = (int *)(wb + L.w_fp);
-  unsigned int *s_lut = (unsigned int *)(wb + L.w_lut);
-  unsigned int *s_queue = (unsigned int *)(wb + L.w_queue);
-  int *s_misc = (int *)(wb + L.w_misc);  // [0..2] base cell of the node per axis
+  unsigned int *s_box = (unsigned int *)(wb + L.w_box);
+  double *s_trow = (double *)(wb + L.w_box);  // [RM][tts] sample times, live only while the rows are built
+  int *s_misc = (int *)(wb + L.w_misc);
   unsigned char *s_rowmap = wb + L.w_rowmap;
+  unsigned short *s_list = (unsigned short *)(wb + L.w_list);
   unsigned char *s_cell = wb + L.w_cell;
 
-  const int tts = L.tts, EN = L.EN, PN = L.PN, LUTN = L.LUTN;
-  const int half = A.n_max + 2;  // cell-offset code = offset + half
+  const int tts = L.tts, EN = L.EN, PN = L.PN;
+  const int half = A.n_max + 2;  // cell-offset code = offset from the node's cell + half
+  const int code_max = 2 * half;
   const double T = A.dt;
   const double org[3] = {A.org0, A.org1, A.org2};
   const int dims[3] = {A.dim0, A.dim1, A.dim2};
@@ -153,11 +162,6 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
 
   // ---- once per (persistent) workgroup: shared read-only tables
   {
-    double *tt = (double *)(smem + L.o_tt);
-    for (int i = threadIdx.x; i < (A.n_max + 1) * tts; i += kBT) {
-      const int n = i / tts, k = i - n * tts;
-      tt[i] = A.ttab[n * kTabStride + k];
-    }
     double *uv = (double *)(smem + L.o_uval);
     for (int i = threadIdx.x; i < EN; i += kBT) {
       const int ax = i / ndp, j = i - ax * ndp;
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
     if (lane < F) s_node[lane] = nxt;
     if (node + wave_stride < A.n_nodes && lane < F)
       nxt = A.nodes[(int64_t)lane * A.node_stride + node + wave_stride];
-    s_rowmap[lane] = 0xff;
+    if (lane < 2) s_misc[M_NMASK + lane] = 0;
     wave_sync();
 
     // ---- phase T1: axis entries; node hash (lane 63)
@@ -207,10 +211,11 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         const double nv_ = q.template vel<true>(T);
         const double na_ = q.template acc<true>(T);
         const double nj_ = q.template jrk<true>(T);
-        s_est[lane * 4 + 0] = np_;
-        s_est[lane * 4 + 1] = nv_;
-        s_est[lane * 4 + 2] = na_;
-        s_est[lane * 4 + 3] = nj_;
+        // fields of order < K; order K is 0.0 + u and the higher ones are 0 (primitive.h:128-145)
+        s_est[lane * K + 0] = np_;
+        if (K >= 2) s_est[lane * K + 1] = nv_;
+        if (K >= 3) s_est[lane * K + 2] = na_;
+        if (K >= 4) s_est[lane * K + 3] = nj_;
         s_eq[lane * 4 + 0] = quantise(np_, 0.01, A.R001);
         s_eq[lane * 4 + 1] = (K >= 2) ? quantise(nv_, 0.1, A.R01) : 0;
         s_eq[lane * 4 + 2] = (K >= 3) ? quantise(na_, 0.1, A.R01) : 0;
@@ -218,26 +223,24 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         s_eJ[lane] = u * u * T;  // Primitive::J of a forward primitive (see expand_kernel.hip)
         flag = (valid ? 1 : 0) | ((p == np_) ? 2 : 0) | (n << 8);
         if (jv == 0) {
-          // reference cell of the node on this axis (any integer would do: offsets are relative to it)
+          // the node's own cell on this axis (map_util.h:103-108); the codes are offsets from it.
+          // Every negative cell is outside the map alike, so -1 stands for all of them.
           const double qd = div_by(p - org[ax], A.res, A.Rres);
-          s_misc[ax] = (qd - 0.5 > -0.5) ? (int)qd : -1;
+          s_misc[M_BASE + ax] = (qd - 0.5 > -0.5) ? (int)qd : -1;
         }
       }
       s_eflag[lane] = flag;
-    } else if (lane == 63) {
-      double p[D], v[D], a[D], j[D];
-#pragma unroll
-      for (int i = 0; i < D; i++) {
-        p[i] = s_node[0 * D + i];
-        v[i] = (K >= 2) ? s_node[1 * D + i] : 0.0;
-        a[i] = (K >= 3) ? s_node[2 * D + i] : 0.0;
-        j[i] = (K >= 4) ? s_node[3 * D + i] : 0.0;
+    } else if (lane >= 48 && lane < 48 + 4 * D) {
+      // lattice integers of the node itself (waypoint.h:93-125), one field per lane
+      const int i = (lane - 48) >> 2, f = (lane - 48) & 3;
+      if (f < K) {
+        const double x = s_node[f * D + i];
+        s_misc[M_NODEQ + i * 4 + f] = f == 0 ? quantise(x, 0.01, A.R001) : quantise(x, 0.1, A.R01);
       }
-      s_hcur[0] = lattice_hash<D, K>(p, v, a, j, A.R001, A.R01);
     }
     wave_sync();
 
-    // ---- prefix tables over the first D-1 axes; address LUT of the neighbourhood
+    // ---- prefix tables over the first D-1 axes
     for (int x = lane; x < PN; x += 64) {
       int e0, e1 = 0;
       bool ok;
@@ -274,73 +277,200 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         s_fp[x] = f;
       }
     }
-    for (int x = lane; x < D * LUTN; x += 64) {
-      const int ax = x / LUTN, d = x - ax * LUTN;
-      const int c = s_misc[ax] + d - half;
-      unsigned int w = kOut;
-      if (c >= 0 && c < dims[ax]) {
-        if (D == 3) {
-          if (ax == 0) w = (unsigned)(((c >> 3) * 16) << 5) | (unsigned)(c & 7);
-          else if (ax == 1) w = (unsigned)((((c >> 3) * A.nbx * 16) + ((c >> 2) & 1)) << 5) | (unsigned)((c & 3) << 3);
-          else w = (unsigned)((((c >> 3) * A.nbx * A.nby * 16) + ((c & 7) << 1)) << 5);
-        } else {
-          if (ax == 0) w = (unsigned)(((c >> 5) * 16) << 5) | (unsigned)(c & 31);
-          else w = (unsigned)((((c >> 4) * A.nbx * 16) + (c & 15)) << 5);
-        }
-      }
-      s_lut[x] = w;
-    }
     wave_sync();
 
-    const uint64_t hcur = s_hcur[0];
+    uint64_t hcur = 0;  // hash of the node, folded by every lane alike (no divergence)
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      const int4 q = *(const int4 *)(s_misc + M_NODEQ + i * 4);
+      fold(hcur, q.x);
+      if (K >= 2) fold(hcur, q.y);
+      if (K >= 3) fold(hcur, q.z);
+      if (K >= 4) fold(hcur, q.w);
+    }
     const double node_t = s_node[4 * D + 1];
-    int qn = 0;       // queued emitted pairs (uniform)
-    int drained = 0;  // successors already written for this node (uniform)
-    int nrows = 0;    // rows in the cell-row cache (uniform)
+    int base_c[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) base_c[i] = (i < D) ? __builtin_amdgcn_readfirstlane(s_misc[M_BASE + i]) : 0;
 
+    // ---- phase A: every pair; ordered list of the emitted ones; sample counts in use
+    int E = 0;  // emitted successors of the node (uniform)
     for (int base = 0; base < nU; base += 64) {
-      // ---- phase A: 64 pairs
-      {
-        const int ci = base + lane;
-        bool emit = false;
-        unsigned int info = 0;
-        if (ci < nU) {
-          const unsigned int pk = s_uidx[ci];
-          const int j0 = pk & 255, j1 = (pk >> 8) & 255, j2 = (pk >> 16) & 255;
-          const int px = (D == 3) ? j0 * ndp + j1 : j0;
-          const int eL = (D - 1) * ndp + ((D == 3) ? j2 : j1);
-          uint64_t h = s_hp[px];
-          const int4 q = *(const int4 *)(s_eq + eL * 4);
-          fold(h, q.x);
-          if (K >= 2) fold(h, q.y);
-          if (K >= 3) fold(h, q.z);
-          if (K >= 4) fold(h, q.w);
-          const int f0 = s_fp[px], f1 = s_eflag[eL];
-          const int fl = f0 & f1;
-          const int n0 = f0 >> 8, n1 = f1 >> 8;
-          const int n = (fl & 2) ? 0 : (n0 > n1 ? n0 : n1);  // unchanged position: not traversed (env_map.h:163)
-          emit = (fl & 1) && (h != hcur);                    // env_map.h:158: `tn == curr` is a hash comparison
-          info = (pk & 15u) | (((pk >> 8) & 15u) << 4) | (((pk >> 16) & 15u) << 8) | ((unsigned)n << 12) |
-                 ((unsigned)ci << 18);
-        }
-        const unsigned long long m = __ballot(emit);
-        if (emit) s_queue[qn + __popcll(m & ((1ull << lane) - 1ull))] = info;
-        qn += __popcll(m);
+      const int ci = base + lane;
+      bool emit = false;
+      int n = 0;
+      if (ci < nU) {
+        const unsigned int pk = s_uidx[ci];
+        const int j0 = pk & 255, j1 = (pk >> 8) & 255, j2 = (pk >> 16) & 255;
+        const int px = (D == 3) ? __umul24(j0, ndp) + j1 : j0;
+        const int eL = (D - 1) * ndp + ((D == 3) ? j2 : j1);
+        uint64_t h = s_hp[px];
+        const int4 q = *(const int4 *)(s_eq + eL * 4);
+        fold(h, q.x);
+        if (K >= 2) fold(h, q.y);
+        if (K >= 3) fold(h, q.z);
+        if (K >= 4) fold(h, q.w);
+        const int f0 = s_fp[px], f1 = s_eflag[eL];
+        const int fl = f0 & f1;
+        const int n0 = f0 >> 8, n1 = f1 >> 8;
+        n = (fl & 2) ? 0 : (n0 > n1 ? n0 : n1);  // unchanged position: not traversed (env_map.h:163)
+        emit = (fl & 1) && (h != hcur);          // env_map.h:158: `tn == curr` is a hash comparison
       }
-      const bool last = base + 64 >= nU;
-      // ---- phase D: drain the queue, 64 dense lanes at a time
-      while (qn >= 64 || (last && qn > 0)) {
-        wave_sync();
-        const int cnt_d = qn < 64 ? qn : 64;
-        const bool act = lane < cnt_d;
-        const unsigned int info = s_queue[act ? lane : 0];
-        const int j0 = info & 15, j1 = (info >> 4) & 15, j2 = (info >> 8) & 15;
-        const int n = act ? (int)((info >> 12) & 63u) : 0;
-        const int ci = info >> 18;
-        int en[3] = {j0, ndp + j1, 2 * ndp + j2};
-        const int64_t idx = node * (int64_t)nU + drained + lane;
-        if (act && !(A.dbg & 2)) {
-          const int px = (D == 3) ? j0 * ndp + j1 : j0;
+      const unsigned long long m = __ballot(emit);
+      if (emit) {
+        s_list[E + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)ci;
+        if (n) atomicOr((unsigned int *)&s_misc[M_NMASK + (n >> 5)], 1u << (n & 31));
+      }
+      E += __popcll(m);
+    }
+    wave_sync();
+    if (lane == 0 && A.l_count) A.l_count[node] = E;
+    unsigned long long nm = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(s_misc[M_NMASK]) |
+                            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(s_misc[M_NMASK + 1]) << 32);
+    if (A.dbg & 1) nm = 0;  // timing ablation: no sampling
+
+    // ---- rounds of up to RM sample counts
+    for (int pass = 0; pass == 0 || nm != 0ull; pass++) {
+      // this round's sample counts and their rows
+      unsigned long long sub = 0;
+      {
+        unsigned long long t = nm;
+        for (int r = 0; r < RM && t; r++) {
+          sub |= t & (~t + 1ull);
+          t &= t - 1ull;
+        }
+      }
+      nm &= ~sub;
+      wave_sync();
+      s_rowmap[lane] = ((sub >> lane) & 1ull) ? (unsigned char)__popcll(sub & ((1ull << lane) - 1ull)) : 0xff;
+      if (lane < D) {
+        s_misc[M_LO + lane] = 0x7fffffff;
+        s_misc[M_HI + lane] = -1;
+      }
+      {
+        // the accumulated sample times of this pass' rows: one global round trip for all of them
+        const int n_sub = __popcll(sub);
+        for (int i = lane; i < n_sub * tts; i += 64) {
+          const int row = i / tts, k = i - row * tts;
+          unsigned long long t = sub;
+          for (int r = 0; r < row; r++) t &= t - 1ull;
+          const int nn = __ffsll((long long)t) - 1;
+          s_trow[i] = A.ttab[nn * kTabStride + k];
+        }
+      }
+      wave_sync();
+      // rows: cell-offset codes of every axis entry at t_0 .. t_{cnt-1} of each sample count;
+      // lanes = (value, k) of ONE axis at a time, so everything per axis is scalar
+      {
+        int row = 0;
+        for (unsigned long long t = sub; t; t &= t - 1ull, row++) {
+          const int nn = __ffsll((long long)t) - 1;
+          const int cn = (int)s_tc[nn];
+          const float inv_cn = 1.0f / (float)cn;
+          const double *trow = s_trow + row * tts;
+#pragma unroll
+          for (int ax = 0; ax < D; ax++) {
+            const double p0 = s_node[0 * D + ax];
+            const double v0 = (K >= 2) ? s_node[1 * D + ax] : 0.0;
+            const double a0 = (K >= 3) ? s_node[2 * D + ax] : 0.0;
+            const double j0 = (K >= 4) ? s_node[3 * D + ax] : 0.0;
+            const int shift = half - base_c[ax];
+            int lo_l = 0x7fffffff, hi_l = -1;
+            for (int x = lane; x < nd[ax] * cn; x += 64) {
+              const int jv = (int)(((float)x + 0.5f) * inv_cn);  // exact: x < 2^12
+              const int k = x - __umul24(jv, cn);
+              const int aj = ax * ndp + jv;
+              Ax<K> q;
+              q.init(p0, v0, a0, j0, s_uval[aj]);
+              // map_util.h:103-108: cell = round((pos - origin) / res - 0.5)
+              const double qd = div_by(q.template pos<false>(trow[k]) - org[ax], A.res, A.Rres);
+              // qd - 0.5 > -0.5 <=> the rounded cell is >= 0; then qd > 0 and (qd - 0.5 being exact
+              // for qd >= 0.5) round-half-away(qd - 0.5) == trunc(qd).  Negative cells: see M_BASE.
+              const int c = (qd - 0.5 > -0.5) ? (int)qd : -1;
+              int code = c + shift;
+              code = code < 0 ? 0 : (code > code_max ? code_max : code);  // clamps only entries no valid pair uses
+              s_cell[__umul24(__umul24(aj, RM) + row, tts) + k] = (unsigned char)code;
+              if (s_eflag[aj] & 1) {
+                lo_l = code < lo_l ? code : lo_l;
+                hi_l = code > hi_l ? code : hi_l;
+              }
+            }
+            if (hi_l >= 0) {
+              atomicMin(&s_misc[M_LO + ax], lo_l);
+              atomicMax(&s_misc[M_HI + ax], hi_l);
+            }
+          }
+        }
+      }
+      wave_sync();
+      // the box of codes the valid entries reach, and its blocked bits
+      int lo[3] = {0, 0, 0}, nb[3] = {1, 1, 1};
+      bool have_box = true;
+#pragma unroll
+      for (int i = 0; i < D; i++) {
+        lo[i] = __builtin_amdgcn_readfirstlane(s_misc[M_LO + i]);
+        const int hi = __builtin_amdgcn_readfirstlane(s_misc[M_HI + i]);
+        if (hi < lo[i]) have_box = false;
+        nb[i] = hi - lo[i] + 1;
+      }
+      const int WX = (nb[0] + 31) >> 5;
+      const int n_rows = nb[1] * nb[2];
+      const bool fits = have_box && n_rows * WX <= A.boxcap;
+      if (fits && sub) {
+        const float inv_ny = 1.0f / (float)nb[1];
+        const int ax0 = base_c[0] + lo[0] - half;
+        constexpr int SU = 4;  // rows per lane with their loads in flight together
+        const int ayb = base_c[1] + lo[1] - half, azb = (D == 3) ? base_c[2] + lo[2] - half : 0;
+        for (int w = 0; w < WX; w++) {
+          const int xw = ax0 + 32 * w;
+          const int vlo = xw < 0 ? -xw : 0;
+          const int vhi = (dims[0] - xw) < 32 ? (dims[0] - xw) : 32;
+          const unsigned int mask = (vhi >= 32 ? 0xffffffffu : ((1u << (vhi > 0 ? vhi : 0)) - 1u)) & ~((1u << vlo) - 1u);
+          for (int r0 = lane; r0 < n_rows; r0 += 64 * SU) {
+            unsigned int a0[SU], a1[SU], shf[SU];
+            bool in[SU];
+#pragma unroll
+            for (int u = 0; u < SU; u++) {
+              const int r = r0 + 64 * u;
+              const int rz = (D == 3) ? (int)(((float)r + 0.5f) * inv_ny) : 0;  // exact: r < 2^14
+              const int ry = r - rz * nb[1];
+              const int ay = ayb + ry, az = azb + rz;
+              in[u] = r < n_rows && vhi > vlo && ay >= 0 && ay < dims[1] && (D == 2 || (az >= 0 && az < dims[2]));
+              const int64_t off = in[u] ? ((int64_t)az * dims[1] + ay) * (int64_t)dims[0] + xw : 0;
+              const int64_t wi = off >> 5;
+              shf[u] = (unsigned)(off & 31);
+              const int64_t w0 = wi < 0 ? 0 : wi;
+              const int64_t w1 = wi + 1 >= A.blk_words ? A.blk_words - 1 : wi + 1;
+              a0[u] = A.blk[w0];
+              a1[u] = A.blk[w1 < 0 ? 0 : w1];
+            }
+#pragma unroll
+            for (int u = 0; u < SU; u++) {
+              const int r = r0 + 64 * u;
+              const unsigned int val = in[u] ? (__builtin_amdgcn_alignbit(a1[u], a0[u], shf[u]) | ~mask) : 0xffffffffu;
+              if (r < n_rows) s_box[r * WX + w] = val;
+            }
+          }
+        }
+      }
+      wave_sync();
+
+      // ---- phase D: the list, 64 dense lanes at a time
+      const int rowc = lo[1] + nb[1] * lo[2];
+      for (int e0 = 0; e0 < E; e0 += 64) {
+        const int e = e0 + lane;
+        const bool act = e < E;
+        const int ci = act ? (int)s_list[e] : 0;
+        const unsigned int pk = s_uidx[ci];
+        const int j0 = pk & 255, j1 = (pk >> 8) & 255, j2 = (pk >> 16) & 255;
+        const int en[3] = {j0, ndp + j1, 2 * ndp + j2};
+        const int px = (D == 3) ? __umul24(j0, ndp) + j1 : j0;
+        const int f0 = s_fp[px], f1 = s_eflag[en[D - 1]];
+        const int n0 = f0 >> 8, n1 = f1 >> 8;
+        const int n = (f0 & f1 & 2) ? 0 : (n0 > n1 ? n0 : n1);
+        const bool mine = act && (n ? ((sub >> n) & 1ull) != 0ull : pass == 0);
+        const int64_t idx = node * (int64_t)nU + e;
+        if (mine && !(A.dbg & 2)) {
           uint64_t h = s_hp[px];
           const int4 q = *(const int4 *)(s_eq + en[D - 1] * 4);
           fold(h, q.x);
@@ -354,104 +484,79 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
             const int64_t ss = A.l_stride;
 #pragma unroll
             for (int i = 0; i < D; i++) {
-              const double *st = s_est + en[i] * 4;
+              const double *st = s_est + en[i] * K;
+              const double uK = 0.0 + s_uval[en[i]];
               o[(0 * D + i) * ss] = st[0];
-              o[(1 * D + i) * ss] = st[1];
-              o[(2 * D + i) * ss] = st[2];
-              o[(3 * D + i) * ss] = st[3];
+              o[(1 * D + i) * ss] = (K >= 2) ? st[1] : uK;
+              o[(2 * D + i) * ss] = (K >= 3) ? st[2] : (K == 2 ? uK : 0.0);
+              o[(3 * D + i) * ss] = (K >= 4) ? st[3] : (K == 3 ? uK : 0.0);
             }
             o[(4 * D) * ss] = 0.0;                // Waypoint::yaw of a control without yaw (primitive.h:322)
             o[(4 * D + 1) * ss] = node_t + A.dt;  // env_map.h:161
           }
         }
         // ---- the sample loop of traverse_primitive (env_map.h:97-120)
-        const int cntl = (int)s_tc[n];  // iterations of `for (t = 0; t < T; t += T/n)`; tc[0] == 0
-        int fb = -1;                    // first blocked sample
-        unsigned long long pend = (A.dbg & 1) ? 0ull : __ballot(act && n != 0);
-        while (pend) {
-          const bool inp = (pend >> lane) & 1ull;
-          int r = inp ? (int)s_rowmap[n] : 0;
-          unsigned long long miss = __ballot(inp && r == 0xff);
-          if (miss == pend && nrows == RM) {  // nothing usable and no room: start the cache over
-            s_rowmap[lane] = 0xff;
-            nrows = 0;
-            wave_sync();
-          }
-          while (miss && nrows < RM) {
-            const int src = __ffsll((long long)miss) - 1;
-            const int nn = __builtin_amdgcn_readlane(n, src);
-            // build the row of sample count nn: cell-offset codes of every axis entry at t_0 .. t_{cnt-1}
-            const int cn = (int)s_tc[nn];
-            const float inv_cn = 1.0f / (float)cn;
-            for (int x = lane; x < EN * cn; x += 64) {
-              const int aj = (int)(((float)x + 0.5f) * inv_cn);  // exact: x < 2^12
-              const int k = x - aj * cn;
-              const int ax = aj / ndp, jv = aj - ax * ndp;
-              if (jv >= nd[ax]) continue;
-              Ax<K> q;
-              q.init(s_node[0 * D + ax], (K >= 2) ? s_node[1 * D + ax] : 0.0, (K >= 3) ? s_node[2 * D + ax] : 0.0,
-                     (K >= 4) ? s_node[3 * D + ax] : 0.0, s_uval[aj]);
-              const double t = s_tt[nn * tts + k];
-              // map_util.h:103-108: cell = round((pos - origin) / res - 0.5), then bounds.
-              const double qd = div_by(q.template pos<false>(t) - org[ax], A.res, A.Rres);
-              const double sh = qd - 0.5;
-              // sh > -0.5  <=>  the rounded cell is >= 0; then qd > 0 and (qd - 0.5 being exact for
-              // qd >= 0.5) round-half-away(sh) == trunc(qd).  Otherwise the cell is negative: outside.
-              int code = 0xff;
-              if (sh > -0.5) {
-                int d = (int)qd - s_misc[ax] + half;
-                d = d < 0 ? 0 : (d > LUTN - 1 ? LUTN - 1 : d);  // out of range only for entries no valid pair uses
-                code = d;
-              }
-              s_cell[(aj * RM + nrows) * tts + k] = (unsigned char)code;
-            }
-            if (lane == 0) s_rowmap[nn] = (unsigned char)nrows;
-            const unsigned long long same = __ballot(inp && n == nn);
-            if (n == nn) r = nrows;
-            nrows++;
-            miss &= ~same;
-            wave_sync();
-          }
-          const unsigned long long ready = pend & ~miss;
-          const bool rdy = (ready >> lane) & 1ull;
-          {
-            int ptr[D];
+        const bool smp = mine && n != 0;
+        const int cntl = smp ? (int)s_tc[n] : 0;  // iterations of `for (t = 0; t < T; t += T/n)`
+        int fb = -1;                              // first blocked sample
+        {
+          const int r = smp ? (int)s_rowmap[n] : 0;
+          int ptr[3] = {0, 0, 0};
 #pragma unroll
-            for (int i = 0; i < D; i++) ptr[i] = (en[i] * RM + r) * tts;
-            const int cl = rdy ? cntl : 0;
-            bool done = !rdy;
+          for (int i = 0; i < D; i++) ptr[i] = __umul24(__umul24(en[i], RM) + r, tts);
+          bool done = !smp;
+          if (fits) {
             for (int k0 = 0; __ballot(!done) != 0ull; k0 += kUB) {
-              unsigned int w[kUB], word[kUB];
-              bool out[kUB];
+              unsigned int m = 0;
+              if (WX == 1) {  // the box is at most 32 cells wide: one word per (y, z) row
 #pragma unroll
-              for (int q = 0; q < kUB; q++) {
-                int k = k0 + q;
-                k = k < cl ? k : (cl > 0 ? cl - 1 : 0);
-                unsigned int any = 0, sum = 0;
+                for (int q = 0; q < kUB; q++) {
+                  const int k = k0 + q;
+                  const int ex = s_cell[ptr[0] + k];
+                  const int ey = s_cell[ptr[1] + k];
+                  const int ez = (D == 3) ? (int)s_cell[ptr[2] + k] : 0;
+                  const unsigned int word = s_box[(D == 3 ? __umul24(nb[1], ez) : 0) + ey - rowc];
+                  m |= ((word >> (ex - lo[0])) & 1u) << q;
+                }
+              } else {
+#pragma unroll
+                for (int q = 0; q < kUB; q++) {
+                  const int k = k0 + q;
+                  const int ex = s_cell[ptr[0] + k];
+                  const int ey = s_cell[ptr[1] + k];
+                  const int ez = (D == 3) ? (int)s_cell[ptr[2] + k] : 0;
+                  const int dx = ex - lo[0];
+                  const unsigned int word = s_box[__umul24((D == 3 ? __umul24(nb[1], ez) : 0) + ey - rowc, WX) + (dx >> 5)];
+                  m |= ((word >> (dx & 31)) & 1u) << q;
+                }
+              }
+              const int left = cntl - k0;
+              if (left < kUB) m &= (1u << (left > 0 ? left : 0)) - 1u;
+              if (!done && m) { fb = k0 + __ffs((int)m) - 1; done = true; }
+              if (left <= kUB) done = true;
+            }
+          } else {
+            // box too large for LDS: straight from the blocked-bit map, one sample per step
+            for (int k = 0; __ballot(!done) != 0ull; k++) {
+              if (!done) {
+                bool inside = true;
+                int64_t cell = 0, mul = 1;
 #pragma unroll
                 for (int i = 0; i < D; i++) {
-                  const unsigned int e = done ? 0u : (unsigned)s_cell[ptr[i] + k];
-                  any |= e;
-                  const unsigned int ec = e < (unsigned)LUTN ? e : (unsigned)(LUTN - 1);
-                  sum += s_lut[i * LUTN + ec];
+                  const int c = base_c[i] + (int)s_cell[ptr[i] + k] - half;
+                  inside = inside && c >= 0 && c < dims[i];
+                  cell += mul * c;
+                  mul *= dims[i];
                 }
-                out[q] = (any & 0x80u) || sum >= kOut;
-                w[q] = sum;
+                const bool blocked = !inside || ((A.blk[inside ? (cell >> 5) : 0] >> (cell & 31)) & 1u);
+                if (blocked) { fb = k; done = true; }
+                if (k + 1 >= cntl) done = true;
               }
-#pragma unroll
-              for (int q = 0; q < kUB; q++) word[q] = A.blk[(out[q] || done) ? 0u : (w[q] >> 5)];
-#pragma unroll
-              for (int q = 0; q < kUB; q++) {
-                const bool blocked = out[q] || ((word[q] >> (w[q] & 31u)) & 1u);
-                if (!done && k0 + q < cl && blocked) { fb = k0 + q; done = true; }
-              }
-              if (k0 + kUB >= cl) done = true;
             }
           }
-          pend = miss;
         }
         // ---- cost (env_map.h:162-169) and iteration count
-        if (act && !(A.dbg & 4)) {
+        if (mine && !(A.dbg & 4)) {
           const bool blocked = fb >= 0;
           double J = 0;
 #pragma unroll
@@ -460,52 +565,23 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
           if (A.l_cost) A.l_cost[idx] = cost;
           if (A.l_iters) A.l_iters[idx] = blocked ? fb + 1 : cntl;
         }
-        // ---- pop 64 entries
-        drained += cnt_d;
-        const unsigned int mv = (lane + 64 < qn) ? s_queue[lane + 64] : 0u;
-        wave_sync();
-        if (lane + 64 < qn) s_queue[lane] = mv;
-        qn -= cnt_d;
       }
     }
-    if (lane == 0 && A.l_count) A.l_count[node] = drained;
   }
 }
 
-// Blocked-bit map: 1 bit per cell, 1 = occupied (map == 100), outside the search
-// region, or padding; bricks of 8x8x8 cells (2D: 32x16) = 16 dwords.
-template <int D>
-__global__ void build_blocked_bits_kernel(const int8_t *map, const uint32_t *region, int dim0, int dim1, int dim2,
-                                          int nbx, int nby, int64_t n_dwords, uint32_t *out) {
+// Blocked-bit map: 1 bit per cell in the map's own order (x fastest), 1 = occupied
+// (map == 100) or outside the search region.
+__global__ void build_blocked_bits_kernel(const int8_t *map, const uint32_t *region, int64_t n_cells, int64_t n_words,
+                                          uint32_t *out) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n_dwords) return;
-  const int64_t b = g >> 4;
-  const int dw = (int)(g & 15);
+  if (g >= n_words) return;
   uint32_t bits = 0;
-  if (D == 3) {
-    const int bx = (int)(b % nbx), by = (int)((b / nbx) % nby), bz = (int)(b / ((int64_t)nbx * nby));
-    const int z = bz * 8 + (dw >> 1);
-    for (int bit = 0; bit < 32; bit++) {
-      const int y = by * 8 + (dw & 1) * 4 + (bit >> 3), x = bx * 8 + (bit & 7);
-      bool blocked = true;
-      if (x < dim0 && y < dim1 && z < dim2) {
-        const int64_t idx = x + (int64_t)dim0 * y + (int64_t)dim0 * dim1 * z;
-        blocked = map[idx] == 100 || (region != nullptr && !((region[idx >> 5] >> (idx & 31)) & 1u));
-      }
-      bits |= (blocked ? 1u : 0u) << bit;
-    }
-  } else {
-    const int bx = (int)(b % nbx), by = (int)(b / nbx);
-    const int y = by * 16 + dw;
-    for (int bit = 0; bit < 32; bit++) {
-      const int x = bx * 32 + bit;
-      bool blocked = true;
-      if (x < dim0 && y < dim1) {
-        const int64_t idx = x + (int64_t)dim0 * y;
-        blocked = map[idx] == 100 || (region != nullptr && !((region[idx >> 5] >> (idx & 31)) & 1u));
-      }
-      bits |= (blocked ? 1u : 0u) << bit;
-    }
+  const uint32_t reg = region ? region[g] : 0xffffffffu;
+  for (int b = 0; b < 32; b++) {
+    const int64_t idx = g * 32 + b;
+    const bool blocked = idx >= n_cells || map[idx] == 100 || !((reg >> b) & 1u);
+    bits |= (blocked ? 1u : 0u) << b;
   }
   out[g] = bits;
 }
@@ -515,7 +591,7 @@ hipError_t launch_grid_inst(const GridArgs &a, hipStream_t stream) {
   if (a.n_nodes == 0) return hipSuccess;
   const int64_t n_wg = (a.n_nodes + kWPB - 1) / kWPB;
   const int64_t blocks = n_wg < (int64_t)a.grid_limit ? n_wg : (int64_t)a.grid_limit;
-  const size_t lds = grid_lds_bytes(D, a.nU, a.ndp, a.n_max, a.rmax);
+  const size_t lds = grid_lds_bytes(D, K, a.nU, a.ndp, a.n_max, a.rmax, a.boxcap);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)expand_grid_kernel<D, K>,
@@ -529,35 +605,16 @@ hipError_t launch_grid_inst(const GridArgs &a, hipStream_t stream) {
 
 }  // namespace
 
-size_t grid_lds_bytes(int dim, int nU, int ndp, int n_max, int rmax) {
-  return (size_t)GridLds(dim, kWPB, nU, ndp, n_max, rmax).total;
+size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap) {
+  return (size_t)GridLds(dim, order, kWPB, nU, ndp, n_max, rmax, boxcap).total;
 }
 int grid_waves_per_block() { return kWPB; }
 
-void blocked_bits_geometry(int dim, const int32_t *mdim, int *nbx, int *nby, int64_t *n_dwords) {
-  if (dim == 3) {
-    *nbx = (mdim[0] + 7) / 8;
-    *nby = (mdim[1] + 7) / 8;
-    *n_dwords = (int64_t)(*nbx) * (*nby) * ((mdim[2] + 7) / 8) * 16;
-  } else {
-    *nbx = (mdim[0] + 31) / 32;
-    *nby = (mdim[1] + 15) / 16;
-    *n_dwords = (int64_t)(*nbx) * (*nby) * 16;
-  }
-}
-
-hipError_t launch_build_blocked_bits(int dim, const int8_t *map, const uint32_t *region, const int32_t *mdim,
-                                     uint32_t *out, hipStream_t stream) {
-  int nbx, nby;
-  int64_t n;
-  blocked_bits_geometry(dim, mdim, &nbx, &nby, &n);
-  const unsigned blocks = (unsigned)((n + 255) / 256);
-  if (dim == 3)
-    hipLaunchKernelGGL(build_blocked_bits_kernel<3>, dim3(blocks), dim3(256), 0, stream, map, region, mdim[0], mdim[1],
-                       mdim[2], nbx, nby, n, out);
-  else
-    hipLaunchKernelGGL(build_blocked_bits_kernel<2>, dim3(blocks), dim3(256), 0, stream, map, region, mdim[0], mdim[1],
-                       1, nbx, nby, n, out);
+hipError_t launch_build_blocked_bits(const int8_t *map, const uint32_t *region, int64_t n_cells, uint32_t *out,
+                                     hipStream_t stream) {
+  const int64_t n_words = (n_cells + 31) >> 5;
+  const unsigned blocks = (unsigned)((n_words + 255) / 256);
+  hipLaunchKernelGGL(build_blocked_bits_kernel, dim3(blocks), dim3(256), 0, stream, map, region, n_cells, n_words, out);
   return hipGetLastError();
 }
 

@@ -438,7 +438,7 @@ TilePlan plan_tile(const mplx_ctx *c) {
 
 struct GridPlan {
   bool ok = false;
-  int ndp = 1, n_max = 0, rmax = 0, grid = 0;
+  int ndp = 1, n_max = 0, rmax = 0, boxcap = 0, grid = 0;
 };
 
 // Does the factorised kernel cover the current configuration, and how is it sized?
@@ -448,12 +448,6 @@ GridPlan plan_grid(const mplx_ctx *c) {
   if (p.control & 0x10) return g;
   if (c->has_pot) return g;
   if (!c->u_factored || c->nU > 1024 || c->nU < 1) return g;
-  {
-    int nbx, nby;
-    int64_t nd;
-    mplx::blocked_bits_geometry(c->dim, c->mdim, &nbx, &nby, &nd);
-    if (nd > (1 << 24)) return g;               // word address + bit must stay below 2^29
-  }
   double vbound;
   if ((p.control & 0x0f) == MPLX_VEL) vbound = c->u_absmax;
   else if (p.v_max > 0) vbound = p.v_max;
@@ -464,14 +458,18 @@ GridPlan plan_grid(const mplx_ctx *c) {
   if (n_max < 5) n_max = 5;
   int ndp = 1;
   for (int i = 0; i < c->dim; i++) ndp = c->u_nd[i] > ndp ? c->u_nd[i] : ndp;
-  // rows of the per-wave cell-row cache: as many as keep five workgroups on a CU, at least 2
-  int rmax = 0;
-  if (const char *e = getenv("MPLX_GRID_RMAX")) rmax = atoi(e);  // tuning only
-  if (rmax < 1) {
-    for (rmax = 6; rmax > 2; rmax--)
-      if (mplx::grid_lds_bytes(c->dim, c->nU, ndp, n_max, rmax) <= 32 * 1024) break;
-  }
-  const size_t lds = mplx::grid_lds_bytes(c->dim, c->nU, ndp, n_max, rmax);
+  // LDS per wave: `rmax` rows of cell codes per axis entry and `boxcap` dwords of staged blocked bits.
+  // A box of (n_max + 3)^(D-1) rows covers every node whose per-axis velocities keep their sign.
+  const int ctl = p.control & 0x0f;
+  const int order = ctl == MPLX_VEL ? 1 : ctl == MPLX_ACC ? 2 : ctl == MPLX_JRK ? 3 : 4;
+  int rmax = 4, boxcap = (c->dim == 3) ? (n_max + 3) * (n_max + 3) : 4 * (n_max + 3);
+  if (boxcap < 64) boxcap = 64;
+  if (boxcap > 1024) boxcap = 1024;
+  if (const char *e = getenv("MPLX_GRID_RMAX")) rmax = atoi(e);      // tuning only
+  if (const char *e = getenv("MPLX_GRID_BOXCAP")) boxcap = atoi(e);  // tuning only
+  if (rmax < 1) rmax = 1;
+  while (rmax > 1 && mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rmax, boxcap) > 80 * 1024) rmax--;
+  const size_t lds = mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rmax, boxcap);
   if (lds > 160 * 1024) return g;
   int per_cu = (int)((160 * 1024) / lds);
   const int wpb = mplx::grid_waves_per_block();
@@ -480,18 +478,17 @@ GridPlan plan_grid(const mplx_ctx *c) {
   g.ndp = ndp;
   g.n_max = n_max;
   g.rmax = rmax;
+  g.boxcap = boxcap;
   g.grid = c->n_cus * per_cu;
   return g;
 }
 
 int ensure_blocked_bits(mplx_ctx *c) {
   if (c->blk_ok) return MPLX_OK;
-  int nbx, nby;
-  int64_t nd;
-  mplx::blocked_bits_geometry(c->dim, c->mdim, &nbx, &nby, &nd);
-  if (int rc = ensure(c, c->blk, (size_t)nd * 4)) return rc;
-  HIP_TRY(c, mplx::launch_build_blocked_bits(c->dim, (const int8_t *)c->map.p,
-                                             c->has_region ? (const uint32_t *)c->region_bits.p : nullptr, c->mdim,
+  const int64_t words = (c->n_cells + 31) >> 5;
+  if (int rc = ensure(c, c->blk, (size_t)words * 4)) return rc;
+  HIP_TRY(c, mplx::launch_build_blocked_bits((const int8_t *)c->map.p,
+                                             c->has_region ? (const uint32_t *)c->region_bits.p : nullptr, c->n_cells,
                                              (uint32_t *)c->blk.p, c->stream));
   c->blk_ok = true;
   return MPLX_OK;
@@ -526,10 +523,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     mplx::GridArgs a{};
     if (int rc = ensure_blocked_bits(c)) return rc;
     a.blk = (const uint32_t *)c->blk.p;
-    {
-      int64_t nd;
-      mplx::blocked_bits_geometry(c->dim, c->mdim, &a.nbx, &a.nby, &nd);
-    }
+    a.blk_words = (c->n_cells + 31) >> 5;
     a.dim0 = c->mdim[0]; a.dim1 = c->mdim[1]; a.dim2 = c->mdim[2];
     a.org0 = c->origin[0]; a.org1 = c->origin[1]; a.org2 = c->origin[2];
     a.res = c->res;
@@ -541,7 +535,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.ndp = gp.ndp;
     a.nU = c->nU;
     a.nodes = d_nodes; a.n_nodes = n_nodes; a.node_stride = node_stride;
-    a.n_max = gp.n_max; a.rmax = gp.rmax; a.grid_limit = gp.grid;
+    a.n_max = gp.n_max; a.rmax = gp.rmax; a.boxcap = gp.boxcap; a.grid_limit = gp.grid;
     if (const char *dbg = getenv("MPLX_TILE_DBG")) a.dbg = atoi(dbg);  // timing ablations, never set in production
     a.ttab = (const double *)c->tables.p;
     a.tcnt = (const unsigned char *)c->tables.p + 64 * 64 * 8;

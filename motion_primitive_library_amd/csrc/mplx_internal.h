@@ -85,8 +85,8 @@ hipError_t launch_expand_tile(int dim, int control, const TileArgs &args, hipStr
 // the control table is given per axis as its distinct values plus, per control,
 // the packed indices of its entries (j0 | j1 << 8 | j2 << 16).
 struct GridArgs {
-  const uint32_t *blk;   // blocked-bit map in bricks (launch_build_blocked_bits)
-  int32_t nbx, nby;      // bricks along x and y
+  const uint32_t *blk;   // blocked-bit map, 1 bit per cell, x fastest (launch_build_blocked_bits)
+  int64_t blk_words;
   int32_t dim0, dim1, dim2;
   double org0, org1, org2;
   double res;
@@ -100,7 +100,8 @@ struct GridArgs {
   const double *nodes;
   int64_t n_nodes, node_stride;
   int32_t n_max;         // largest sample count n (<= 61)
-  int32_t rmax;          // rows of the per-wave cell-row cache
+  int32_t rmax;          // sample counts handled per round (rows of cell codes per axis entry)
+  int32_t boxcap;        // dwords of LDS per wave for the staged blocked bits
   int32_t dbg;           // timing ablations (env MPLX_TILE_DBG); 0 in production
   int32_t grid_limit;    // persistent workgroups to launch
   const double *ttab;    // tables of launch_make_tables
@@ -114,14 +115,13 @@ struct GridArgs {
   int64_t l_stride;
   int32_t *l_iters;
 };
-size_t grid_lds_bytes(int dim, int nU, int ndp, int n_max, int rmax);
+size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap);
 int grid_waves_per_block();
 hipError_t launch_expand_grid(int dim, int control, const GridArgs &args, hipStream_t stream);
-// Blocked-bit map: 1 bit per cell (occupied, outside the search region, or
-// padding), bricks of 8x8x8 cells (2D: 32x16) of 16 dwords each.
-void blocked_bits_geometry(int dim, const int32_t *mdim, int *nbx, int *nby, int64_t *n_dwords);
-hipError_t launch_build_blocked_bits(int dim, const int8_t *map, const uint32_t *region, const int32_t *mdim,
-                                     uint32_t *out, hipStream_t stream);
+// Blocked-bit map: 1 bit per cell in map order, 1 = occupied or outside the search
+// region; (n_cells + 31) / 32 dwords.
+hipError_t launch_build_blocked_bits(const int8_t *map, const uint32_t *region, int64_t n_cells, uint32_t *out,
+                                     hipStream_t stream);
 
 // Dense slots of a chunk of nodes -> per-node successor lists (used for the
 // configurations the tiled kernel does not cover).
