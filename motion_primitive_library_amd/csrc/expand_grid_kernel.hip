@@ -343,10 +343,6 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       nm &= ~sub;
       wave_sync();
       s_rowmap[lane] = ((sub >> lane) & 1ull) ? (unsigned char)__popcll(sub & ((1ull << lane) - 1ull)) : 0xff;
-      if (lane < D) {
-        s_misc[M_LO + lane] = 0x7fffffff;
-        s_misc[M_HI + lane] = -1;
-      }
       {
         // the accumulated sample times of this pass' rows: one global round trip for all of them
         const int n_sub = __popcll(sub);
@@ -361,6 +357,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       wave_sync();
       // rows: cell-offset codes of every axis entry at t_0 .. t_{cnt-1} of each sample count;
       // lanes = (value, k) of ONE axis at a time, so everything per axis is scalar
+      int lo_l[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi_l[3] = {-1, -1, -1};  // per lane, reduced below
       {
         int row = 0;
         for (unsigned long long t = sub; t; t &= t - 1ull, row++) {
@@ -375,7 +372,6 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
             const double a0 = (K >= 3) ? s_node[2 * D + ax] : 0.0;
             const double j0 = (K >= 4) ? s_node[3 * D + ax] : 0.0;
             const int shift = half - base_c[ax];
-            int lo_l = 0x7fffffff, hi_l = -1;
             for (int x = lane; x < nd[ax] * cn; x += 64) {
               const int jv = (int)(((float)x + 0.5f) * inv_cn);  // exact: x < 2^12
               const int k = x - __umul24(jv, cn);
@@ -391,28 +387,32 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               code = code < 0 ? 0 : (code > code_max ? code_max : code);  // clamps only entries no valid pair uses
               s_cell[__umul24(__umul24(aj, RM) + row, tts) + k] = (unsigned char)code;
               if (s_eflag[aj] & 1) {
-                lo_l = code < lo_l ? code : lo_l;
-                hi_l = code > hi_l ? code : hi_l;
+                lo_l[ax] = code < lo_l[ax] ? code : lo_l[ax];
+                hi_l[ax] = code > hi_l[ax] ? code : hi_l[ax];
               }
-            }
-            if (hi_l >= 0) {
-              atomicMin(&s_misc[M_LO + ax], lo_l);
-              atomicMax(&s_misc[M_HI + ax], hi_l);
             }
           }
         }
       }
-      wave_sync();
-      // the box of codes the valid entries reach, and its blocked bits
+      // the box of codes the valid entries reach: butterfly min / max over the wave (no LDS
+      // atomics: hipcc serialises a divergent LDS atomic into a 64-trip scalar loop)
       int lo[3] = {0, 0, 0}, nb[3] = {1, 1, 1};
       bool have_box = true;
 #pragma unroll
       for (int i = 0; i < D; i++) {
-        lo[i] = __builtin_amdgcn_readfirstlane(s_misc[M_LO + i]);
-        const int hi = __builtin_amdgcn_readfirstlane(s_misc[M_HI + i]);
+        int mn = lo_l[i], mx = hi_l[i];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int omn = __shfl_xor(mn, d, 64), omx = __shfl_xor(mx, d, 64);
+          mn = omn < mn ? omn : mn;
+          mx = omx > mx ? omx : mx;
+        }
+        lo[i] = __builtin_amdgcn_readfirstlane(mn);
+        const int hi = __builtin_amdgcn_readfirstlane(mx);
         if (hi < lo[i]) have_box = false;
         nb[i] = hi - lo[i] + 1;
       }
+      wave_sync();  // rows complete; the sample times (aliasing the box) are no longer needed
       const int WX = (nb[0] + 31) >> 5;
       const int n_rows = nb[1] * nb[2];
       const bool fits = have_box && n_rows * WX <= A.boxcap;
