@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MPLX_ABI_VERSION 1
+#define MPLX_ABI_VERSION 2
 
 typedef struct mplx_ctx mplx_ctx;
 
@@ -132,20 +132,23 @@ int mplx_get_succ(mplx_ctx *ctx, const double *node, double *succ, double *cost,
 
 /* Per-node successor LISTS -- the reference's own output shape (succ,
  * succ_cost, action_idx of env_base.h:358-362) for a whole frontier.  Node k
- * owns the entries [k*nU, k*nU + count[k]) of every array, in ascending control
- * index; blocked successors are included with cost = +inf (env_map.h:162-170),
+ * owns the entries [k*S, k*S + count[k]) of every array, S = node_stride (or nU
+ * when node_stride is 0), in ascending control index; blocked successors are included with cost = +inf (env_map.h:162-170),
  * skipped ones are not.  Only emitted successors are written, so this is the
  * bandwidth-lean output (SURVEY.md 8d counts exactly these bytes).  Any pointer
  * but `count` may be NULL.  `state` as in mplx_succ (row stride state_stride >=
- * n_nodes*nU doubles).                                                       */
+ * n_nodes*S doubles).  A node_stride that is a multiple of 16 entries makes
+ * every 64-successor store of the kernels start on a 128-byte line (measured
+ * 11 % faster on C4 than S = 729).                                            */
 typedef struct {
   int32_t *count;          /* [n_nodes]                                       */
-  int32_t *action;         /* [n_nodes*nU] control index of each successor    */
-  double *cost;            /* [n_nodes*nU]                                    */
-  uint64_t *hash;          /* [n_nodes*nU]                                    */
+  int32_t *action;         /* [n_nodes*S] control index of each successor     */
+  double *cost;            /* [n_nodes*S]                                     */
+  uint64_t *hash;          /* [n_nodes*S]                                     */
   double *state;           /* [4D+2][state_stride]                            */
   int64_t state_stride;
   int32_t *iters;          /* diagnostic: executed sample-loop iterations     */
+  int64_t node_stride;     /* S: entries reserved per node, >= nU; 0 = nU     */
 } mplx_succ_lists;
 
 /* Batched get_succ producing lists; device pointers, asynchronous on the

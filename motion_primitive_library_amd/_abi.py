@@ -48,7 +48,7 @@ class Succ(C.Structure):
 class SuccLists(C.Structure):
     _fields_ = [
         ("count", C.c_void_p), ("action", C.c_void_p), ("cost", C.c_void_p), ("hash", C.c_void_p),
-        ("state", C.c_void_p), ("state_stride", C.c_int64), ("iters", C.c_void_p),
+        ("state", C.c_void_p), ("state_stride", C.c_int64), ("iters", C.c_void_p), ("node_stride", C.c_int64),
     ]
 
 

@@ -110,10 +110,16 @@ namespace {
 
 using namespace dev;
 
-constexpr int kWPB = 4;         // waves (= nodes in flight) per workgroup
+#ifndef MPLX_GRID_WPB
+#define MPLX_GRID_WPB 4
+#endif
+#ifndef MPLX_GRID_UB
+#define MPLX_GRID_UB 8
+#endif
+constexpr int kWPB = MPLX_GRID_WPB;  // waves (= nodes in flight) per workgroup
 constexpr int kBT = 64 * kWPB;
 constexpr int kTabStride = 64;  // row stride of the global time table (launch_make_tables)
-constexpr int kUB = 8;          // samples per step of the sample loop
+constexpr int kUB = MPLX_GRID_UB;    // samples per step of the sample loop
 
 // Orders this wave's LDS traffic: LDS executes a wave's instructions in order, so
 // only the compiler has to be kept from moving accesses across the point.
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
             const double a0 = (K >= 3) ? s_node[2 * D + ax] : 0.0;
             const double j0 = (K >= 4) ? s_node[3 * D + ax] : 0.0;
             const int shift = half - base_c[ax];
-            for (int x = lane; x < nd[ax] * cn; x += 64) {
+            for (int x = lane; x < ((A.dbg & 16) ? 0 : nd[ax] * cn); x += 64) {  // dbg 16: timing ablation
               const int jv = (int)(((float)x + 0.5f) * inv_cn);  // exact: x < 2^12
               const int k = x - __umul24(jv, cn);
               const int aj = ax * ndp + jv;
@@ -441,8 +447,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               shf[u] = (unsigned)(off & 31);
               const int64_t w0 = wi < 0 ? 0 : wi;
               const int64_t w1 = wi + 1 >= A.blk_words ? A.blk_words - 1 : wi + 1;
-              a0[u] = A.blk[w0];
-              a1[u] = A.blk[w1 < 0 ? 0 : w1];
+              a0[u] = (A.dbg & 8) ? 0u : A.blk[w0];  // dbg 8: timing ablation, no staging loads
+              a1[u] = (A.dbg & 8) ? 0u : A.blk[w1 < 0 ? 0 : w1];
             }
 #pragma unroll
             for (int u = 0; u < SU; u++) {
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         const int n0 = f0 >> 8, n1 = f1 >> 8;
         const int n = (f0 & f1 & 2) ? 0 : (n0 > n1 ? n0 : n1);
         const bool mine = act && (n ? ((sub >> n) & 1ull) != 0ull : pass == 0);
-        const int64_t idx = node * (int64_t)nU + e;
+        const int64_t idx = node * A.l_nstride + e;
         if (mine && !(A.dbg & 2)) {
           uint64_t h = s_hp[px];
           const int4 q = *(const int4 *)(s_eq + en[D - 1] * 4);

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void compact_lists_kernel(const CompactArgs A)
     for (int i = 0; i < 4; i++) { const int c = s_wsum[i]; if (i < wv) pre += c; tot += c; }
     __syncthreads();
     if (emit) {
-      const int64_t idx = node * A.nU + emitted + pre + within;
+      const int64_t idx = node * A.l_nstride + emitted + pre + within;
       if (A.l_action) A.l_action[idx] = ci;
       if (A.l_cost) A.l_cost[idx] = A.cost[slot];
       if (A.l_hash) A.l_hash[idx] = A.hash[slot];

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A) {
       if (emit) {
         const int j = ONE ? e : e - s_nbase[nl];
         s_j[v] = (unsigned short)j;
-        const int64_t idx = (node0 + nl) * (int64_t)nU + j;
+        const int64_t idx = (node0 + nl) * A.l_nstride + j;
         const bool wr = !(A.dbg & 2);  // timing ablation only
         if (wr && A.l_action) A.l_action[idx] = ci;
         if (wr && A.l_hash) A.l_hash[idx] = h_next;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A) {
 #pragma unroll
     for (int i = 0; i < D; i++) J += u[i] * u[i] * T;  // Primitive::J of a forward primitive (see expand_kernel.hip)
     const double cost = blocked ? INFINITY : 0.0 + (J + A.w * A.dt);
-    const int64_t idx = (node0 + nl) * (int64_t)nU + j;
+    const int64_t idx = (node0 + nl) * A.l_nstride + j;
     if (A.l_cost) A.l_cost[idx] = cost;
     if (A.l_iters) A.l_iters[idx] = iters;
   }

@@ -542,6 +542,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.Rres = c->recips[0]; a.R001 = c->recips[1]; a.R01 = c->recips[2];
     a.l_count = o->count; a.l_action = o->action; a.l_cost = o->cost; a.l_hash = o->hash;
     a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
+    a.l_nstride = o->node_stride ? o->node_stride : c->nU;
     HIP_TRY(c, mplx::launch_expand_grid(c->dim, c->prm.control, a, c->stream));
     c->last_route = MPLX_ROUTE_GRID;
     return MPLX_OK;
@@ -571,6 +572,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.Rres = c->recips[0]; a.R001 = c->recips[1]; a.R01 = c->recips[2];
     a.l_count = o->count; a.l_action = o->action; a.l_cost = o->cost; a.l_hash = o->hash;
     a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
+    a.l_nstride = o->node_stride ? o->node_stride : c->nU;
     HIP_TRY(c, mplx::launch_expand_tile(c->dim, c->prm.control, a, c->stream));
     c->last_route = MPLX_ROUTE_TILE;
     return MPLX_OK;
@@ -603,6 +605,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     ca.node_offset = k0; ca.n_nodes_chunk = nk;
     ca.l_count = o->count; ca.l_action = o->action; ca.l_cost = o->cost; ca.l_hash = o->hash;
     ca.l_state = o->state; ca.l_stride = o->state_stride; ca.l_iters = o->iters;
+    ca.l_nstride = o->node_stride ? o->node_stride : c->nU;
     HIP_TRY(c, mplx::launch_compact_lists(ca, c->stream));
   }
   c->last_route = MPLX_ROUTE_DENSE;
@@ -620,8 +623,10 @@ int mplx_expand_lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes
     return fail(c, MPLX_ERR_ARG, "mplx_expand_lists_device: bad arguments");
   if (int rc = ready(c)) return rc;
   if (n_nodes == 0) return MPLX_OK;
-  if (d_out->state && d_out->state_stride < n_nodes * c->nU)
-    return fail(c, MPLX_ERR_ARG, "mplx_expand_lists_device: state_stride < n_nodes*nU");
+  if (d_out->node_stride != 0 && d_out->node_stride < c->nU)
+    return fail(c, MPLX_ERR_ARG, "mplx_expand_lists_device: node_stride %lld < nU %d", (long long)d_out->node_stride, c->nU);
+  if (d_out->state && d_out->state_stride < n_nodes * (d_out->node_stride ? d_out->node_stride : c->nU))
+    return fail(c, MPLX_ERR_ARG, "mplx_expand_lists_device: state_stride < n_nodes*node_stride");
   if (int rc = bind_device(c)) return rc;
   return lists_device(c, d_nodes, n_nodes, node_stride, d_out);
 }
@@ -635,9 +640,11 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
   if (n_nodes == 0) return MPLX_OK;
   if (int rc = bind_device(c)) return rc;
   const int F = 4 * c->dim + 2;
-  const int64_t n_slots = n_nodes * c->nU;
+  if (h_out->node_stride != 0 && h_out->node_stride < c->nU)
+    return fail(c, MPLX_ERR_ARG, "mplx_expand_lists: node_stride %lld < nU %d", (long long)h_out->node_stride, c->nU);
+  const int64_t n_slots = n_nodes * (h_out->node_stride ? h_out->node_stride : c->nU);
   if (h_out->state && h_out->state_stride < n_slots)
-    return fail(c, MPLX_ERR_ARG, "mplx_expand_lists: state_stride < n_nodes*nU");
+    return fail(c, MPLX_ERR_ARG, "mplx_expand_lists: state_stride < n_nodes*node_stride");
   if (int rc = ensure(c, c->s_nodes, (size_t)F * n_nodes * sizeof(double))) return rc;
   HIP_TRY(c, hipMemcpy2DAsync(c->s_nodes.p, (size_t)n_nodes * sizeof(double), h_nodes,
                               (size_t)node_stride * sizeof(double), (size_t)n_nodes * sizeof(double), F,
@@ -654,6 +661,7 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
     d.state = (double *)c->s_state.p;
     d.state_stride = n_slots;
   }
+  d.node_stride = h_out->node_stride;
   if (int rc = lists_device(c, (const double *)c->s_nodes.p, n_nodes, n_nodes, &d)) return rc;
   HIP_TRY(c, hipMemcpyAsync(h_out->count, d.count, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, c->stream));
   if (n_nodes == 1) {

@@ -73,6 +73,7 @@ struct TileArgs {
   double *l_state;
   int64_t l_stride;
   int32_t *l_iters;
+  int64_t l_nstride;  // entries reserved per node (>= nU)
 };
 
 size_t tile_lds_bytes(int tile_pairs, int npb, int wl_cap, int n_max, int n_fields, int u_doubles,
@@ -114,6 +115,7 @@ struct GridArgs {
   double *l_state;
   int64_t l_stride;
   int32_t *l_iters;
+  int64_t l_nstride;  // entries reserved per node (>= nU)
 };
 size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap);
 int grid_waves_per_block();
@@ -141,6 +143,7 @@ struct CompactArgs {
   double *l_state;
   int64_t l_stride;
   int32_t *l_iters;
+  int64_t l_nstride;  // entries reserved per node (>= nU)
 };
 hipError_t launch_compact_lists(const CompactArgs &args, hipStream_t stream);
 

@@ -139,9 +139,11 @@ class Slots:
 class Lists:
     """HBM-resident per-node successor lists (mplx_succ_lists)."""
 
-    def __init__(self, env, n_nodes, nU, want_state=True, want_iters=False, want_hash=True):
+    def __init__(self, env, n_nodes, nU, want_state=True, want_iters=False, want_hash=True, stride=None):
         self.n_nodes, self.nU = int(n_nodes), int(nU)
-        self.n_slots = self.n_nodes * self.nU
+        # entries reserved per node: a multiple of 16 keeps every 64-successor store on 128-byte lines
+        self.stride = (self.nU + 15) & ~15 if stride is None else int(stride)
+        self.n_slots = self.n_nodes * self.stride
         self.n_fields = env.n_fields
         n = max(self.n_slots, 1)
         self.count = DeviceArray(env, max(self.n_nodes, 1) * 4)
@@ -158,10 +160,12 @@ class Lists:
         s.state = self.state.ptr if self.state else None
         s.state_stride = self.n_slots
         s.iters = self.iters.ptr if self.iters else None
+        s.node_stride = self.stride
         return s
 
     def download(self):
         out = {
+            "stride": self.stride,
             "count": self.count.download(np.int32, (self.n_nodes,)),
             "action": self.action.download(np.int32, (self.n_slots,)),
             "cost": self.cost.download(np.float64, (self.n_slots,)),
@@ -355,17 +359,20 @@ class EnvMap:
         _abi.check(self._ctx, _abi.lib().mplx_expand(self._ctx, nodes.ctypes.data, n, n, C.byref(s)))
         return out
 
-    def expand_lists(self, nodes, want_state=True, want_iters=True):
-        """Per-node successor lists of a host frontier [4D+2][N] (mplx_expand_lists)."""
+    def expand_lists(self, nodes, want_state=True, want_iters=True, stride=None):
+        """Per-node successor lists of a host frontier [4D+2][N] (mplx_expand_lists).
+        `stride` = entries reserved per node (default nU; out["stride"] reports it)."""
         self._flush()
         nodes = np.ascontiguousarray(nodes, dtype=np.float64)
         if nodes.ndim != 2 or nodes.shape[0] != self.n_fields:
             raise ValueError("nodes must be [%d][N]" % self.n_fields)
         n = nodes.shape[1]
-        ns = n * self.nU
-        out = {"count": np.zeros(n, np.int32), "action": np.zeros(ns, np.int32), "cost": np.zeros(ns, np.float64),
-               "hash": np.zeros(ns, np.uint64)}
+        stride = self.nU if stride is None else int(stride)
+        ns = n * stride
+        out = {"stride": stride, "count": np.zeros(n, np.int32), "action": np.zeros(ns, np.int32),
+               "cost": np.zeros(ns, np.float64), "hash": np.zeros(ns, np.uint64)}
         s = _abi.SuccLists()
+        s.node_stride = stride
         s.count, s.action = out["count"].ctypes.data, out["action"].ctypes.data
         s.cost, s.hash = out["cost"].ctypes.data, out["hash"].ctypes.data
         if want_state:
@@ -377,8 +384,8 @@ class EnvMap:
         _abi.check(self._ctx, _abi.lib().mplx_expand_lists(self._ctx, nodes.ctypes.data, n, n, C.byref(s)))
         return out
 
-    def alloc_lists(self, n_nodes, want_state=True, want_iters=False, want_hash=True):
-        return Lists(self, n_nodes, self.nU, want_state, want_iters, want_hash)
+    def alloc_lists(self, n_nodes, want_state=True, want_iters=False, want_hash=True, stride=None):
+        return Lists(self, n_nodes, self.nU, want_state, want_iters, want_hash, stride)
 
     def expand_lists_resident(self, frontier, lists, n_nodes=None):
         """Asynchronous launch on HBM-resident buffers (mplx_expand_lists_device)."""

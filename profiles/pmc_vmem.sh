@@ -1,0 +1,15 @@
+#!/bin/bash
+export TMPDIR=/tmp
+for d in 0 2; do
+OUT=$PWD/gpurun_out/pv$d; mkdir -p $OUT
+MPLX_TILE_DBG=$d rocprofv3 --pmc SQ_INST_CYCLES_VMEM_WR SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES -f csv -d $OUT -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/log 2>&1
+python - <<PY
+import csv,collections,glob
+for f in glob.glob("$OUT/*counter_collection.csv"):
+    agg=collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if 'grid' in r['Kernel_Name']:
+            agg[r['Counter_Name']].append(float(r['Counter_Value']))
+    print("dbg=$d", " ".join("%s=%.4g"%(k[3:],sum(v)/len(v)/65536) for k,v in sorted(agg.items())))
+PY
+done

@@ -28,13 +28,14 @@ def test_library_exports_every_declared_symbol(engine):
     for s in _declared_symbols():
         assert hasattr(lib, s), "libmplx.so does not export %s" % s
     assert sorted(engine._abi.SYMBOLS) == sorted(set(_declared_symbols()) - {"mplx_status"})
-    assert engine._abi.lib().mplx_abi_version() == 1
+    assert engine._abi.lib().mplx_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header(engine):
     # mplx_params: 2 x int32 + 9 doubles; mplx_succ: 4 pointers + int64 + pointer
     assert C.sizeof(engine._abi.Params) == 8 + 9 * 8
     assert C.sizeof(engine._abi.Succ) == 6 * 8
+    assert C.sizeof(engine._abi.SuccLists) == 8 * 8  # 6 pointers + state_stride + node_stride
 
 
 def test_no_cpu_fallback(engine):

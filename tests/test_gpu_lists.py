@@ -71,10 +71,11 @@ def test_lists_routes_agree(engine, oracle_lib, dim, control, variant):
     wl = _small_world(engine, dim, control, seed=900 * dim + control, region=(variant == "region"), n_nodes=75)
     ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
     env = engine_env(engine, wl)
-    for route in ("grid", "tile", "dense"):
+    nU = wl.U.shape[0]
+    for route, stride in (("grid", None), ("tile", nU + 5), ("dense", (nU + 15) & ~15), ("grid", nU + 16)):
         env.set_lists_route(route)
-        got = env.expand_lists(wl.nodes)
-        assert env.last_lists_route() == route
+        got = env.expand_lists(wl.nodes, stride=stride)  # node_stride: default nU, odd, and line-aligned
+        assert env.last_lists_route() == route and got["stride"] == (stride or nU)
         assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="route %s dim%d ctrl0x%x %s" % (
             route, dim, control, variant))
     env.set_lists_route("auto")
@@ -100,6 +101,15 @@ def test_lists_irregular_control_tables(engine, oracle_lib, dim, n_controls, n_d
     assert env.last_lists_route() == expect
     env.close()
     assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="irregular U %dx%d" % (n_controls, n_distinct))
+
+
+def test_node_stride_smaller_than_the_control_table_is_rejected(engine):
+    wl = _small_world(engine, 2, 0x03, seed=6, n_nodes=8)
+    env = engine_env(engine, wl)
+    with pytest.raises(engine._abi.MplxError) as e:
+        env.expand_lists(wl.nodes, stride=wl.U.shape[0] - 1)
+    assert e.value.code == engine._abi.ERR_ARG
+    env.close()
 
 
 def test_forcing_a_route_outside_its_scope_fails_loudly(engine):
