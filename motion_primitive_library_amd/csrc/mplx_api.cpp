@@ -5,8 +5,7 @@
 // host-pointer convenience calls, and a pair of events used as a stopwatch.
 // There is deliberately no CPU implementation behind this ABI: every compute
 // entry either runs the gfx950 kernels or returns an error.
-#include "../../include/mplx.h"
-#include "mplx_internal.h"
+#include "mplx_ctx.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -17,99 +16,16 @@
 #include <string>
 #include <vector>
 
-namespace {
+using namespace mplx_detail;
 
-thread_local std::string g_create_error;
-
-struct DevBuf {
-  void *p = nullptr;
-  size_t cap = 0;
-};
-
-}  // namespace
-
-struct mplx_ctx {
-  int dim = 0;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  std::string err;
-
-  // environment (device copies)
-  DevBuf map, pot, region_bits, region_bytes, U;
-  bool has_map = false, has_pot = false, has_region = false, has_params = false, has_U = false;
-  int32_t mdim[3] = {1, 1, 1};
-  double origin[3] = {0, 0, 0};
-  double res = 0;
-  int64_t n_cells = 0;
-  mplx_params prm{};
-  int32_t nU = 0, udim = 0;
-  double u_absmax = 0;  // max |u| over the spatial control entries
-  // per-axis factorisation of the control table (expand_grid_kernel.hip)
-  DevBuf uvals, uidx, blk;
-  bool blk_ok = false;   // blocked-bit map matches the current map + region
-  bool u_factored = false;
-  int32_t u_nd[3] = {0, 0, 0};
-  int lists_route = MPLX_ROUTE_AUTO;
-  int last_route = MPLX_ROUTE_AUTO;
-  int n_cus = 256;
-
-  // tables of the tiled kernel (sample times, loop counts, reciprocals)
-  DevBuf tables;
-  bool tables_ok = false;
-  double tab_dt = 0, tab_res = 0;
-  double recips[3] = {0, 0, 0};
-  // scratch for the dense -> lists route
-  DevBuf d_status, d_cost, d_hash, d_state, d_iters;
-  // staging for the host-pointer entry points
-  DevBuf s_nodes, s_status, s_cost, s_hash, s_state, s_iters, s_count, s_action;
-  std::vector<uint8_t> h_status;
-  std::vector<double> h_cost, h_state;
-};
+namespace mplx_detail {
+std::string &create_error() {
+  thread_local std::string e;
+  return e;
+}
+}  // namespace mplx_detail
 
 namespace {
-
-int fail(mplx_ctx *c, int code, const char *fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  if (c) c->err = buf; else g_create_error = buf;
-  return code;
-}
-
-#define HIP_TRY(c, expr)                                                                   \
-  do {                                                                                     \
-    hipError_t e__ = (expr);                                                               \
-    if (e__ != hipSuccess)                                                                 \
-      return fail((c), MPLX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
-                  __FILE__, __LINE__);                                                     \
-  } while (0)
-
-int bind_device(mplx_ctx *c) {
-  HIP_TRY(c, hipSetDevice(c->device));
-  return MPLX_OK;
-}
-
-int ensure(mplx_ctx *c, DevBuf &b, size_t bytes) {
-  if (bytes <= b.cap) return MPLX_OK;
-  if (b.p) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipFree(b.p));
-    b.p = nullptr;
-    b.cap = 0;
-  }
-  HIP_TRY(c, hipMalloc(&b.p, bytes));
-  b.cap = bytes;
-  return MPLX_OK;
-}
-
-void release(DevBuf &b) {
-  if (b.p) (void)hipFree(b.p);
-  b.p = nullptr;
-  b.cap = 0;
-}
 
 bool control_ok(int32_t control) {
   switch (control) {
@@ -159,7 +75,7 @@ extern "C" {
 int mplx_abi_version(void) { return MPLX_ABI_VERSION; }
 
 const char *mplx_last_error(const mplx_ctx *ctx) {
-  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+  return ctx ? ctx->err.c_str() : create_error().c_str();
 }
 
 int mplx_create(int dim, int device, mplx_ctx **out) {

@@ -1,0 +1,109 @@
+// mplx_ctx.h -- the context object behind the C ABI (include/mplx.h) and the small
+// helpers every API translation unit uses.  Private to libmplx.so.
+#ifndef MPLX_CTX_H
+#define MPLX_CTX_H
+
+#include "../../include/mplx.h"
+#include "mplx_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace mplx_detail {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+std::string &create_error();  // text of the last failed mplx_create (thread local)
+
+}  // namespace mplx_detail
+
+struct mplx_ctx {
+  int dim = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+
+  // environment (device copies)
+  mplx_detail::DevBuf map, pot, region_bits, region_bytes, U;
+  bool has_map = false, has_pot = false, has_region = false, has_params = false, has_U = false;
+  int32_t mdim[3] = {1, 1, 1};
+  double origin[3] = {0, 0, 0};
+  double res = 0;
+  int64_t n_cells = 0;
+  mplx_params prm{};
+  int32_t nU = 0, udim = 0;
+  double u_absmax = 0;  // max |u| over the spatial control entries
+  // per-axis factorisation of the control table (expand_grid_kernel.hip)
+  mplx_detail::DevBuf uvals, uidx, blk;
+  bool blk_ok = false;   // blocked-bit map matches the current map + region
+  bool u_factored = false;
+  int32_t u_nd[3] = {0, 0, 0};
+  int lists_route = MPLX_ROUTE_AUTO;
+  int last_route = MPLX_ROUTE_AUTO;
+  int n_cus = 256;
+
+  // tables of the tiled kernel (sample times, loop counts, reciprocals)
+  mplx_detail::DevBuf tables;
+  bool tables_ok = false;
+  double tab_dt = 0, tab_res = 0;
+  double recips[3] = {0, 0, 0};
+  // scratch for the dense -> lists route
+  mplx_detail::DevBuf d_status, d_cost, d_hash, d_state, d_iters;
+  // staging for the host-pointer entry points
+  mplx_detail::DevBuf s_nodes, s_status, s_cost, s_hash, s_state, s_iters, s_count, s_action;
+  std::vector<uint8_t> h_status;
+  std::vector<double> h_cost, h_state;
+};
+
+namespace mplx_detail {
+
+inline int fail(mplx_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else create_error() = buf;
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                                   \
+  do {                                                                                     \
+    hipError_t e__ = (expr);                                                               \
+    if (e__ != hipSuccess)                                                                 \
+      return mplx_detail::fail((c), MPLX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                  __FILE__, __LINE__);                                                     \
+  } while (0)
+
+inline int bind_device(mplx_ctx *c) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  return MPLX_OK;
+}
+
+inline int ensure(mplx_ctx *c, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return MPLX_OK;
+  if (b.p) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  HIP_TRY(c, hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return MPLX_OK;
+}
+
+inline void release(DevBuf &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+}  // namespace mplx_detail
+#endif
