@@ -113,6 +113,27 @@ int mplx_set_params(mplx_ctx *ctx, const mplx_params *p);
  * D+1 when the control flag carries yaw (last entry = yaw rate).             */
 int mplx_set_controls(mplx_ctx *ctx, const double *U, int32_t nU, int32_t udim);
 
+/* ---- map preprocessing on the device (the producers of the potential map and
+ *      of the search region) ------------------------------- */
+/* MapPlanner<Dim>::updatePotentialMap(pos) with createMask
+ * (src/mpl_planner/map_planner.cpp:246-283, 286-391): every cell > 0 inside the
+ * update box becomes H_MAX = 100 and stamps the int8 cone mask
+ *   H_MAX * pow((1 - hypot(n0,n1)/rn) [* (1 - |n2|/hn)], pow)
+ * around itself with `max`.  As in the reference the result REPLACES the map and
+ * is installed as the potential map.  radius: `dim` doubles
+ * (setPotentialRadius); range_or_null: `dim` doubles (setPotentialMapRange; NULL
+ * or all zero = whole map) centred on pos; pow: the reference's pow_ (1.0).
+ * h_map_out_or_null receives the new map (for the caller's MapUtil).          */
+int mplx_update_potential_map(mplx_ctx *ctx, const double *pos, const double *radius,
+                              const double *range_or_null, double pow, int8_t *h_map_out_or_null);
+/* MapPlanner<Dim>::setSearchRegion(path, dense) (map_planner.cpp:46-95): the
+ * cells along the path (MapUtil::rayTrace, map_util.h:117-135, when dense == 0 --
+ * the reference's flag is inverted and so is this one) dilated by
+ * ceil(search_radius / res) cells per axis.  path: [n_points][dim].  Installs the
+ * region like mplx_set_region; h_region_out_or_null receives one byte per cell. */
+int mplx_set_search_region_path(mplx_ctx *ctx, const double *path, int32_t n_points, int32_t dense,
+                                const double *search_radius, uint8_t *h_region_out_or_null);
+
 /* ---- expansion ---------------------------------------------------------- */
 /* Batched get_succ on device-resident buffers, asynchronous on the context
  * stream.  d_nodes is field-major [4D+2][node_stride] (same rows as `state`),

@@ -17,6 +17,7 @@ ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_STATE = -1, -2, -3, -4
 SYMBOLS = [
     "mplx_create", "mplx_destroy", "mplx_last_error", "mplx_abi_version",
     "mplx_set_map", "mplx_set_potential", "mplx_set_region", "mplx_set_params", "mplx_set_controls",
+    "mplx_update_potential_map", "mplx_set_search_region_path",
     "mplx_expand_device", "mplx_expand", "mplx_expand_lists_device", "mplx_expand_lists", "mplx_get_succ",
     "mplx_device_alloc", "mplx_device_free", "mplx_memcpy_h2d", "mplx_memcpy_d2h", "mplx_memset",
     "mplx_synchronize", "mplx_timer_begin", "mplx_timer_end",
@@ -103,6 +104,8 @@ def lib():
         "mplx_set_region": (C.c_int, [vp, vp]),
         "mplx_set_params": (C.c_int, [vp, C.POINTER(Params)]),
         "mplx_set_controls": (C.c_int, [vp, vp, i32, i32]),
+        "mplx_update_potential_map": (C.c_int, [vp, vp, vp, vp, dbl, vp]),
+        "mplx_set_search_region_path": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "mplx_expand_device": (C.c_int, [vp, vp, i64, i64, C.POINTER(Succ)]),
         "mplx_expand": (C.c_int, [vp, vp, i64, i64, C.POINTER(Succ)]),
         "mplx_expand_lists_device": (C.c_int, [vp, vp, i64, i64, C.POINTER(SuccLists)]),

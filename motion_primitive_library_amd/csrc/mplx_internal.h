@@ -125,6 +125,14 @@ hipError_t launch_expand_grid(int dim, int control, const GridArgs &args, hipStr
 hipError_t launch_build_blocked_bits(const int8_t *map, const uint32_t *region, int64_t n_cells, uint32_t *out,
                                      hipStream_t stream);
 
+// Map preprocessing (map_prep_kernel.hip).  d, c1, c2: 3 entries (unused axes 1 / [0,1)).
+hipError_t launch_potential_passes(const int8_t *map, const int32_t *d, const int32_t *c1, const int32_t *c2, int rn,
+                                   int hn, const int8_t *lut, int8_t h_max, unsigned short *tmp_a,
+                                   unsigned short *tmp_b, int8_t *out, hipStream_t s);
+hipError_t launch_region_boxes(const int *cells, int n_path_cells, int dim, const int32_t *d, const int32_t *rn,
+                               uint32_t *bits, hipStream_t s);
+hipError_t launch_unpack_region(const uint32_t *bits, int64_t n_cells, uint8_t *bytes, hipStream_t s);
+
 // Dense slots of a chunk of nodes -> per-node successor lists (used for the
 // configurations the tiled kernel does not cover).
 struct CompactArgs {

@@ -314,6 +314,29 @@ class EnvMap:
             raise ValueError("search region size mismatch")
         _abi.check(self._ctx, _abi.lib().mplx_set_region(self._ctx, mask.ctypes.data))
 
+    # ---- MapPlanner-level map preprocessing on the device (map_planner.cpp:46-95, 246-391)
+    def updatePotentialMap(self, pos, radius, range_=None, power=1.0):
+        """MapPlanner::updatePotentialMap: stamps the potential field into the device map (which it also
+        installs as the potential map, as the reference does) and returns the new int8 map."""
+        D = len(self.map_dim)
+        p = (C.c_double * 3)(*([float(x) for x in pos] + [0.0] * (3 - D)))
+        r = (C.c_double * 3)(*([float(x) for x in radius] + [0.0] * (3 - D)))
+        g = None if range_ is None else (C.c_double * 3)(*([float(x) for x in range_] + [0.0] * (3 - D)))
+        out = np.empty(self._ncell, dtype=np.int8)
+        _abi.check(self._ctx, _abi.lib().mplx_update_potential_map(self._ctx, p, r, g, float(power), out.ctypes.data))
+        return out
+
+    def setSearchRegion(self, path, search_radius, dense=False):
+        """MapPlanner::setSearchRegion: installs the tunnel around `path` ([n][D]) and returns it, one byte
+        per cell.  `dense` has the reference's (inverted) meaning: False = ray-trace between the points."""
+        D = len(self.map_dim)
+        pts = np.ascontiguousarray(path, dtype=np.float64).reshape(-1, D)
+        sr = (C.c_double * 3)(*([float(x) for x in search_radius] + [0.0] * (3 - D)))
+        out = np.empty(self._ncell, dtype=np.uint8)
+        _abi.check(self._ctx, _abi.lib().mplx_set_search_region_path(self._ctx, pts.ctypes.data, pts.shape[0],
+                                                                      int(bool(dense)), sr, out.ctypes.data))
+        return out
+
     def _flush(self):
         if self._dirty:
             _abi.check(self._ctx, _abi.lib().mplx_set_params(self._ctx, C.byref(self._p)))

@@ -47,6 +47,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
 #include <thread>
 #include <vector>
@@ -671,6 +672,171 @@ int32_t mpl_oracle_loop_count(double T, int32_t n) {
   int32_t it = 0;
   for (double t = 0; t < T; t += dt) it++;
   return it;
+}
+
+}  // extern "C"
+
+/* ===================================================================== *
+ *  Map preprocessing: CPU restatements, same structure  *
+ *  as the reference's loops.  TEST INFRASTRUCTURE, like everything here. *
+ * ===================================================================== */
+namespace {
+
+/* MapUtil::floatToInt, include/mpl_collision/map_util.h:103-108 */
+inline int prep_float_to_int(double pt, double origin, double res) { return (int)std::round((pt - origin) / res - 0.5); }
+
+struct PrepGrid {
+  int dim;
+  int d[3];
+  double origin[3];
+  double res;
+  bool outside(const int *pn) const { /* map_util.h:43-57 */
+    for (int i = 0; i < dim; i++)
+      if (pn[i] < 0 || pn[i] >= d[i]) return true;
+    return false;
+  }
+  int64_t index(const int *pn) const { /* map_util.h:34-41 */
+    return dim == 2 ? pn[0] + (int64_t)d[0] * pn[1] : pn[0] + (int64_t)d[0] * pn[1] + (int64_t)d[0] * d[1] * pn[2];
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+/* MapPlanner<Dim>::createMask + updatePotentialMap, src/mpl_planner/map_planner.cpp:246-283, 286-391.
+ * map_in / map_out: int8 cells, x fastest.  radius, range, pos: `dim` doubles (range all zero = global).
+ * H_MAX = 100 (map_planner.h:104).                                                                     */
+int mpl_oracle_update_potential_map(int32_t dim, const int8_t *map_in, const int32_t *map_dim, const double *origin,
+                                    double res, const double *pos, const double *radius, const double *range,
+                                    double pow_, int8_t *map_out) {
+  if (dim != 2 && dim != 3) return -1;
+  PrepGrid g;
+  g.dim = dim;
+  g.res = res;
+  int64_t n_cells = 1;
+  for (int i = 0; i < 3; i++) {
+    g.d[i] = i < dim ? map_dim[i] : 1;
+    g.origin[i] = i < dim ? origin[i] : 0;
+    n_cells *= g.d[i];
+  }
+  const int8_t H_MAX = 100;
+  /* createMask :246-283 */
+  struct Ent { int n[3]; int8_t v; };
+  std::vector<Ent> mask;
+  const double h_max = H_MAX;
+  const int rn = (int)std::ceil(radius[0] / res);
+  if (dim == 2) {
+    for (int n0 = -rn; n0 <= rn; n0++)
+      for (int n1 = -rn; n1 <= rn; n1++) {
+        if (std::hypot(n0, n1) > rn) continue;
+        const double h = h_max * std::pow((1 - (double)std::hypot(n0, n1) / rn), pow_);
+        if (h > 1e-3) mask.push_back(Ent{{n0, n1, 0}, (int8_t)h});
+      }
+  } else {
+    const int hn = (int)std::ceil(radius[2] / res);
+    for (int n0 = -rn; n0 <= rn; n0++)
+      for (int n1 = -rn; n1 <= rn; n1++)
+        for (int n2 = -hn; n2 <= hn; n2++) {
+          if (std::hypot(n0, n1) > rn) continue;
+          const double h = h_max * std::pow((1 - (double)std::hypot(n0, n1) / rn) * (1 - (double)std::abs(n2) / hn), pow_);
+          if (h > 1e-3) mask.push_back(Ent{{n0, n1, n2}, (int8_t)h});
+        }
+  }
+  /* updatePotentialMap :286-391 */
+  int c1[3] = {0, 0, 0}, c2[3] = {g.d[0], g.d[1], g.d[2]};
+  double rnorm = 0;
+  for (int i = 0; i < dim; i++) rnorm += range[i] * range[i];
+  if (std::sqrt(rnorm) > 0) {
+    for (int i = 0; i < dim; i++) {
+      c1[i] = prep_float_to_int(pos[i] - range[i], g.origin[i], res);
+      c2[i] = prep_float_to_int(pos[i] + range[i], g.origin[i], res);
+      if (c1[i] < 0) c1[i] = 0; else if (c1[i] >= g.d[i]) c1[i] = g.d[i] - 1;
+      if (c2[i] < 0) c2[i] = 0; else if (c2[i] >= g.d[i]) c2[i] = g.d[i] - 1;
+    }
+  }
+  std::vector<int8_t> dmap(map_in, map_in + n_cells);
+  int n[3] = {0, 0, 0};
+  const int z1 = dim == 3 ? c1[2] : 0, z2 = dim == 3 ? c2[2] : 1;
+  for (n[0] = c1[0]; n[0] < c2[0]; n[0]++)
+    for (n[1] = c1[1]; n[1] < c2[1]; n[1]++)
+      for (n[2] = z1; n[2] < z2; n[2]++) {
+        const int64_t idx = g.index(n);
+        if (map_in[idx] > 0) {
+          dmap[idx] = H_MAX;
+          for (const Ent &it : mask) {
+            const int nn[3] = {n[0] + it.n[0], n[1] + it.n[1], n[2] + it.n[2]};
+            if (!g.outside(nn)) {
+              const int64_t ni = g.index(nn);
+              dmap[ni] = std::max(dmap[ni], it.v);
+            }
+          }
+        }
+      }
+  std::memcpy(map_out, dmap.data(), (size_t)n_cells);
+  return 0;
+}
+
+/* MapPlanner<Dim>::setSearchRegion with MapUtil::rayTrace, map_planner.cpp:46-95, map_util.h:117-135.
+ * path: [n_points][dim]; region_out: one byte per cell (1 = inside).                                  */
+int mpl_oracle_search_region(int32_t dim, const int32_t *map_dim, const double *origin, double res, const double *path,
+                             int32_t n_points, int32_t dense, const double *search_radius, uint8_t *region_out) {
+  if (dim != 2 && dim != 3) return -1;
+  PrepGrid g;
+  g.dim = dim;
+  g.res = res;
+  int64_t n_cells = 1;
+  for (int i = 0; i < 3; i++) {
+    g.d[i] = i < dim ? map_dim[i] : 1;
+    g.origin[i] = i < dim ? origin[i] : 0;
+    n_cells *= g.d[i];
+  }
+  std::vector<std::array<int, 3>> ps;
+  auto to_cell = [&](const double *pt) {
+    std::array<int, 3> c = {0, 0, 0};
+    for (int i = 0; i < dim; i++) c[i] = prep_float_to_int(pt[i], g.origin[i], res);
+    return c;
+  };
+  if (!dense) {
+    for (int i = 1; i < n_points; i++) {
+      const double *p1 = path + (size_t)(i - 1) * dim, *p2 = path + (size_t)i * dim;
+      /* rayTrace :117-135 */
+      double diff[3] = {0, 0, 0}, linf = 0;
+      for (int k = 0; k < dim; k++) {
+        diff[k] = p2[k] - p1[k];
+        linf = std::max(linf, std::fabs(diff[k] / res));
+      }
+      const double kk = 0.8;
+      const int max_diff = (int)(linf / kk);
+      const double s = 1.0 / max_diff;
+      double step[3];
+      for (int k = 0; k < dim; k++) step[k] = diff[k] * s;
+      std::array<int, 3> prev = {-1, -1, dim == 3 ? -1 : 0};
+      for (int m = 1; m < max_diff; m++) {
+        double pt[3] = {0, 0, 0};
+        for (int k = 0; k < dim; k++) pt[k] = p1[k] + step[k] * m;
+        std::array<int, 3> c = to_cell(pt);
+        if (g.outside(c.data())) break;
+        if (c != prev) ps.push_back(c);
+        prev = c;
+      }
+      ps.push_back(to_cell(p2));
+    }
+  } else {
+    for (int i = 0; i < n_points; i++) ps.push_back(to_cell(path + (size_t)i * dim));
+  }
+  int rn[3] = {0, 0, 0};
+  for (int i = 0; i < dim; i++) rn[i] = (int)std::ceil(search_radius[i] / res);
+  std::memset(region_out, 0, (size_t)n_cells);
+  for (const auto &it : ps)
+    for (int a = -rn[0]; a <= rn[0]; a++)
+      for (int b = -rn[1]; b <= rn[1]; b++)
+        for (int c = -rn[2]; c <= rn[2]; c++) {
+          const int pn[3] = {it[0] + a, it[1] + b, it[2] + c};
+          if (g.outside(pn)) continue;
+          region_out[g.index(pn)] = 1;
+        }
+  return 0;
 }
 
 }  // extern "C"

@@ -99,6 +99,20 @@ double mpl_oracle_heur(int32_t dim, int32_t control, double w, double v_max,
  * (env_map.h:97-99): n or n+1.                                              */
 int32_t mpl_oracle_loop_count(double T, int32_t n);
 
+/* Map preprocessing.  MapPlanner<Dim>::updatePotentialMap with
+ * createMask (src/mpl_planner/map_planner.cpp:246-283, 286-391): map_out
+ * receives the map with the potential field stamped in.  radius / range / pos
+ * have `dim` entries; an all-zero range means the whole map.                 */
+int mpl_oracle_update_potential_map(int32_t dim, const int8_t *map_in, const int32_t *map_dim,
+                                    const double *origin, double res, const double *pos,
+                                    const double *radius, const double *range, double pow_,
+                                    int8_t *map_out);
+/* MapPlanner<Dim>::setSearchRegion (map_planner.cpp:46-95) with
+ * MapUtil::rayTrace (map_util.h:117-135): one byte per cell, 1 = in region.  */
+int mpl_oracle_search_region(int32_t dim, const int32_t *map_dim, const double *origin, double res,
+                             const double *path, int32_t n_points, int32_t dense,
+                             const double *search_radius, uint8_t *region_out);
+
 #ifdef __cplusplus
 }
 #endif

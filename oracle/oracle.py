@@ -233,3 +233,55 @@ def ref_plan(env, start_row, goal_row, use_gpu=False, epsilon=1.0, reps=1):
     return {"ok": bool(out.ok), "closed": out.closed, "opened": out.opened, "expansions": out.expansions,
             "segments": out.segments, "cost": out.cost, "total_time": out.total_time, "J": list(out.J),
             "wall_ms": out.wall_ms}
+
+
+# ---- map preprocessing: restatement, and the reference's own MapPlanner via the shim
+def _prep_lib(ref):
+    if not ref:
+        lib = load()
+        fn_pot, fn_reg = lib.mpl_oracle_update_potential_map, lib.mpl_oracle_search_region
+    else:
+        if "ref_planner" not in _LIBS:
+            ref_plan  # noqa: B018  (same library as ref_plan)
+            _LIBS["ref_planner_prep"] = C.CDLL(REF_PLANNER_SO)
+        lib = _LIBS.setdefault("ref_planner_prep", C.CDLL(REF_PLANNER_SO))
+        fn_pot, fn_reg = lib.mpl_ref_update_potential_map, lib.mpl_ref_search_region
+    fn_pot.restype = C.c_int
+    fn_pot.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                       C.c_double, C.c_void_p]
+    fn_reg.restype = C.c_int
+    fn_reg.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                       C.c_void_p]
+    return fn_pot, fn_reg
+
+
+def update_potential_map(grid, map_dim, origin, res, pos, radius, range_=None, power=1.0, ref=False):
+    """MapPlanner::updatePotentialMap: returns the new int8 map (flat, x fastest)."""
+    dim = len(map_dim)
+    cells = np.ascontiguousarray(grid, dtype=np.int8).ravel()
+    md = np.asarray(map_dim, dtype=np.int32)
+    org = np.asarray(origin, dtype=np.float64)
+    p = np.asarray(pos, dtype=np.float64)
+    r = np.asarray(radius, dtype=np.float64)
+    g = np.zeros(dim) if range_ is None else np.asarray(range_, dtype=np.float64)
+    out = np.empty_like(cells)
+    rc = _prep_lib(ref)[0](dim, cells.ctypes.data, md.ctypes.data, org.ctypes.data, float(res), p.ctypes.data,
+                           r.ctypes.data, g.ctypes.data, float(power), out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("update_potential_map failed: %d" % rc)
+    return out
+
+
+def search_region(map_dim, origin, res, path, search_radius, dense=False, ref=False):
+    """MapPlanner::setSearchRegion: returns one byte per cell (flat, x fastest)."""
+    dim = len(map_dim)
+    md = np.asarray(map_dim, dtype=np.int32)
+    org = np.asarray(origin, dtype=np.float64)
+    pts = np.ascontiguousarray(path, dtype=np.float64).reshape(-1, dim)
+    sr = np.asarray(search_radius, dtype=np.float64)
+    out = np.empty(int(np.prod(md)), dtype=np.uint8)
+    rc = _prep_lib(ref)[1](dim, md.ctypes.data, org.ctypes.data, float(res), pts.ctypes.data, pts.shape[0],
+                           int(bool(dense)), sr.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("search_region failed: %d" % rc)
+    return out

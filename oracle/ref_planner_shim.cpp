@@ -106,3 +106,83 @@ extern "C" int mpl_ref_plan(const mpl_oracle_env *env, const double *start, cons
   if (env->dim == 3) return run_plan<3>(env, start, goal, use_gpu, epsilon, reps, out);
   return -1;
 }
+
+/* ---- map preprocessing through the reference's own MapPlanner (map_planner.cpp:46-95, 246-391) ---- */
+namespace {
+
+template <int D>
+struct PrepPlanner : MPL::MapPlanner<D> {
+  PrepPlanner() : MPL::MapPlanner<D>(false) {}
+  void set_pow(double p) { this->pow_ = p; }
+};
+
+template <int D>
+std::shared_ptr<MPL::MapUtil<D>> make_map(const int8_t *cells, const int32_t *map_dim, const double *origin, double res) {
+  auto mu = std::make_shared<MPL::MapUtil<D>>();
+  Vecf<D> ori;
+  Veci<D> dim;
+  size_t n = 1;
+  for (int i = 0; i < D; i++) { ori(i) = origin[i]; dim(i) = map_dim[i]; n *= (size_t)map_dim[i]; }
+  if (cells) mu->setMap(ori, dim, MPL::Tmap(cells, cells + n), res);
+  else mu->setMap(ori, dim, MPL::Tmap(n, 0), res);
+  return mu;
+}
+
+template <int D>
+int ref_potential(const int8_t *map_in, const int32_t *map_dim, const double *origin, double res, const double *pos,
+                  const double *radius, const double *range, double pow_, int8_t *map_out) {
+  auto mu = make_map<D>(map_in, map_dim, origin, res);
+  PrepPlanner<D> pl;
+  pl.setMapUtil(mu);
+  Vecf<D> r, g, p;
+  for (int i = 0; i < D; i++) { r(i) = radius[i]; g(i) = range[i]; p(i) = pos[i]; }
+  pl.setPotentialRadius(r);
+  pl.setPotentialMapRange(g);
+  pl.set_pow(pow_);
+  pl.updatePotentialMap(p);
+  const auto m = mu->getMap();
+  std::copy(m.begin(), m.end(), map_out);
+  return 0;
+}
+
+template <int D>
+int ref_region(const int32_t *map_dim, const double *origin, double res, const double *path, int n_points, int dense,
+               const double *search_radius, uint8_t *region_out) {
+  auto mu = make_map<D>(nullptr, map_dim, origin, res);
+  PrepPlanner<D> pl;
+  pl.setMapUtil(mu);
+  Vecf<D> sr;
+  for (int i = 0; i < D; i++) sr(i) = search_radius[i];
+  pl.setSearchRadius(sr);
+  vec_Vecf<D> pts;
+  for (int k = 0; k < n_points; k++) {
+    Vecf<D> p;
+    for (int i = 0; i < D; i++) p(i) = path[(size_t)k * D + i];
+    pts.push_back(p);
+  }
+  pl.setSearchRegion(pts, dense != 0);
+  /* getSearchRegion returns the in-region cell centres (map_planner.cpp:98-122) */
+  size_t n = 1;
+  for (int i = 0; i < D; i++) n *= (size_t)map_dim[i];
+  std::fill(region_out, region_out + n, (uint8_t)0);
+  for (const auto &c : pl.getSearchRegion()) region_out[mu->getIndex(mu->floatToInt(c))] = 1;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mpl_ref_update_potential_map(int32_t dim, const int8_t *map_in, const int32_t *map_dim,
+                                            const double *origin, double res, const double *pos, const double *radius,
+                                            const double *range, double pow_, int8_t *map_out) {
+  if (dim == 2) return ref_potential<2>(map_in, map_dim, origin, res, pos, radius, range, pow_, map_out);
+  if (dim == 3) return ref_potential<3>(map_in, map_dim, origin, res, pos, radius, range, pow_, map_out);
+  return -1;
+}
+
+extern "C" int mpl_ref_search_region(int32_t dim, const int32_t *map_dim, const double *origin, double res,
+                                     const double *path, int32_t n_points, int32_t dense, const double *search_radius,
+                                     uint8_t *region_out) {
+  if (dim == 2) return ref_region<2>(map_dim, origin, res, path, n_points, dense, search_radius, region_out);
+  if (dim == 3) return ref_region<3>(map_dim, origin, res, path, n_points, dense, search_radius, region_out);
+  return -1;
+}
