@@ -102,6 +102,39 @@ class env_map_hip : public env_map<Dim> {
     }
   }
 
+  /// MapPlanner::updatePotentialMap on the device (map_planner.cpp:286-391): the map held by
+  /// `map_util` is dilated in HBM, read back, installed in the MapUtil and as potential map.
+  bool device_update_potential_map(const Vecf<Dim> &pos, const Vecf<Dim> &radius, const Vecf<Dim> &range,
+                                   decimal_t pow, const std::shared_ptr<MapUtil<Dim>> &map_util) {
+    maps_stale_ = true;
+    if (!ctx_ || !sync_maps()) return false;
+    double p[3] = {0, 0, 0}, r[3] = {0, 0, 0}, g[3] = {0, 0, 0};
+    for (int i = 0; i < Dim; i++) { p[i] = pos(i); r[i] = radius(i); g[i] = range(i); }
+    Tmap dmap(map_util->getMap().size());
+    if (mplx_update_potential_map(ctx_, p, r, g, pow, dmap.data()) != MPLX_OK) return complain();
+    map_util->setMap(map_util->getOrigin(), map_util->getDim(), dmap, map_util->getRes());
+    env_map<Dim>::set_potential_map(map_util->getMap());
+    maps_stale_ = false;  // the device already holds exactly this map and potential
+    return true;
+  }
+
+  /// MapPlanner::setSearchRegion on the device (map_planner.cpp:46-95).
+  bool device_set_search_region(const vec_Vecf<Dim> &path, bool dense, const Vecf<Dim> &search_radius) {
+    if (!ctx_ || !sync_maps()) return false;
+    std::vector<double> pts(path.size() * Dim);
+    for (size_t k = 0; k < path.size(); k++)
+      for (int i = 0; i < Dim; i++) pts[k * Dim + i] = path[k](i);
+    double sr[3] = {0, 0, 0};
+    for (int i = 0; i < Dim; i++) sr[i] = search_radius(i);
+    std::vector<uint8_t> bytes(this->map_util_->getMap().size());
+    if (mplx_set_search_region_path(ctx_, pts.data(), (int32_t)path.size(), dense ? 1 : 0, sr, bytes.data()) != MPLX_OK)
+      return complain();
+    std::vector<bool> in_region(bytes.size());
+    for (size_t i = 0; i < bytes.size(); i++) in_region[i] = bytes[i] != 0;
+    env_map<Dim>::set_search_region(in_region);
+    return true;
+  }
+
   /// Batched form: dense slots for `nodes` (see mplx_expand); host buffers.
   bool expand(const vec_E<Waypoint<Dim>> &nodes, std::vector<uint8_t> &status, std::vector<decimal_t> &cost,
               std::vector<uint64_t> &hash, std::vector<decimal_t> &state) const {
@@ -149,7 +182,7 @@ class env_map_hip : public env_map<Dim> {
     w.t = row[4 * Dim + 1];
   }
 
-  bool sync(int control) const {
+  bool sync_maps() const {
     if (maps_stale_) {
       const Veci<Dim> dim = this->map_util_->getDim();
       const Vecf<Dim> ori = this->map_util_->getOrigin();
@@ -169,6 +202,11 @@ class env_map_hip : public env_map<Dim> {
       }
       maps_stale_ = false;
     }
+    return true;
+  }
+
+  bool sync(int control) const {
+    if (!sync_maps()) return false;
     mplx_params p{};
     p.control = control;
     p.dt = this->dt_;
@@ -220,6 +258,23 @@ class GpuMapPlanner : public MapPlanner<Dim> {
     this->ENV_.reset(new env_map_hip<Dim>(map_util, device_));
     this->map_util_ = map_util;
   }
+
+  /// Shadows MapPlanner::updatePotentialMap (not virtual in the reference): same result, the
+  /// dilation runs on the GPU (mplx_update_potential_map).
+  void updatePotentialMap(const Vecf<Dim> &pos) {
+    env_map_hip<Dim> *env = static_cast<env_map_hip<Dim> *>(this->ENV_.get());
+    env->device_update_potential_map(pos, this->potential_radius_, this->potential_map_range_, this->pow_,
+                                     this->map_util_);
+  }
+
+  /// Shadows MapPlanner::setSearchRegion: the tunnel mask is built on the GPU.  (iterativePlan
+  /// calls the base version through the base class; that still reaches the device through
+  /// env_base::set_search_region.)
+  void setSearchRegion(const vec_Vecf<Dim> &path, bool dense = false) {
+    env_map_hip<Dim> *env = static_cast<env_map_hip<Dim> *>(this->ENV_.get());
+    env->device_set_search_region(path, dense, this->search_radius_);
+  }
+  void set_pow(decimal_t p) { this->pow_ = p; }  // the reference has no setter for pow_ (map_planner.h:113)
 
  private:
   int device_;

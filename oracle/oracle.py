@@ -237,6 +237,8 @@ def ref_plan(env, start_row, goal_row, use_gpu=False, epsilon=1.0, reps=1):
 
 # ---- map preprocessing: restatement, and the reference's own MapPlanner via the shim
 def _prep_lib(ref):
+    """ref: False = the restatement, True = the reference's MapPlanner, "gpu" = the reference's
+    MapPlanner API on MPL::GpuMapPlanner (the drop-in adapter; needs a GPU)."""
     if not ref:
         lib = load()
         fn_pot, fn_reg = lib.mpl_oracle_update_potential_map, lib.mpl_oracle_search_region
@@ -245,7 +247,10 @@ def _prep_lib(ref):
             ref_plan  # noqa: B018  (same library as ref_plan)
             _LIBS["ref_planner_prep"] = C.CDLL(REF_PLANNER_SO)
         lib = _LIBS.setdefault("ref_planner_prep", C.CDLL(REF_PLANNER_SO))
-        fn_pot, fn_reg = lib.mpl_ref_update_potential_map, lib.mpl_ref_search_region
+        if ref == "gpu":
+            fn_pot, fn_reg = lib.mpl_gpu_update_potential_map, lib.mpl_gpu_search_region
+        else:
+            fn_pot, fn_reg = lib.mpl_ref_update_potential_map, lib.mpl_ref_search_region
     fn_pot.restype = C.c_int
     fn_pot.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                        C.c_double, C.c_void_p]

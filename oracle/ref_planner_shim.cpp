@@ -128,11 +128,11 @@ std::shared_ptr<MPL::MapUtil<D>> make_map(const int8_t *cells, const int32_t *ma
   return mu;
 }
 
-template <int D>
+template <int D, class Planner>
 int ref_potential(const int8_t *map_in, const int32_t *map_dim, const double *origin, double res, const double *pos,
                   const double *radius, const double *range, double pow_, int8_t *map_out) {
   auto mu = make_map<D>(map_in, map_dim, origin, res);
-  PrepPlanner<D> pl;
+  Planner pl;
   pl.setMapUtil(mu);
   Vecf<D> r, g, p;
   for (int i = 0; i < D; i++) { r(i) = radius[i]; g(i) = range[i]; p(i) = pos[i]; }
@@ -145,11 +145,11 @@ int ref_potential(const int8_t *map_in, const int32_t *map_dim, const double *or
   return 0;
 }
 
-template <int D>
+template <int D, class Planner>
 int ref_region(const int32_t *map_dim, const double *origin, double res, const double *path, int n_points, int dense,
                const double *search_radius, uint8_t *region_out) {
   auto mu = make_map<D>(nullptr, map_dim, origin, res);
-  PrepPlanner<D> pl;
+  Planner pl;
   pl.setMapUtil(mu);
   Vecf<D> sr;
   for (int i = 0; i < D; i++) sr(i) = search_radius[i];
@@ -174,15 +174,32 @@ int ref_region(const int32_t *map_dim, const double *origin, double res, const d
 extern "C" int mpl_ref_update_potential_map(int32_t dim, const int8_t *map_in, const int32_t *map_dim,
                                             const double *origin, double res, const double *pos, const double *radius,
                                             const double *range, double pow_, int8_t *map_out) {
-  if (dim == 2) return ref_potential<2>(map_in, map_dim, origin, res, pos, radius, range, pow_, map_out);
-  if (dim == 3) return ref_potential<3>(map_in, map_dim, origin, res, pos, radius, range, pow_, map_out);
+  if (dim == 2) return ref_potential<2, PrepPlanner<2>>(map_in, map_dim, origin, res, pos, radius, range, pow_, map_out);
+  if (dim == 3) return ref_potential<3, PrepPlanner<3>>(map_in, map_dim, origin, res, pos, radius, range, pow_, map_out);
+  return -1;
+}
+
+/* the same calls on MPL::GpuMapPlanner (include/mplx_env_map.hpp): the drop-in adapter, needs a GPU */
+extern "C" int mpl_gpu_update_potential_map(int32_t dim, const int8_t *map_in, const int32_t *map_dim,
+                                            const double *origin, double res, const double *pos, const double *radius,
+                                            const double *range, double pow_, int8_t *map_out) {
+  if (dim == 2) return ref_potential<2, MPL::GpuMapPlanner<2>>(map_in, map_dim, origin, res, pos, radius, range, pow_, map_out);
+  if (dim == 3) return ref_potential<3, MPL::GpuMapPlanner<3>>(map_in, map_dim, origin, res, pos, radius, range, pow_, map_out);
+  return -1;
+}
+
+extern "C" int mpl_gpu_search_region(int32_t dim, const int32_t *map_dim, const double *origin, double res,
+                                     const double *path, int32_t n_points, int32_t dense, const double *search_radius,
+                                     uint8_t *region_out) {
+  if (dim == 2) return ref_region<2, MPL::GpuMapPlanner<2>>(map_dim, origin, res, path, n_points, dense, search_radius, region_out);
+  if (dim == 3) return ref_region<3, MPL::GpuMapPlanner<3>>(map_dim, origin, res, path, n_points, dense, search_radius, region_out);
   return -1;
 }
 
 extern "C" int mpl_ref_search_region(int32_t dim, const int32_t *map_dim, const double *origin, double res,
                                      const double *path, int32_t n_points, int32_t dense, const double *search_radius,
                                      uint8_t *region_out) {
-  if (dim == 2) return ref_region<2>(map_dim, origin, res, path, n_points, dense, search_radius, region_out);
-  if (dim == 3) return ref_region<3>(map_dim, origin, res, path, n_points, dense, search_radius, region_out);
+  if (dim == 2) return ref_region<2, PrepPlanner<2>>(map_dim, origin, res, path, n_points, dense, search_radius, region_out);
+  if (dim == 3) return ref_region<3, PrepPlanner<3>>(map_dim, origin, res, path, n_points, dense, search_radius, region_out);
   return -1;
 }

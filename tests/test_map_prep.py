@@ -132,3 +132,21 @@ def test_expansion_consumes_the_device_made_potential_and_region(engine, oracle_
     ref = oracle_lib.expand(oenv, wl.nodes, threads=8)
     assert_slots_equal(got, ref, what="device-made potential + region, dim %d" % dim)
     assert ref["stats"]["finite"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(O.REF_PLANNER_SO), reason="reference build (oracle/_ref) not present")
+@pytest.mark.parametrize("case", CASES[:2], ids=[c[0] for c in CASES[:2]])
+def test_drop_in_adapter_runs_the_reference_api_on_the_device(case):
+    """The reference's own call sequence (setPotentialRadius / setPotentialMapRange /
+    updatePotentialMap, setSearchRadius / setSearchRegion / getSearchRegion) on
+    MPL::GpuMapPlanner from include/mplx_env_map.hpp gives the reference's cells."""
+    name, dim, grid, md, org, res, centre, pots, path, regs = case
+    for radius, rng_, pw in pots[:3]:
+        a = O.update_potential_map(grid, md, org, res, centre, radius, rng_, pw, ref="gpu")
+        b = O.update_potential_map(grid, md, org, res, centre, radius, rng_, pw)
+        assert np.array_equal(a, b), "adapter potential %s" % (radius,)
+    for sr, dense in regs:
+        a = O.search_region(md, org, res, path, sr, dense, ref="gpu")
+        b = O.search_region(md, org, res, path, sr, dense)
+        assert np.array_equal(a, b), "adapter region %s" % (sr,)
