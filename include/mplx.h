@@ -181,6 +181,39 @@ int mplx_expand_lists_device(mplx_ctx *ctx, const double *d_nodes, int64_t n_nod
 int mplx_expand_lists(mplx_ctx *ctx, const double *h_nodes, int64_t n_nodes, int64_t node_stride,
                       const mplx_succ_lists *h_out);
 
+/* ---- successor post-processing on the device: what
+ *      GraphSearch::Astar does with every successor right after get_succ
+ *      (graph_search.h:84-88, :146), for a whole batch of lists in HBM ------ */
+typedef struct {
+  const double *goal;      /* host pointer: goal waypoint, 4D+2 doubles         */
+  int32_t control;         /* Waypoint::control of goal and successors          */
+  int32_t reserved;
+  double w, v_max;         /* env_base.h:370, :382 (cal_heur, :58-64)           */
+  double tol_pos, tol_vel, tol_acc, tol_yaw; /* env_base.h:374-380; vel / acc /
+                              yaw tests are skipped when < 0 (env_map.h:29-36)  */
+} mplx_goal_spec;
+
+/* Outputs, device pointers of n_nodes*S entries each (S = node_stride of the
+ * lists), any may be NULL; only the entries of emitted successors are written.
+ *   heur   env_base::get_heur, default branch (env_base.h:46-64): 0 for the
+ *          goal's own lattice state, else w * |pos - goal.pos|_inf / v_max
+ *          (w * |.|_inf when v_max <= 0)
+ *   flags  bit 0: inside the goal tolerances (env_map.h:25-37; the ray trace of
+ *          :38-43 is left to the caller), bit 1: same lattice state as the
+ *          goal, bit 2 (with canon): first successor of the batch with its hash
+ *   canon  list index (node*S + j) of the first successor of the batch with the
+ *          same lattice hash -- the search's node identity (waypoint.h:128-135) */
+typedef struct {
+  double *heur;
+  uint8_t *flags;
+  int32_t *canon;
+} mplx_post;
+
+/* d_lists: the lists as filled by mplx_expand_lists_device (count, hash and
+ * state are read).  Asynchronous on the context stream.                      */
+int mplx_post_lists_device(mplx_ctx *ctx, const mplx_succ_lists *d_lists, int64_t n_nodes,
+                           const mplx_goal_spec *goal, const mplx_post *d_out);
+
 /* ---- device memory + stream helpers (so any host language can keep the
  *      frontier and the successor slots resident in HBM) ------------------- */
 int mplx_device_alloc(mplx_ctx *ctx, size_t bytes, void **dptr);

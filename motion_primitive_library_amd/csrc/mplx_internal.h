@@ -125,6 +125,24 @@ hipError_t launch_expand_grid(int dim, int control, const GridArgs &args, hipStr
 hipError_t launch_build_blocked_bits(const int8_t *map, const uint32_t *region, int64_t n_cells, uint32_t *out,
                                      hipStream_t stream);
 
+// Successor post-processing (post_kernel.hip): heuristic, goal tolerances, node identity.
+struct PostArgs {
+  const int32_t *count;    // [n_nodes]
+  const uint64_t *hash;    // [n_nodes * nstride]
+  const double *state;     // [4D+2][sstride]
+  int64_t n_nodes, nstride, sstride;
+  double goal[14];         // goal waypoint, 4D+2 doubles
+  uint64_t goal_hash;
+  double w, v_max, tol_pos, tol_vel, tol_acc, tol_yaw;
+  double *heur;            // outputs, any may be null
+  uint8_t *flags;
+  int32_t *canon;
+  uint64_t *keys;          // identity table: cap keys (+1 unused), cap + 1 values; cap a power of two
+  int32_t *vals;
+  uint64_t cap;
+};
+hipError_t launch_post_lists(int dim, const PostArgs &args, hipStream_t s);
+
 // Map preprocessing (map_prep_kernel.hip).  d, c1, c2: 3 entries (unused axes 1 / [0,1)).
 hipError_t launch_potential_passes(const int8_t *map, const int32_t *d, const int32_t *c1, const int32_t *c2, int rn,
                                    int hn, const int8_t *lut, int8_t h_max, unsigned short *tmp_a,

@@ -1,0 +1,56 @@
+// post_api.cpp -- C ABI of the successor post-processing: heuristic,
+// goal tolerances and node identity of a whole batch of successor lists, on the
+// device (post_kernel.hip).
+#include "mplx_ctx.h"
+#include "host_planner.hpp"
+
+#include <cstring>
+
+using namespace mplx_detail;
+
+extern "C" int mplx_post_lists_device(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t n_nodes,
+                                      const mplx_goal_spec *goal, const mplx_post *d_out) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!d_lists || !goal || !d_out || n_nodes < 0 || !goal->goal)
+    return fail(c, MPLX_ERR_ARG, "mplx_post_lists_device: NULL argument");
+  if (!d_lists->count || !d_lists->hash || !d_lists->state)
+    return fail(c, MPLX_ERR_ARG, "mplx_post_lists_device: the lists need count, hash and state");
+  if (!c->has_U) return fail(c, MPLX_ERR_STATE, "mplx_post_lists_device: controls not set");
+  if (n_nodes == 0) return MPLX_OK;
+  if (int rc = bind_device(c)) return rc;
+  const int D = c->dim, F = 4 * D + 2;
+  const int64_t S = d_lists->node_stride ? d_lists->node_stride : c->nU;
+  const int64_t n = n_nodes * S;
+  if (n >= 0x7f7f7f7fLL) return fail(c, MPLX_ERR_ARG, "mplx_post_lists_device: %lld list entries exceed the int32 index", (long long)n);
+  mplx::PostArgs a{};
+  a.count = d_lists->count;
+  a.hash = d_lists->hash;
+  a.state = d_lists->state;
+  a.n_nodes = n_nodes;
+  a.nstride = S;
+  a.sstride = d_lists->state_stride;
+  std::memcpy(a.goal, goal->goal, sizeof(double) * F);
+  a.goal_hash = mplx::host::lattice_hash(D, goal->control, goal->goal);
+  a.w = goal->w;
+  a.v_max = goal->v_max;
+  a.tol_pos = goal->tol_pos;
+  a.tol_vel = goal->tol_vel;
+  a.tol_acc = goal->tol_acc;
+  a.tol_yaw = goal->tol_yaw;
+  a.heur = d_out->heur;
+  a.flags = d_out->flags;
+  a.canon = d_out->canon;
+  if (d_out->canon) {
+    uint64_t cap = 1024;
+    while (cap < 2 * (uint64_t)n_nodes * (uint64_t)c->nU) cap <<= 1;  // load factor <= 0.5 whatever is emitted
+    if (int rc = ensure(c, c->post_keys, (cap + 1) * 8)) return rc;
+    if (int rc = ensure(c, c->post_vals, (cap + 1) * 4)) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->post_keys.p, 0xff, (cap + 1) * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->post_vals.p, 0x7f, (cap + 1) * 4, c->stream));
+    a.keys = (uint64_t *)c->post_keys.p;
+    a.vals = (int32_t *)c->post_vals.p;
+    a.cap = cap;
+  }
+  HIP_TRY(c, mplx::launch_post_lists(D, a, c->stream));
+  return MPLX_OK;
+}

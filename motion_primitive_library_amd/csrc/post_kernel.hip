@@ -1,0 +1,117 @@
+// post_kernel.hip -- what the graph search does with every successor right after
+// get_succ, batched on the device, reading the per-node successor
+// lists where the expansion kernels left them in HBM:
+//   heuristic       env_base<Dim>::get_heur / cal_heur with heur_ignore_dynamics
+//                   (reference include/mpl_planner/common/env_base.h:46-64):
+//                   0 if the successor is the goal's lattice state, else
+//                   w * |pos - goal.pos|_inf / v_max
+//   goal tolerance  env_map<Dim>::is_goal, the norm tests
+//                   (include/mpl_planner/env/env_map.h:25-37); the ray trace of
+//                   :38-43 needs the host's map walk and stays with the caller
+//   node identity   the search keys its hash map with the Waypoint, whose ==
+//                   compares hash values (waypoint.h:128-135;
+//                   graph_search.h:84-88): for every successor the list index of
+//                   the FIRST successor of the batch with the same hash, so the
+//                   host creates each new state once and only transfers the rest
+//                   as edges.  Deterministic: the canonical duplicate is the one
+//                   with the smallest list index.
+// The identity pass is an open-addressing table in HBM keyed by the 64-bit lattice
+// hash (linear probing, 64-bit CAS for the key, 32-bit atomicMin for the index).
+#include "mplx_internal.h"
+
+namespace mplx {
+namespace {
+
+constexpr uint64_t kEmpty = ~0ull;
+
+__device__ __forceinline__ uint64_t mix(uint64_t h) {  // table position only; never leaves the device
+  h ^= h >> 33;
+  h *= 0xff51afd7ed558ccdULL;
+  h ^= h >> 33;
+  return h;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void post_lists_kernel(const PostArgs A) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= A.n_nodes * A.nstride) return;
+  const int64_t node = g / A.nstride;
+  const int j = (int)(g - node * A.nstride);
+  if (j >= A.count[node]) return;
+  const uint64_t h = A.hash[g];
+  const bool is_goal_state = (h == A.goal_hash);  // `goal_node_ == state` is a hash comparison (env_base.h:47)
+  double m = 0;  // lpNorm<Infinity> of pos - goal.pos
+#pragma unroll
+  for (int i = 0; i < D; i++) {
+    const double d = fabs(A.state[(int64_t)i * A.sstride + g] - A.goal[i]);
+    m = d > m ? d : m;
+  }
+  if (A.heur) A.heur[g] = is_goal_state ? 0.0 : (A.v_max > 0 ? A.w * m / A.v_max : A.w * m);
+  if (A.flags) {
+    bool goaled = m <= A.tol_pos;  // env_map.h:26-28
+    if (goaled && A.tol_vel >= 0) {
+      double mv = 0;
+#pragma unroll
+      for (int i = 0; i < D; i++) {
+        const double d = fabs(A.state[(int64_t)(D + i) * A.sstride + g] - A.goal[D + i]);
+        mv = d > mv ? d : mv;
+      }
+      goaled = mv <= A.tol_vel;
+    }
+    if (goaled && A.tol_acc >= 0) {
+      double ma = 0;
+#pragma unroll
+      for (int i = 0; i < D; i++) {
+        const double d = fabs(A.state[(int64_t)(2 * D + i) * A.sstride + g] - A.goal[2 * D + i]);
+        ma = d > ma ? d : ma;
+      }
+      goaled = ma <= A.tol_acc;
+    }
+    if (goaled && A.tol_yaw >= 0) goaled = fabs(A.state[(int64_t)(4 * D) * A.sstride + g] - A.goal[4 * D]) <= A.tol_yaw;
+    A.flags[g] = (uint8_t)((goaled ? 1 : 0) | (is_goal_state ? 2 : 0));
+  }
+  if (A.keys) {
+    if (h == kEmpty) {  // the one hash the key array cannot hold: a dedicated slot past the table
+      atomicMin(&A.vals[A.cap], (int)g);
+    } else {
+      uint64_t s = mix(h) & (A.cap - 1);
+      while (true) {
+        const uint64_t old = atomicCAS((unsigned long long *)&A.keys[s], (unsigned long long)kEmpty, (unsigned long long)h);
+        if (old == kEmpty || old == h) break;
+        s = (s + 1) & (A.cap - 1);
+      }
+      atomicMin(&A.vals[s], (int)g);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void post_canon_kernel(const PostArgs A) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= A.n_nodes * A.nstride) return;
+  const int64_t node = g / A.nstride;
+  const int j = (int)(g - node * A.nstride);
+  if (j >= A.count[node]) return;
+  const uint64_t h = A.hash[g];
+  uint64_t s = A.cap;
+  if (h != kEmpty) {
+    s = mix(h) & (A.cap - 1);
+    while (A.keys[s] != h) s = (s + 1) & (A.cap - 1);
+  }
+  const int c = A.vals[s];
+  A.canon[g] = c;
+  if (A.flags && c == (int)g) A.flags[g] |= 4;  // first occurrence of this lattice state in the batch
+}
+
+}  // namespace
+
+hipError_t launch_post_lists(int dim, const PostArgs &a, hipStream_t s) {
+  const int64_t n = a.n_nodes * a.nstride;
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (dim == 2) hipLaunchKernelGGL(post_lists_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(post_lists_kernel<3>, dim3(blocks), dim3(256), 0, s, a);
+  if (a.keys && a.canon) hipLaunchKernelGGL(post_canon_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace mplx

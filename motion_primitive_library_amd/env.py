@@ -418,6 +418,36 @@ class EnvMap:
         _abi.check(self._ctx, _abi.lib().mplx_expand_lists_device(self._ctx, frontier.ptr, n, frontier.n_nodes,
                                                                   C.byref(s)))
 
+    def post_lists(self, lists, goal_row, w=None, v_max=None, tol_pos=0.5, tol_vel=-1.0, tol_acc=-1.0, tol_yaw=-1.0,
+                   n_nodes=None, want_canon=True):
+        """Heuristic, goal-tolerance flags and node identity of HBM-resident lists
+        (mplx_post_lists_device).  Returns host arrays indexed like the lists."""
+        self._flush()
+        n = lists.n_nodes if n_nodes is None else int(n_nodes)
+        goal = np.ascontiguousarray(goal_row, dtype=np.float64)
+        g = _abi.GoalSpec()
+        g.goal, g.control = goal.ctypes.data, int(self._p.control)
+        g.w = float(self._p.w if w is None else w)
+        g.v_max = float(self._p.v_max if v_max is None else v_max)
+        g.tol_pos, g.tol_vel, g.tol_acc, g.tol_yaw = float(tol_pos), float(tol_vel), float(tol_acc), float(tol_yaw)
+        ns = lists.n_slots
+        heur = DeviceArray(self, max(ns, 1) * 8)
+        flags = DeviceArray(self, max(ns, 1))
+        canon = DeviceArray(self, max(ns, 1) * 4) if want_canon else None
+        _abi.check(self._ctx, _abi.lib().mplx_memset(self._ctx, flags.ptr, 0, max(ns, 1)))
+        o = _abi.Post()
+        o.heur, o.flags, o.canon = heur.ptr, flags.ptr, canon.ptr if canon else None
+        s = lists.c_struct()
+        _abi.check(self._ctx, _abi.lib().mplx_post_lists_device(self._ctx, C.byref(s), n, C.byref(g), C.byref(o)))
+        self.synchronize()
+        out = {"heur": heur.download(np.float64, (ns,)), "flags": flags.download(np.uint8, (ns,))}
+        if canon:
+            out["canon"] = canon.download(np.int32, (ns,))
+            canon.free()
+        heur.free()
+        flags.free()
+        return out
+
     def upload_frontier(self, nodes):
         nodes = np.ascontiguousarray(nodes, dtype=np.float64)
         if nodes.ndim != 2 or nodes.shape[0] != self.n_fields:

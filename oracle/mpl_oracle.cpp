@@ -667,6 +667,22 @@ double mpl_oracle_heur(int32_t dim, int32_t control, double w, double v_max, con
   return w * m;
 }
 
+/* env_map<Dim>::is_goal, the norm tests (env_map.h:25-37); the ray trace of
+ * :38-43 is not part of this (it cannot fail on a free map). */
+int32_t mpl_oracle_goal_tol(int32_t dim, const double *wp, const double *goal, double tol_pos, double tol_vel,
+                            double tol_acc, double tol_yaw) {
+  auto linf = [&](int row) {
+    double m = 0;
+    for (int i = 0; i < dim; i++) m = std::max(m, std::abs(wp[row * dim + i] - goal[row * dim + i]));
+    return m;
+  };
+  bool goaled = linf(0) <= tol_pos;
+  if (goaled && tol_vel >= 0) goaled = linf(1) <= tol_vel;
+  if (goaled && tol_acc >= 0) goaled = linf(2) <= tol_acc;
+  if (goaled && tol_yaw >= 0) goaled = std::abs(wp[4 * dim] - goal[4 * dim]) <= tol_yaw;
+  return goaled ? 1 : 0;
+}
+
 int32_t mpl_oracle_loop_count(double T, int32_t n) {
   double dt = T / n;
   int32_t it = 0;

@@ -95,6 +95,10 @@ uint64_t mpl_oracle_hash(int32_t dim, int32_t control, const double *wp);
 double mpl_oracle_heur(int32_t dim, int32_t control, double w, double v_max,
                        const double *wp, const double *goal);
 
+/* env_map<Dim>::is_goal without its ray trace (env_map.h:25-37).             */
+int32_t mpl_oracle_goal_tol(int32_t dim, const double *wp, const double *goal, double tol_pos,
+                            double tol_vel, double tol_acc, double tol_yaw);
+
 /* Sample-loop iteration count of `for (t = 0; t < T; t += T/n)`
  * (env_map.h:97-99): n or n+1.                                              */
 int32_t mpl_oracle_loop_count(double T, int32_t n);

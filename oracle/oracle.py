@@ -69,6 +69,9 @@ def _bind(path):
     lib.mpl_oracle_hash.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
     lib.mpl_oracle_heur.restype = C.c_double
     lib.mpl_oracle_heur.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    lib.mpl_oracle_goal_tol.restype = C.c_int32
+    lib.mpl_oracle_goal_tol.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                        C.c_double]
     lib.mpl_oracle_loop_count.restype = C.c_int32
     lib.mpl_oracle_loop_count.argtypes = [C.c_double, C.c_int32]
     return lib
@@ -196,6 +199,14 @@ def heur(dim, control, w, v_max, wp, goal, ref=False):
     wp = np.ascontiguousarray(wp, dtype=np.float64)
     goal = np.ascontiguousarray(goal, dtype=np.float64)
     return float(load(ref=ref).mpl_oracle_heur(dim, control, w, v_max, wp.ctypes.data, goal.ctypes.data))
+
+
+def goal_tol(dim, wp, goal, tol_pos, tol_vel=-1.0, tol_acc=-1.0, tol_yaw=-1.0, ref=False):
+    """env_map::is_goal without the ray trace; wp / goal: 4D+2 doubles."""
+    a = np.ascontiguousarray(wp, dtype=np.float64)
+    b = np.ascontiguousarray(goal, dtype=np.float64)
+    return bool(load(ref).mpl_oracle_goal_tol(dim, a.ctypes.data, b.ctypes.data, float(tol_pos), float(tol_vel),
+                                              float(tol_acc), float(tol_yaw)))
 
 
 def loop_count(T, n, ref=False):

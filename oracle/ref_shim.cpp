@@ -252,6 +252,24 @@ static int get_succ_lists(const mpl_oracle_env *e, const double *node, double *s
   return 0;
 }
 
+/* env_map<Dim>::is_goal on an all-free map (so that the ray trace of env_map.h:38-43 cannot fail) */
+template <int D>
+static int32_t goal_tol(const double *wp, const double *goal, double tol_pos, double tol_vel, double tol_acc,
+                        double tol_yaw) {
+  auto mu = std::make_shared<MPL::MapUtil<D>>();
+  Vecf<D> ori;
+  Veci<D> dim;
+  for (int i = 0; i < D; i++) { ori(i) = -1e6; dim(i) = 4; }
+  mu->setMap(ori, dim, MPL::Tmap((size_t)(D == 2 ? 16 : 64), 0), 5e5);
+  MPL::env_map<D> env(mu);
+  env.set_tol_pos(tol_pos);
+  env.set_tol_vel(tol_vel);
+  env.set_tol_acc(tol_acc);
+  env.set_tol_yaw(tol_yaw);
+  env.set_goal(load_wp<D>(goal, 1, 0, 0x1f));
+  return env.is_goal(load_wp<D>(wp, 1, 0, 0x1f)) ? 1 : 0;
+}
+
 extern "C" {
 
 int mpl_oracle_get_succ(void *user, const double *node, double *succ, double *cost, int32_t *action,
@@ -288,6 +306,12 @@ double mpl_oracle_heur(int32_t dim, int32_t control, double w, double v_max, con
   env.set_v_max(v_max);
   env.set_goal(load_wp<3>(goal, 1, 0, control));
   return env.get_heur(load_wp<3>(wp, 1, 0, control));
+}
+
+int32_t mpl_oracle_goal_tol(int32_t dim, const double *wp, const double *goal, double tol_pos, double tol_vel,
+                            double tol_acc, double tol_yaw) {
+  if (dim == 2) return goal_tol<2>(wp, goal, tol_pos, tol_vel, tol_acc, tol_yaw);
+  return goal_tol<3>(wp, goal, tol_pos, tol_vel, tol_acc, tol_yaw);
 }
 
 int32_t mpl_oracle_loop_count(double T, int32_t n) {

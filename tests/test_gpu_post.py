@@ -1,0 +1,89 @@
+"""GPU: successor post-processing (post_kernel.hip through
+mplx_post_lists_device) against the oracle: the default heuristic
+(env_base.h:46-64), the goal tolerances of env_map::is_goal (env_map.h:25-37)
+and the node identity the search derives from the lattice hash."""
+import numpy as np
+import pytest
+
+from helpers import engine_env
+from test_gpu_parity import _small_world
+
+pytestmark = pytest.mark.gpu
+
+
+def _emitted_indices(lists):
+    S = lists["stride"]
+    idx = np.concatenate([k * S + np.arange(c) for k, c in enumerate(lists["count"])]) if lists["count"].sum() else \
+        np.zeros(0, np.int64)
+    return idx.astype(np.int64)
+
+
+@pytest.mark.parametrize("dim,control", [(2, 0x03), (3, 0x03), (3, 0x07), (2, 0x13)])
+def test_heuristic_goal_flags_and_identity(engine, oracle_lib, dim, control):
+    O = oracle_lib
+    wl = _small_world(engine, dim, control, seed=4000 + 10 * dim + control, n_nodes=150)
+    # duplicates across the batch: repeat some nodes (same successors), and nodes that reach common states
+    wl.nodes[:, 100:150] = wl.nodes[:, 0:50]
+    env = engine_env(engine, wl)
+    fr = env.upload_frontier(wl.nodes)
+    lists = env.alloc_lists(wl.n_nodes, want_state=True)
+    env.expand_lists_resident(fr, lists)
+    env.synchronize()
+    L = lists.download()
+    idx = _emitted_indices(L)
+    assert idx.size > 500
+    # goal: the state of one emitted successor, so that "same lattice state" and the tolerances fire
+    goal = L["state"][:, idx[idx.size // 3]].copy()
+    w, v_max = 10.0, 1.5
+    for tols in ((0.5, -1.0, -1.0, -1.0), (1.0, 0.5, -1.0, -1.0), (1.0, 1.0, 1.5, 0.6), (0.0, 0.0, 0.0, 0.0)):
+        got = env.post_lists(lists, goal, w=w, v_max=v_max, tol_pos=tols[0], tol_vel=tols[1], tol_acc=tols[2],
+                             tol_yaw=tols[3])
+        gh = O.lattice_hash(dim, control, goal)
+        n_goal = n_same = 0
+        for g in idx[::7]:  # every 7th successor through the scalar oracle entry points
+            wp = L["state"][:, g]
+            assert got["heur"][g] == O.heur(dim, control, w, v_max, wp, goal), "heur @%d" % g
+            want_goal = O.goal_tol(dim, wp, goal, *tols)
+            assert bool(got["flags"][g] & 1) == want_goal, "goal flag @%d" % g
+            assert bool(got["flags"][g] & 2) == (int(L["hash"][g]) == gh)
+            n_goal += want_goal
+            n_same += int(L["hash"][g]) == gh
+        # vectorised check of every successor
+        d = np.abs(L["state"][:dim, idx] - goal[:dim, None]).max(axis=0)
+        same = L["hash"][idx] == np.uint64(gh)
+        assert np.array_equal(got["heur"][idx], np.where(same, 0.0, w * d / v_max))
+        assert same.any() and (got["flags"][idx] & 1).any()
+        # node identity: canon = smallest list index with the same hash; bit 2 marks it
+        h = L["hash"][idx]
+        order = np.lexsort((idx, h))
+        hs, ids = h[order], idx[order]
+        first = np.concatenate([[True], hs[1:] != hs[:-1]])
+        canon_sorted = np.maximum.accumulate(np.where(first, np.arange(ids.size), 0))
+        want_canon = np.empty(idx.size, np.int64)
+        want_canon[order] = ids[canon_sorted]
+        assert np.array_equal(got["canon"][idx].astype(np.int64), want_canon)
+        assert np.array_equal((got["flags"][idx] & 4) != 0, want_canon == idx)
+        assert (want_canon != idx).sum() > 50  # the batch really had duplicates
+    lists.free()
+    fr.free()
+    env.close()
+
+
+def test_post_lists_without_velocity_limit_and_without_identity(engine, oracle_lib):
+    wl = _small_world(engine, 2, 0x03, seed=4242, n_nodes=40)
+    env = engine_env(engine, wl)
+    fr = env.upload_frontier(wl.nodes)
+    lists = env.alloc_lists(wl.n_nodes, want_state=True, stride=wl.U.shape[0])
+    env.expand_lists_resident(fr, lists)
+    env.synchronize()
+    L = lists.download()
+    idx = _emitted_indices(L)
+    goal = np.zeros(10)
+    goal[:2] = [2.0, 1.0]
+    got = env.post_lists(lists, goal, w=3.0, v_max=0.0, want_canon=False)  # v_max <= 0: w * |.|_inf (env_base.h:62)
+    for g in idx[::5]:
+        assert got["heur"][g] == oracle_lib.heur(2, 0x03, 3.0, 0.0, L["state"][:, g], goal)
+    assert "canon" not in got
+    lists.free()
+    fr.free()
+    env.close()

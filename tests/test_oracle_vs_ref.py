@@ -38,3 +38,18 @@ def test_hash_heur_loopcount_match_reference():
     for T in (1.0, 0.5, 0.3, 2.0):
         for n in range(5, 120):
             assert O.loop_count(T, n) == O.loop_count(T, n, ref=True)
+
+
+def test_goal_tolerance_matches_reference_is_goal():
+    """The norm tests of env_map::is_goal (env_map.h:25-37) against the reference's is_goal on a free map."""
+    rng = np.random.default_rng(9)
+    hits = 0
+    for dim in (2, 3):
+        for _ in range(400):
+            goal = np.round(rng.uniform(-5, 5, 4 * dim + 2), 2)
+            wp = goal + rng.choice([0.0, 0.1, 0.3, 0.5, 0.50000001, 1.0], size=goal.size) * rng.choice([-1, 1], size=goal.size)
+            tp, tv, ta, ty = rng.choice([0.5, 0.3, 1.0]), rng.choice([-1.0, 0.0, 0.3]), rng.choice([-1.0, 0.5]), rng.choice([-1.0, 0.3])
+            a = O.goal_tol(dim, wp, goal, tp, tv, ta, ty)
+            assert a == O.goal_tol(dim, wp, goal, tp, tv, ta, ty, ref=True)
+            hits += a
+    assert 0 < hits < 800
