@@ -214,6 +214,33 @@ typedef struct {
 int mplx_post_lists_device(mplx_ctx *ctx, const mplx_succ_lists *d_lists, int64_t n_nodes,
                            const mplx_goal_spec *goal, const mplx_post *d_out);
 
+/* ---- batched re-validation of stored edges for incremental re-planning
+ *       --------------------------------------------------- */
+/* For every edge (parent waypoint, action id): env_base::forward_action
+ * (env_base.h:228-231), then
+ *   free_flag   env_map::is_free(Primitive), env_map.h:60-76 (uniform samples
+ *               i * t/n, n = ceil(max_v * t / res); occupied / outside / outside
+ *               the search region -> 0); an edge that does not move (n == 0) is
+ *               reported not free (the reference's behaviour there is undefined)
+ *   cost        calculate_intrinsic_cost (env_base.h:343-345) = J + w*dt for a
+ *               free edge, +inf otherwise -- what StateSpace::decreaseCost
+ *               installs (state_space.h:230-253)
+ *   cells       MapPlanner::getLinkedNodes (map_planner.cpp:125-157): the cell
+ *               indices the samples fall into, consecutive repeats removed;
+ *               cell_count[e] entries of row e ([n_edges][cell_cap]; a count
+ *               above cell_cap means the row was truncated)
+ * All pointers are host pointers; any output may be NULL.                     */
+typedef struct {
+  uint8_t *free_flag;
+  double *cost;
+  int32_t *cells;
+  int32_t *cell_count;
+  int32_t cell_cap;
+} mplx_edges_out;
+/* parents: field-major [4D+2][stride] (stride >= n_edges), actions: [n_edges]. */
+int mplx_check_edges(mplx_ctx *ctx, const double *h_parents, const int32_t *h_actions, int64_t n_edges,
+                     int64_t stride, const mplx_edges_out *h_out);
+
 /* ---- device memory + stream helpers (so any host language can keep the
  *      frontier and the successor slots resident in HBM) ------------------- */
 int mplx_device_alloc(mplx_ctx *ctx, size_t bytes, void **dptr);

@@ -19,7 +19,7 @@ SYMBOLS = [
     "mplx_set_map", "mplx_set_potential", "mplx_set_region", "mplx_set_params", "mplx_set_controls",
     "mplx_update_potential_map", "mplx_set_search_region_path",
     "mplx_expand_device", "mplx_expand", "mplx_expand_lists_device", "mplx_expand_lists", "mplx_get_succ",
-    "mplx_post_lists_device",
+    "mplx_post_lists_device", "mplx_check_edges",
     "mplx_device_alloc", "mplx_device_free", "mplx_memcpy_h2d", "mplx_memcpy_d2h", "mplx_memset",
     "mplx_synchronize", "mplx_timer_begin", "mplx_timer_end",
     "mplx_planner_create", "mplx_planner_destroy", "mplx_planner_attach_ctx", "mplx_planner_set_provider",
@@ -58,6 +58,11 @@ class GoalSpec(C.Structure):
     _fields_ = [("goal", C.c_void_p), ("control", C.c_int32), ("reserved", C.c_int32), ("w", C.c_double),
                 ("v_max", C.c_double), ("tol_pos", C.c_double), ("tol_vel", C.c_double), ("tol_acc", C.c_double),
                 ("tol_yaw", C.c_double)]
+
+
+class EdgesOut(C.Structure):
+    _fields_ = [("free_flag", C.c_void_p), ("cost", C.c_void_p), ("cells", C.c_void_p), ("cell_count", C.c_void_p),
+                ("cell_cap", C.c_int32)]
 
 
 class Post(C.Structure):
@@ -123,6 +128,7 @@ def lib():
         "mplx_expand_lists": (C.c_int, [vp, vp, i64, i64, C.POINTER(SuccLists)]),
         "mplx_get_succ": (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(i32)]),
         "mplx_post_lists_device": (C.c_int, [vp, C.POINTER(SuccLists), i64, C.POINTER(GoalSpec), C.POINTER(Post)]),
+        "mplx_check_edges": (C.c_int, [vp, vp, vp, i64, i64, C.POINTER(EdgesOut)]),
         "mplx_device_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
         "mplx_device_free": (C.c_int, [vp, vp]),
         "mplx_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),

@@ -125,6 +125,27 @@ hipError_t launch_expand_grid(int dim, int control, const GridArgs &args, hipStr
 hipError_t launch_build_blocked_bits(const int8_t *map, const uint32_t *region, int64_t n_cells, uint32_t *out,
                                      hipStream_t stream);
 
+// Batched edge re-validation (edge_kernel.hip).
+struct EdgeArgs {
+  const int8_t *map;
+  const uint32_t *region;
+  int32_t dim0, dim1, dim2;
+  double org0, org1, org2;
+  double res;
+  double dt, w;
+  const double *U;
+  int32_t nU, udim;
+  const double *parents;   // [4D+2][stride]
+  const int32_t *action;   // [n_edges]
+  int64_t n_edges, stride;
+  uint8_t *free_out;       // outputs, any may be null
+  double *cost;
+  int32_t *cells;          // [n_edges][cell_cap]
+  int32_t *cell_count;
+  int32_t cell_cap;
+};
+hipError_t launch_check_edges(int dim, int control, const EdgeArgs &args, hipStream_t s);
+
 // Successor post-processing (post_kernel.hip): heuristic, goal tolerances, node identity.
 struct PostArgs {
   const int32_t *count;    // [n_nodes]

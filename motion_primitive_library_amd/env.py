@@ -448,6 +448,26 @@ class EnvMap:
         flags.free()
         return out
 
+    def check_edges(self, parents, actions, cell_cap=0):
+        """Batched env_map::is_free(Primitive) + calculate_intrinsic_cost (+ the linked cells of
+        MapPlanner::getLinkedNodes when cell_cap > 0) for edges (parent column, action id)."""
+        self._flush()
+        parents = np.ascontiguousarray(parents, dtype=np.float64)
+        actions = np.ascontiguousarray(actions, dtype=np.int32)
+        n = actions.size
+        if parents.ndim != 2 or parents.shape != (self.n_fields, n):
+            raise ValueError("parents must be [%d][%d]" % (self.n_fields, n))
+        out = {"free": np.zeros(n, np.uint8), "cost": np.zeros(n, np.float64)}
+        o = _abi.EdgesOut()
+        o.free_flag, o.cost = out["free"].ctypes.data, out["cost"].ctypes.data
+        if cell_cap > 0:
+            out["cells"] = np.zeros((n, int(cell_cap)), np.int32)
+            out["cell_count"] = np.zeros(n, np.int32)
+            o.cells, o.cell_count, o.cell_cap = out["cells"].ctypes.data, out["cell_count"].ctypes.data, int(cell_cap)
+        _abi.check(self._ctx, _abi.lib().mplx_check_edges(self._ctx, parents.ctypes.data, actions.ctypes.data, n, n,
+                                                           C.byref(o)))
+        return out
+
     def upload_frontier(self, nodes):
         nodes = np.ascontiguousarray(nodes, dtype=np.float64)
         if nodes.ndim != 2 or nodes.shape[0] != self.n_fields:

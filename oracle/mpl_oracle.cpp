@@ -692,6 +692,58 @@ int32_t mpl_oracle_loop_count(double T, int32_t n) {
 
 }  // extern "C"
 
+/* ---- batched edge re-validation ------------------------- */
+namespace {
+template <int D>
+void check_edges(const mpl_oracle_env *e, const double *parents, const int32_t *actions, int64_t n, uint8_t *free_out,
+                 double *cost_out, int32_t *cells, int32_t *cell_count, int32_t cell_cap) {
+  Env<D> env{e};
+  for (int64_t k = 0; k < n; k++) {
+    const State<D> par = load_state<D>(parents, n, k, e->control);
+    /* env_base::forward_action, env_base.h:228-231 */
+    Prim<D> pr(par, e->U + (size_t)actions[k] * e->udim, e->dt);
+    /* env_map::is_free(Primitive), env_map.h:60-76, and MapPlanner::getLinkedNodes, map_planner.cpp:136-153 */
+    double max_v = 0;
+    for (int i = 0; i < D; i++)
+      if (pr.max_vel(i) > max_v) max_v = pr.max_vel(i);
+    const int N = std::ceil(max_v * pr.T / e->res);
+    bool is_free = N > 0; /* N == 0: the reference samples t = NaN (undefined cell); reported not free */
+    int n_cells = 0, prev_id = -1;
+    if (N > 0) {
+      const double dt = pr.T / N; /* Primitive::sample, primitive.h:415-420 */
+      for (int i = 0; i <= N; i++) {
+        const State<D> pt = pr.evaluate(i * dt);
+        int pn[3];
+        env.to_cell(pt.pos, pn);
+        const int id = env.index(pn);
+        if (cells && id != prev_id) {
+          if (n_cells < cell_cap) cells[k * cell_cap + n_cells] = id;
+          n_cells++;
+          prev_id = id;
+        }
+        if (is_free) {
+          if (env.occupied(pn) || env.outside(pn)) is_free = false;
+          else if (e->region && !e->region[id]) is_free = false;
+        }
+      }
+    }
+    if (free_out) free_out[k] = is_free ? 1 : 0;
+    if (cost_out) cost_out[k] = is_free ? pr.effort() + e->w * e->dt : kInf; /* env_base.h:343-345 */
+    if (cell_count) cell_count[k] = n_cells;
+  }
+}
+}  // namespace
+
+extern "C" int mpl_oracle_check_edges(const mpl_oracle_env *env, const double *parents, const int32_t *actions,
+                                      int64_t n, uint8_t *free_out, double *cost_out, int32_t *cells,
+                                      int32_t *cell_count, int32_t cell_cap) {
+  if (!env || (n > 0 && (!parents || !actions))) return -1;
+  if (env->dim == 2) check_edges<2>(env, parents, actions, n, free_out, cost_out, cells, cell_count, cell_cap);
+  else if (env->dim == 3) check_edges<3>(env, parents, actions, n, free_out, cost_out, cells, cell_count, cell_cap);
+  else return -1;
+  return 0;
+}
+
 /* ===================================================================== *
  *  Map preprocessing: CPU restatements, same structure  *
  *  as the reference's loops.  TEST INFRASTRUCTURE, like everything here. *

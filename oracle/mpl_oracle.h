@@ -103,6 +103,15 @@ int32_t mpl_oracle_goal_tol(int32_t dim, const double *wp, const double *goal, d
  * (env_map.h:97-99): n or n+1.                                              */
 int32_t mpl_oracle_loop_count(double T, int32_t n);
 
+/* Batched edge re-validation: env_base::forward_action
+ * (env_base.h:228-231), env_map::is_free(Primitive) (env_map.h:60-76),
+ * calculate_intrinsic_cost (env_base.h:343-345; +inf when not free) and the
+ * linked cells of MapPlanner::getLinkedNodes (map_planner.cpp:125-157).
+ * parents: field-major [4D+2][n]; cells: [n][cell_cap] or NULL.               */
+int mpl_oracle_check_edges(const mpl_oracle_env *env, const double *parents, const int32_t *actions,
+                           int64_t n, uint8_t *free_out, double *cost_out, int32_t *cells,
+                           int32_t *cell_count, int32_t cell_cap);
+
 /* Map preprocessing.  MapPlanner<Dim>::updatePotentialMap with
  * createMask (src/mpl_planner/map_planner.cpp:246-283, 286-391): map_out
  * receives the map with the potential field stamped in.  radius / range / pos

@@ -209,6 +209,29 @@ def goal_tol(dim, wp, goal, tol_pos, tol_vel=-1.0, tol_acc=-1.0, tol_yaw=-1.0, r
                                               float(tol_acc), float(tol_yaw)))
 
 
+def check_edges(env, parents, actions, cell_cap=0, ref=False):
+    """Batched is_free(Primitive) + intrinsic cost (+ linked cells) for edges (parent column, action)."""
+    lib = load(ref)
+    lib.mpl_oracle_check_edges.restype = C.c_int
+    lib.mpl_oracle_check_edges.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int32]
+    parents = np.ascontiguousarray(parents, dtype=np.float64)
+    actions = np.ascontiguousarray(actions, dtype=np.int32)
+    n = actions.size
+    out = {"free": np.zeros(n, np.uint8), "cost": np.zeros(n, np.float64)}
+    cells = cnt = None
+    if cell_cap > 0:
+        out["cells"] = np.zeros((n, int(cell_cap)), np.int32)
+        out["cell_count"] = np.zeros(n, np.int32)
+        cells, cnt = out["cells"].ctypes.data, out["cell_count"].ctypes.data
+    ce = env._c()
+    rc = lib.mpl_oracle_check_edges(C.byref(ce), parents.ctypes.data, actions.ctypes.data, n, out["free"].ctypes.data,
+                                    out["cost"].ctypes.data, cells, cnt, int(cell_cap))
+    if rc != 0:
+        raise RuntimeError("mpl_oracle_check_edges failed: %d" % rc)
+    return out
+
+
 def loop_count(T, n, ref=False):
     return int(load(ref=ref).mpl_oracle_loop_count(float(T), int(n)))
 

@@ -270,6 +270,53 @@ static int32_t goal_tol(const double *wp, const double *goal, double tol_pos, do
   return env.is_goal(load_wp<D>(wp, 1, 0, 0x1f)) ? 1 : 0;
 }
 
+/* Batched edge re-validation through the reference's own env_map (forward_action, is_free(Primitive),
+ * calculate_intrinsic_cost) and the loop body of MapPlanner::getLinkedNodes (map_planner.cpp:136-153). */
+template <int D>
+static void ref_check_edges(const mpl_oracle_env *e, const double *parents, const int32_t *actions, int64_t n,
+                            uint8_t *free_out, double *cost_out, int32_t *cells, int32_t *cell_count, int32_t cell_cap) {
+  Rig<D> rig(e);
+  for (int64_t k = 0; k < n; k++) {
+    const Waypoint<D> par = load_wp<D>(parents, n, k, e->control);
+    Primitive<D> pr;
+    rig.env->forward_action(par, actions[k], pr);
+    decimal_t max_v = 0;
+    for (int i = 0; i < D; i++)
+      if (pr.max_vel(i) > max_v) max_v = pr.max_vel(i);
+    const int N = 1.0 * std::ceil(max_v * pr.t() / rig.map_util->getRes());
+    bool is_free = false;
+    int n_cells = 0;
+    if (N > 0) {  /* N == 0 is undefined behaviour in the reference (sample time NaN) */
+      is_free = rig.env->is_free(pr);
+      if (cells) {
+        int prev_id = -1;
+        vec_E<Waypoint<D>> ws = pr.sample(N);
+        for (const auto &w : ws) {
+          int id = rig.map_util->getIndex(rig.map_util->floatToInt(w.pos));
+          if (id != prev_id) {
+            if (n_cells < cell_cap) cells[k * cell_cap + n_cells] = id;
+            n_cells++;
+            prev_id = id;
+          }
+        }
+      }
+    }
+    if (free_out) free_out[k] = is_free ? 1 : 0;
+    if (cost_out) cost_out[k] = is_free ? rig.env->calculate_intrinsic_cost(pr) : std::numeric_limits<decimal_t>::infinity();
+    if (cell_count) cell_count[k] = n_cells;
+  }
+}
+
+extern "C" int mpl_oracle_check_edges(const mpl_oracle_env *env, const double *parents, const int32_t *actions,
+                                      int64_t n, uint8_t *free_out, double *cost_out, int32_t *cells,
+                                      int32_t *cell_count, int32_t cell_cap) {
+  if (!env || (n > 0 && (!parents || !actions))) return -1;
+  if (env->dim == 2) ref_check_edges<2>(env, parents, actions, n, free_out, cost_out, cells, cell_count, cell_cap);
+  else if (env->dim == 3) ref_check_edges<3>(env, parents, actions, n, free_out, cost_out, cells, cell_count, cell_cap);
+  else return -1;
+  return 0;
+}
+
 extern "C" {
 
 int mpl_oracle_get_succ(void *user, const double *node, double *succ, double *cost, int32_t *action,
