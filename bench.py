@@ -46,6 +46,18 @@ def algorithmic_bytes(wl, n_emit, n_samples):
     return (wl.n_nodes * s_wp + wl.U.size * 8 + n_samples * (1 + r / 8.0) + n_emit * (s_wp + 8 + 4))
 
 
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, each its own
+    run; profiles/README.md): bench.py cannot collect counters itself, so it reports the figure measured for
+    this workload + kernel, or None when no such profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % workload.lower())
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    return rec["traffic_bytes"] if rec.get("kernel", "").split("<")[0] in kernel else None
+
+
 def cpu_baseline(wl, target_seconds=12.0):
     """Times the CPU oracle (reference-structured port) on a bounded sample of
     the workload's frontier, on all host cores and on one core."""
@@ -165,6 +177,8 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
+        out_kernel = {"grid": "expand_grid_kernel", "tile": "expand_tile_kernel", "dense": "expand_kernel",
+                      "none": "expand_kernel"}[env.last_lists_route()]
         kernel_ms = kernel_ms_total / args.steps
         achieved = b_alg / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -194,7 +208,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic(args.workload, out_kernel) if args.output == "lists" else None,
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_alg,
                 "emitted": n_emit, "finite": n_finite, "map_samples": n_samples,
             },

@@ -103,6 +103,26 @@ def test_lists_irregular_control_tables(engine, oracle_lib, dim, n_controls, n_d
     assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="irregular U %dx%d" % (n_controls, n_distinct))
 
 
+@pytest.mark.parametrize("rmax,boxcap", [("1", None), (None, "8"), ("2", "40")])
+def test_grid_kernel_small_lds_budgets(engine, oracle_lib, monkeypatch, rmax, boxcap):
+    """The factorised kernel with a starved LDS budget (tuning overrides read at launch): one row of
+    cell codes per pass forces the multi-pass path, a tiny box forces sampling straight from the
+    blocked-bit map.  Results must not change."""
+    if rmax:
+        monkeypatch.setenv("MPLX_GRID_RMAX", rmax)
+    if boxcap:
+        monkeypatch.setenv("MPLX_GRID_BOXCAP", boxcap)
+    for dim, control, region in ((3, 0x03, False), (2, 0x07, True), (3, 0x0F, True)):
+        wl = _small_world(engine, dim, control, seed=3100 + dim + control, region=region, n_nodes=80)
+        ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+        env = engine_env(engine, wl)
+        env.set_lists_route("grid")
+        got = env.expand_lists(wl.nodes)
+        env.close()
+        assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="rmax=%s boxcap=%s dim%d ctrl0x%x" % (
+            rmax, boxcap, dim, control))
+
+
 def test_node_stride_smaller_than_the_control_table_is_rejected(engine):
     wl = _small_world(engine, 2, 0x03, seed=6, n_nodes=8)
     env = engine_env(engine, wl)
