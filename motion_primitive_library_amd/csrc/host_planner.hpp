@@ -27,6 +27,9 @@
 #include <cstdio>
 #include <limits>
 #include <memory>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <unordered_map>
 #include <vector>
 
@@ -278,6 +281,7 @@ class Planner {
   // PlannerBase::plan (A*), planner_base.h:275-325 + GraphSearch::Astar
   int plan(const double *start, const double *goal) {
     last = PlanResult();
+    t_succ = t_provider = t_fill = t_pick = 0;
     hm.clear();
     pq = OpenList();
     if (!single && !batched) return -1;
@@ -306,7 +310,9 @@ class Planner {
       pq.pop();
       curr->closed = true;
       int32_t n_succ = 0;
+      const auto t_s0 = std::chrono::steady_clock::now();
       if (int rc = successors(curr, succ.data(), cost.data(), act.data(), &n_succ)) return rc;
+      t_succ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_s0).count();
       for (int s = 0; s < n_succ; s++) {
         if (std::isinf(cost[(size_t)s])) continue;  // graph_search.h:81
         const double *sc = &succ[(size_t)s * f];
@@ -337,6 +343,9 @@ class Planner {
       if (max_expand > 0 && expand_iteration >= max_expand) break;
       if (pq.empty()) break;
     }
+    if (getenv("MPLX_PLAN_TIMING"))
+      fprintf(stderr, "[host_planner] successors() %.1f ms (provider %.1f ms, cache fill %.1f ms, candidate pick %.1f ms)\n",
+              t_succ, t_provider, t_fill, t_pick);
     last.expansions = expand_iteration;
     last.nodes = (int)hm.size();
     for (const auto &it : hm) {
@@ -349,6 +358,7 @@ class Planner {
   }
 
  private:
+  double t_succ = 0, t_provider = 0, t_fill = 0, t_pick = 0;  // MPLX_PLAN_TIMING diagnostics
   // One get_succ, possibly served from / filling the batch cache.
   int successors(const NodePtr &curr, double *succ, double *cost, int32_t *act, int32_t *n_succ) {
     const int f = F();
@@ -359,6 +369,7 @@ class Planner {
       return run_batch({curr}), fetch(curr, succ, cost, act, n_succ);
     }
     if (!curr->cached) {
+      const auto t_p0 = std::chrono::steady_clock::now();
       // the popped node plus the best open nodes that have no list yet
       std::vector<NodePtr> group{curr};
       std::vector<OpenList::Item> cand;
@@ -374,6 +385,7 @@ class Planner {
         cand.resize(want);
       }
       for (const auto &it : cand) group.push_back(it.n);
+      t_pick += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p0).count();
       if (int rc = run_batch(group)) return rc;
     }
     (void)f;
@@ -391,7 +403,10 @@ class Planner {
     std::vector<double> cs((size_t)slots), state((size_t)f * slots);
     last.device_launches++;
     last.pairs += slots;
+    const auto t_b0 = std::chrono::steady_clock::now();
     if (int rc = batched(user, nodes.data(), n, st.data(), cs.data(), state.data())) return rc;
+    const auto t_b1 = std::chrono::steady_clock::now();
+    t_provider += std::chrono::duration<double, std::milli>(t_b1 - t_b0).count();
     for (int64_t k = 0; k < n; k++) {
       Node &nd = *group[(size_t)k];
       nd.c_succ.clear(); nd.c_cost.clear(); nd.c_act.clear();
@@ -404,6 +419,7 @@ class Planner {
       }
       nd.cached = true;
     }
+    t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b1).count();
     return 0;
   }
 
