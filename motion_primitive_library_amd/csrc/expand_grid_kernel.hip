@@ -97,7 +97,7 @@ struct GridLds {
     w = (w + 7) & ~7;
     w_box = w; w += (boxcap * 4 > rmax * tts * 8) ? boxcap * 4 : rmax * tts * 8;  // also the sample times while rows are built
     w = (w + 15) & ~15;
-    w_misc = w; w += 24 * 4;
+    w_misc = w; w += 36 * 4;
     w_rowmap = w; w += 64;
     w_list = w; w += ((nU + 1) & ~1) * 2;
     w_cell = w; w += EN * rmax * tts + 8;  // + 8: the sample loop reads up to 7 codes past a row
@@ -129,7 +129,7 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // misc words of a wave
-enum { M_BASE = 0, M_NMASK = 4, M_LO = 6, M_HI = 9, M_NODEQ = 12 };  // NODEQ: [D][4]
+enum { M_BASE = 0, M_NMASK = 4, M_NV = 6, M_NODEQ = 12, M_VL = 24 };  // NV: valid entries per axis; NODEQ: [D][4]; VL: [D][16] bytes
 
 template <int D, int K>
 __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
@@ -160,7 +160,6 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
 
   const int tts = L.tts, EN = L.EN, PN = L.PN;
   const int half = A.n_max + 2;  // cell-offset code = offset from the node's cell + half
-  const int code_max = 2 * half;
   const double T = A.dt;
   const double org[3] = {A.org0, A.org1, A.org2};
   const int dims[3] = {A.dim0, A.dim1, A.dim2};
@@ -193,10 +192,10 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
     if (lane < 2) s_misc[M_NMASK + lane] = 0;
     wave_sync();
 
-    // ---- phase T1: axis entries; node hash (lane 63)
+    // ---- phase T1: axis entries; the node's own lattice integers (lanes 48..)
+    int flag = 0;
     if (lane < EN) {
       const int ax = lane / ndp, jv = lane - ax * ndp;
-      int flag = 0;
       if (jv < nd[ax]) {
         const double p = s_node[0 * D + ax];
         const double v = (K >= 2) ? s_node[1 * D + ax] : 0.0;
@@ -242,6 +241,16 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       if (f < K) {
         const double x = s_node[f * D + i];
         s_misc[M_NODEQ + i * 4 + f] = f == 0 ? quantise(x, 0.01, A.R001) : quantise(x, 0.1, A.R01);
+      }
+    }
+    {
+      // per axis, the values that pass the limits, in order: the only entries whose samples are ever needed
+      const unsigned long long vm = __ballot((flag & 1) != 0);
+      if (lane < EN) {
+        const int ax = lane / ndp, jv = lane - ax * ndp;
+        const unsigned long long am = (((1ull << ndp) - 1ull) << (ax * ndp)) & vm;
+        if (flag & 1) ((unsigned char *)(s_misc + M_VL))[ax * 16 + __popcll(am & ((1ull << lane) - 1ull))] = (unsigned char)jv;
+        if (jv == 0) s_misc[M_NV + ax] = __popcll(am);
       }
     }
     wave_sync();
@@ -364,6 +373,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       // rows: cell-offset codes of every axis entry at t_0 .. t_{cnt-1} of each sample count;
       // lanes = (value, k) of ONE axis at a time, so everything per axis is scalar
       int lo_l[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi_l[3] = {-1, -1, -1};  // per lane, reduced below
+      bool ovf = false;
       {
         int row = 0;
         for (unsigned long long t = sub; t; t &= t - 1ull, row++) {
@@ -378,10 +388,12 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
             const double a0 = (K >= 3) ? s_node[2 * D + ax] : 0.0;
             const double j0 = (K >= 4) ? s_node[3 * D + ax] : 0.0;
             const int shift = half - base_c[ax];
-            for (int x = lane; x < ((A.dbg & 16) ? 0 : nd[ax] * cn); x += 64) {  // dbg 16: timing ablation
-              const int jv = (int)(((float)x + 0.5f) * inv_cn);  // exact: x < 2^12
-              const int k = x - __umul24(jv, cn);
-              const int aj = ax * ndp + jv;
+            const int nv = __builtin_amdgcn_readfirstlane(s_misc[M_NV + ax]);
+            const unsigned char *vl = (const unsigned char *)(s_misc + M_VL) + ax * 16;
+            for (int x = lane; x < nv * cn; x += 64) {
+              const int vi = (int)(((float)x + 0.5f) * inv_cn);  // exact: x < 2^12
+              const int k = x - __umul24(vi, cn);
+              const int aj = ax * ndp + (int)vl[vi];
               Ax<K> q;
               q.init(p0, v0, a0, j0, s_uval[aj]);
               // map_util.h:103-108: cell = round((pos - origin) / res - 0.5)
@@ -389,13 +401,15 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               // qd - 0.5 > -0.5 <=> the rounded cell is >= 0; then qd > 0 and (qd - 0.5 being exact
               // for qd >= 0.5) round-half-away(qd - 0.5) == trunc(qd).  Negative cells: see M_BASE.
               const int c = (qd - 0.5 > -0.5) ? (int)qd : -1;
-              int code = c + shift;
-              code = code < 0 ? 0 : (code > code_max ? code_max : code);  // clamps only entries no valid pair uses
+              // An entry within the limits moves at most n_max + 1 cells in T, so 0 < code < 2 * half --
+              // as long as max_vel is the true maximum.  The reference's root loop can miss an extremum
+              // of a SNP primitive (it stops at the first root >= T, primitive.h:158-159), so the range
+              // is checked and a pass with an escaped code samples by direct evaluation instead.
+              const int code = c + shift;
+              ovf = ovf || code < 0 || code > 2 * half;
               s_cell[__umul24(__umul24(aj, RM) + row, tts) + k] = (unsigned char)code;
-              if (s_eflag[aj] & 1) {
-                lo_l[ax] = code < lo_l[ax] ? code : lo_l[ax];
-                hi_l[ax] = code > hi_l[ax] ? code : hi_l[ax];
-              }
+              lo_l[ax] = code < lo_l[ax] ? code : lo_l[ax];
+              hi_l[ax] = code > hi_l[ax] ? code : hi_l[ax];
             }
           }
         }
@@ -421,7 +435,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       wave_sync();  // rows complete; the sample times (aliasing the box) are no longer needed
       const int WX = (nb[0] + 31) >> 5;
       const int n_rows = nb[1] * nb[2];
-      const bool fits = have_box && n_rows * WX <= A.boxcap;
+      const bool direct = (__ballot(ovf) != 0ull) || (A.dbg & 64);  // dbg 64: test hook, force direct evaluation
+      const bool fits = !direct && have_box && n_rows * WX <= A.boxcap;
       if (fits && sub) {
         const float inv_ny = 1.0f / (float)nb[1];
         const int ax0 = base_c[0] + lo[0] - half;
@@ -540,6 +555,37 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               if (left < kUB) m &= (1u << (left > 0 ? left : 0)) - 1u;
               if (!done && m) { fb = k0 + __ffs((int)m) - 1; done = true; }
               if (left <= kUB) done = true;
+            }
+          } else if (direct) {
+            // a cell code left its range: evaluate every sample of the pair directly (as expand_tile_kernel does)
+            double p0[D], v0[D], a0[D], j0d[D], uu[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+              p0[i] = s_node[0 * D + i];
+              v0[i] = (K >= 2) ? s_node[1 * D + i] : 0.0;
+              a0[i] = (K >= 3) ? s_node[2 * D + i] : 0.0;
+              j0d[i] = (K >= 4) ? s_node[3 * D + i] : 0.0;
+              uu[i] = s_uval[en[i]];
+            }
+            for (int k = 0; __ballot(!done) != 0ull; k++) {
+              if (!done) {
+                const double t_k = A.ttab[n * kTabStride + k];
+                bool inside = true;
+                int64_t cell = 0, mul = 1;
+#pragma unroll
+                for (int i = 0; i < D; i++) {
+                  Ax<K> q;
+                  q.init(p0[i], v0[i], a0[i], j0d[i], uu[i]);
+                  const double qd = div_by(q.template pos<false>(t_k) - org[i], A.res, A.Rres);
+                  const int c = (qd - 0.5 > -0.5) ? (int)qd : -1;
+                  inside = inside && c >= 0 && c < dims[i];
+                  cell += mul * c;
+                  mul *= dims[i];
+                }
+                const bool blocked = !inside || ((A.blk[inside ? (cell >> 5) : 0] >> (cell & 31)) & 1u);
+                if (blocked) { fb = k; done = true; }
+                if (k + 1 >= cntl) done = true;
+              }
             }
           } else {
             // box too large for LDS: straight from the blocked-bit map, one sample per step

@@ -103,8 +103,8 @@ def test_lists_irregular_control_tables(engine, oracle_lib, dim, n_controls, n_d
     assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="irregular U %dx%d" % (n_controls, n_distinct))
 
 
-@pytest.mark.parametrize("rmax,boxcap", [("1", None), (None, "8"), ("2", "40")])
-def test_grid_kernel_small_lds_budgets(engine, oracle_lib, monkeypatch, rmax, boxcap):
+@pytest.mark.parametrize("rmax,boxcap,dbg", [("1", None, None), (None, "8", None), ("2", "40", None), (None, None, "64")])
+def test_grid_kernel_small_lds_budgets(engine, oracle_lib, monkeypatch, rmax, boxcap, dbg):
     """The factorised kernel with a starved LDS budget (tuning overrides read at launch): one row of
     cell codes per pass forces the multi-pass path, a tiny box forces sampling straight from the
     blocked-bit map.  Results must not change."""
@@ -112,6 +112,8 @@ def test_grid_kernel_small_lds_budgets(engine, oracle_lib, monkeypatch, rmax, bo
         monkeypatch.setenv("MPLX_GRID_RMAX", rmax)
     if boxcap:
         monkeypatch.setenv("MPLX_GRID_BOXCAP", boxcap)
+    if dbg:  # bit 64: every pass samples by direct evaluation (the path taken when a cell code leaves its range)
+        monkeypatch.setenv("MPLX_TILE_DBG", dbg)
     for dim, control, region in ((3, 0x03, False), (2, 0x07, True), (3, 0x0F, True)):
         wl = _small_world(engine, dim, control, seed=3100 + dim + control, region=region, n_nodes=80)
         ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
