@@ -396,6 +396,7 @@ GridPlan plan_grid(const mplx_ctx *c) {
   g.rmax = rmax;
   g.boxcap = boxcap;
   g.grid = c->n_cus * per_cu;
+  if (const char *e = getenv("MPLX_GRID_BLOCKS")) g.grid = atoi(e) > 0 ? atoi(e) : g.grid;  // tuning only
   return g;
 }
 

@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-for d in 0 1 4; do
+for d in ${@:-0 2}; do
 OUT=$PWD/gpurun_out/pa$d; mkdir -p $OUT
 MPLX_TILE_DBG=$d rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU -f csv -d $OUT -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/log 2>&1
 python - <<PY
