@@ -114,7 +114,10 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # MPLX_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL init, barrier, all-reduce of the timing) with whatever
+    # world size the launcher gave, including 1 -- the only way to exercise it on a one-GPU box
+    force_dist = os.environ.get("MPLX_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -150,7 +153,7 @@ def main():
     b_alg = algorithmic_bytes(wl, n_emit, n_samples)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +168,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -231,7 +234,7 @@ def main():
     slots.free()
     frontier.free()
     env.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -70,7 +70,7 @@ struct GridLds {
   // shared by the workgroup (read-only after set-up)
   int o_uval, o_uidx, o_tc, o_wave0;
   // per wave, relative to the wave's block
-  int w_hcur, w_node, w_est, w_eJ, w_hp, w_eq, w_eflag, w_fp, w_box, w_misc, w_rowmap, w_list, w_cell, wave_bytes;
+  int w_node, w_est, w_eJ, w_hp, w_eq, w_eflag, w_fp, w_box, w_misc, w_rowmap, w_list, w_cell, wave_bytes;
   int total;
   int F, EN, PN, tts;
   __host__ __device__ GridLds(int D, int K, int waves, int nU, int ndp, int n_max, int rmax, int boxcap) {
@@ -85,7 +85,6 @@ struct GridLds {
     b = (b + 15) & ~15;
     o_wave0 = b;
     int w = 0;
-    w_hcur = w; w += 8;
     w_node = w; w += F * 8;
     w_est = w; w += EN * K * 8;  // end-state fields of order < K (the rest follow from u)
     w_eJ = w; w += EN * 8;
@@ -143,7 +142,6 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   const unsigned int *s_uidx = (const unsigned int *)(smem + L.o_uidx);
   const unsigned char *s_tc = smem + L.o_tc;
   unsigned char *wb = smem + L.o_wave0 + wv * L.wave_bytes;
-  uint64_t *s_hcur = (uint64_t *)(wb + L.w_hcur);
   double *s_node = (double *)(wb + L.w_node);
   double *s_est = (double *)(wb + L.w_est);
   double *s_eJ = (double *)(wb + L.w_eJ);
