@@ -30,6 +30,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <queue>
 #include <unordered_map>
 #include <vector>
 
@@ -120,6 +121,11 @@ typedef int (*succ_fn)(void *user, const double *node, double *succ, double *cos
 typedef int (*batch_fn)(void *user, const double *nodes, int64_t n, uint8_t *status, double *cost,
                         double *state /*[4D+2][n*nU]*/);
 
+// batched form producing per-node lists (the layout of mplx_succ_lists with node stride nU and
+// state row stride n*nU), including the lattice hash of every successor
+typedef int (*lists_fn)(void *user, const double *nodes, int64_t n, int32_t *count, int32_t *action, double *cost,
+                        uint64_t *hash, double *state /*[4D+2][n*nU]*/);
+
 struct Node;
 typedef std::shared_ptr<Node> NodePtr;
 
@@ -138,6 +144,7 @@ struct Node {
   std::vector<double> c_succ;
   std::vector<double> c_cost;
   std::vector<int32_t> c_act;
+  std::vector<uint64_t> c_key;  // lattice hashes of the cached successors (when the provider supplies them)
 };
 
 // Mutable binary max-heap on compare_pair (state_space.h:16-34): the top is the
@@ -249,6 +256,7 @@ class Planner {
   Grid grid;
   succ_fn single = nullptr;
   batch_fn batched = nullptr;
+  lists_fn lists = nullptr;  // preferred over `batched` when set: compact lists + device-side hashes
   void *user = nullptr;
 
   std::unordered_map<uint64_t, NodePtr> hm;
@@ -258,7 +266,10 @@ class Planner {
   int F() const { return 4 * dim + 2; }
 
   double heur(const double *s, const double *goal) const {  // env_base.h:46-64
-    if (lattice_hash(dim, control, s) == lattice_hash(dim, control, goal)) return 0;
+    return heur_keyed(s, lattice_hash(dim, control, s), goal, lattice_hash(dim, control, goal));
+  }
+  double heur_keyed(const double *s, uint64_t s_key, const double *goal, uint64_t goal_key) const {
+    if (s_key == goal_key) return 0;
     double m = 0;
     for (int i = 0; i < dim; i++) m = std::max(m, std::abs(s[i] - goal[i]));
     return v_max > 0 ? w * m / v_max : w * m;
@@ -302,6 +313,8 @@ class Planner {
 
     std::vector<double> succ((size_t)nU * f), cost((size_t)nU);
     std::vector<int32_t> act((size_t)nU);
+    std::vector<uint64_t> keys((size_t)nU);
+    const uint64_t goal_key = lattice_hash(dim, control, goal);
     int expand_iteration = 0;
     bool reached = false;
     for (;;) {
@@ -311,18 +324,19 @@ class Planner {
       curr->closed = true;
       int32_t n_succ = 0;
       const auto t_s0 = std::chrono::steady_clock::now();
-      if (int rc = successors(curr, succ.data(), cost.data(), act.data(), &n_succ)) return rc;
+      bool have_keys = false;
+      if (int rc = successors(curr, succ.data(), cost.data(), act.data(), keys.data(), &have_keys, &n_succ)) return rc;
       t_succ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_s0).count();
       for (int s = 0; s < n_succ; s++) {
         if (std::isinf(cost[(size_t)s])) continue;  // graph_search.h:81
         const double *sc = &succ[(size_t)s * f];
-        const uint64_t key = lattice_hash(dim, control, sc);
+        const uint64_t key = have_keys ? keys[(size_t)s] : lattice_hash(dim, control, sc);
         NodePtr &child = hm[key];
         if (!child) {
           child = std::make_shared<Node>();
           child->coord.assign(sc, sc + f);
           child->key = key;
-          child->h = eps == 0 ? 0 : heur(sc, goal);
+          child->h = eps == 0 ? 0 : heur_keyed(sc, key, goal, goal_key);
         }
         child->pred_key.push_back(curr->key);
         child->pred_cost.push_back(cost[(size_t)s]);
@@ -359,37 +373,48 @@ class Planner {
 
  private:
   double t_succ = 0, t_provider = 0, t_fill = 0, t_pick = 0;  // MPLX_PLAN_TIMING diagnostics
+  std::vector<int32_t> b_cnt, b_act;  // staging of one batched launch (lists provider)
+  std::vector<double> b_cost, b_state;
+  std::vector<uint64_t> b_hash;
   // One get_succ, possibly served from / filling the batch cache.
-  int successors(const NodePtr &curr, double *succ, double *cost, int32_t *act, int32_t *n_succ) {
+  int successors(const NodePtr &curr, double *succ, double *cost, int32_t *act, uint64_t *keys, bool *have_keys,
+                 int32_t *n_succ) {
     const int f = F();
-    if (batch <= 1 || !batched) {
+    if (batch <= 1 || (!batched && !lists)) {
       last.device_launches++;
       last.pairs += nU;
       if (single) return single(user, curr->coord.data(), succ, cost, act, n_succ);
-      return run_batch({curr}), fetch(curr, succ, cost, act, n_succ);
+      return run_batch({curr}), fetch(curr, succ, cost, act, keys, have_keys, n_succ);
     }
     if (!curr->cached) {
       const auto t_p0 = std::chrono::steady_clock::now();
-      // the popped node plus the best open nodes that have no list yet
+      // the popped node plus the best open nodes that have no list yet: best-first walk of the heap
+      // array (k smallest of a binary heap with an auxiliary heap of positions), O(k log k) whatever
+      // the size of the open list
       std::vector<NodePtr> group{curr};
-      std::vector<OpenList::Item> cand;
-      for (const auto &it : pq.items())
-        if (!it.n->cached) cand.push_back(it);
       const size_t want = (size_t)batch - 1;
-      auto better = [](const OpenList::Item &a, const OpenList::Item &b) {
-        if (a.f != b.f) return a.f < b.f;
-        return std::min(a.n->g, a.n->rhs) < std::min(b.n->g, b.n->rhs);
+      const std::vector<OpenList::Item> &h = pq.items();
+      auto worse = [&](int a, int b) {  // max-heap on "better", so top() is the best position
+        const OpenList::Item &x = h[(size_t)a], &y = h[(size_t)b];
+        if (x.f != y.f) return x.f > y.f;
+        return std::min(x.n->g, x.n->rhs) > std::min(y.n->g, y.n->rhs);
       };
-      if (cand.size() > want) {
-        std::partial_sort(cand.begin(), cand.begin() + (long)want, cand.end(), better);
-        cand.resize(want);
+      std::priority_queue<int, std::vector<int>, decltype(worse)> aux(worse);
+      if (!h.empty()) aux.push(0);
+      size_t visited = 0;
+      while (!aux.empty() && group.size() - 1 < want && visited < 16 * want + 64) {
+        const int i = aux.top();
+        aux.pop();
+        visited++;
+        if (!h[(size_t)i].n->cached) group.push_back(h[(size_t)i].n);
+        if (2 * i + 1 < (int)h.size()) aux.push(2 * i + 1);
+        if (2 * i + 2 < (int)h.size()) aux.push(2 * i + 2);
       }
-      for (const auto &it : cand) group.push_back(it.n);
       t_pick += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p0).count();
       if (int rc = run_batch(group)) return rc;
     }
     (void)f;
-    return fetch(curr, succ, cost, act, n_succ);
+    return fetch(curr, succ, cost, act, keys, have_keys, n_succ);
   }
 
   int run_batch(const std::vector<NodePtr> &group) {
@@ -399,10 +424,39 @@ class Planner {
     for (int64_t k = 0; k < n; k++)
       for (int r = 0; r < f; r++) nodes[(size_t)r * n + k] = group[(size_t)k]->coord[(size_t)r];
     const int64_t slots = n * nU;
-    std::vector<uint8_t> st((size_t)slots);
-    std::vector<double> cs((size_t)slots), state((size_t)f * slots);
     last.device_launches++;
     last.pairs += slots;
+    if (lists) {
+      // compact per-node lists with the device's lattice hashes: no scan of skipped slots, no host hashing
+      b_cnt.resize((size_t)n);
+      b_act.resize((size_t)slots);
+      b_cost.resize((size_t)slots);
+      b_hash.resize((size_t)slots);
+      b_state.resize((size_t)f * slots);
+      const auto t_l0 = std::chrono::steady_clock::now();
+      if (int rc = lists(user, nodes.data(), n, b_cnt.data(), b_act.data(), b_cost.data(), b_hash.data(), b_state.data()))
+        return rc;
+      const auto t_l1 = std::chrono::steady_clock::now();
+      t_provider += std::chrono::duration<double, std::milli>(t_l1 - t_l0).count();
+      for (int64_t k = 0; k < n; k++) {
+        Node &nd = *group[(size_t)k];
+        const int32_t m = b_cnt[(size_t)k];
+        const int64_t o = k * nU;
+        nd.c_succ.resize((size_t)m * f);
+        for (int r = 0; r < f; r++) {
+          const double *row = b_state.data() + (size_t)r * slots + o;
+          for (int32_t j = 0; j < m; j++) nd.c_succ[(size_t)j * f + r] = row[j];
+        }
+        nd.c_cost.assign(b_cost.begin() + o, b_cost.begin() + o + m);
+        nd.c_act.assign(b_act.begin() + o, b_act.begin() + o + m);
+        nd.c_key.assign(b_hash.begin() + o, b_hash.begin() + o + m);
+        nd.cached = true;
+      }
+      t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_l1).count();
+      return 0;
+    }
+    std::vector<uint8_t> st((size_t)slots);
+    std::vector<double> cs((size_t)slots), state((size_t)f * slots);
     const auto t_b0 = std::chrono::steady_clock::now();
     if (int rc = batched(user, nodes.data(), n, st.data(), cs.data(), state.data())) return rc;
     const auto t_b1 = std::chrono::steady_clock::now();
@@ -423,12 +477,16 @@ class Planner {
     return 0;
   }
 
-  int fetch(const NodePtr &n, double *succ, double *cost, int32_t *act, int32_t *n_succ) {
+  int fetch(const NodePtr &n, double *succ, double *cost, int32_t *act, uint64_t *keys, bool *have_keys,
+            int32_t *n_succ) {
     if (!n->cached) return -1;
     std::copy(n->c_succ.begin(), n->c_succ.end(), succ);
     std::copy(n->c_cost.begin(), n->c_cost.end(), cost);
     std::copy(n->c_act.begin(), n->c_act.end(), act);
     *n_succ = (int32_t)n->c_act.size();
+    *have_keys = n->c_key.size() == n->c_act.size() && !n->c_act.empty();
+    if (*have_keys) std::copy(n->c_key.begin(), n->c_key.end(), keys);
+    n->c_key.clear(); n->c_key.shrink_to_fit();
     n->c_succ.clear(); n->c_succ.shrink_to_fit();  // a closed node is never expanded again
     return 0;
   }

@@ -29,6 +29,19 @@ int engine_batch(void *user, const double *nodes, int64_t n, uint8_t *status, do
   return mplx_expand(p->ctx, nodes, n, n, &o);
 }
 
+int engine_lists(void *user, const double *nodes, int64_t n, int32_t *count, int32_t *action, double *cost,
+                 uint64_t *hash, double *state) {
+  mplx_planner *p = (mplx_planner *)user;
+  mplx_succ_lists o{};
+  o.count = count;
+  o.action = action;
+  o.cost = cost;
+  o.hash = hash;
+  o.state = state;
+  o.state_stride = n * p->pl.nU;
+  return mplx_expand_lists(p->ctx, nodes, n, n, &o);
+}
+
 int fail(mplx_planner *p, int code, const char *msg) {
   if (p) p->err = msg;
   return code;
@@ -57,6 +70,7 @@ int mplx_planner_attach_ctx(mplx_planner *p, mplx_ctx *ctx) {
   p->ctx = ctx;
   p->pl.single = engine_single;
   p->pl.batched = engine_batch;
+  p->pl.lists = engine_lists;
   p->pl.user = p;
   return MPLX_OK;
 }
@@ -66,6 +80,7 @@ int mplx_planner_set_provider(mplx_planner *p, mplx_succ_fn single, mplx_batch_f
   p->ctx = nullptr;
   p->pl.single = single;
   p->pl.batched = batched;
+  p->pl.lists = nullptr;
   p->pl.user = user;
   return MPLX_OK;
 }
