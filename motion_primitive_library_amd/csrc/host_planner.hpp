@@ -30,6 +30,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <queue>
 #include <unordered_map>
 #include <vector>
@@ -127,15 +128,14 @@ typedef int (*lists_fn)(void *user, const double *nodes, int64_t n, int32_t *cou
                         uint64_t *hash, double *state /*[4D+2][n*nU]*/);
 
 struct Node;
-typedef std::shared_ptr<Node> NodePtr;
+typedef Node *NodePtr;  // nodes live in Planner::pool (a deque: stable addresses, one allocation per block)
 
 // state_space.h:37-70 (A* fields)
 struct Node {
-  std::vector<double> coord;  // 4D+2
+  double coord[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 4D+2 used
   uint64_t key = 0;
-  std::vector<uint64_t> pred_key;
-  std::vector<int> pred_action;
-  std::vector<double> pred_cost;
+  struct Pred { uint64_t key; double cost; int action; };
+  std::vector<Pred> pred;  // pred_coord / pred_action_cost / pred_action_id of state_space.h:49-53
   double g = kInf, rhs = kInf, h = kInf;
   bool opened = false, closed = false;
   int heap_pos = -1;
@@ -145,6 +145,64 @@ struct Node {
   std::vector<double> c_cost;
   std::vector<int32_t> c_act;
   std::vector<uint64_t> c_key;  // lattice hashes of the cached successors (when the provider supplies them)
+};
+
+// hm_ of the reference's StateSpace (state_space.h:78): lattice hash -> node.  Open addressing with
+// linear probing, keys inline (one cache line per look-up at millions of nodes, where a node-based
+// std::unordered_map takes three).
+class NodeMap {
+ public:
+  NodePtr &operator[](uint64_t key) {
+    if ((n_ + 1) * 10 > cap_ * 6) grow();
+    size_t i = slot(key);
+    while (used_[i]) {
+      if (keys_[i] == key) return vals_[i];
+      i = (i + 1) & (cap_ - 1);
+    }
+    used_[i] = 1;
+    keys_[i] = key;
+    vals_[i] = nullptr;
+    n_++;
+    return vals_[i];
+  }
+  size_t size() const { return n_; }
+  void clear() {
+    std::fill(used_.begin(), used_.end(), 0);
+    n_ = 0;
+  }
+
+ private:
+  size_t slot(uint64_t k) const {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    return (size_t)k & (cap_ - 1);
+  }
+  void grow() {
+    const size_t old_cap = cap_;
+    std::vector<uint64_t> ok;
+    std::vector<NodePtr> ov;
+    std::vector<uint8_t> ou;
+    ok.swap(keys_);
+    ov.swap(vals_);
+    ou.swap(used_);
+    cap_ = old_cap ? old_cap * 2 : 1024;
+    keys_.assign(cap_, 0);
+    vals_.assign(cap_, nullptr);
+    used_.assign(cap_, 0);
+    for (size_t j = 0; j < old_cap; j++)
+      if (ou[j]) {
+        size_t i = slot(ok[j]);
+        while (used_[i]) i = (i + 1) & (cap_ - 1);
+        used_[i] = 1;
+        keys_[i] = ok[j];
+        vals_[i] = ov[j];
+      }
+  }
+  std::vector<uint64_t> keys_;
+  std::vector<NodePtr> vals_;
+  std::vector<uint8_t> used_;
+  size_t cap_ = 0, n_ = 0;
 };
 
 // Mutable binary max-heap on compare_pair (state_space.h:16-34): the top is the
@@ -259,7 +317,8 @@ class Planner {
   lists_fn lists = nullptr;  // preferred over `batched` when set: compact lists + device-side hashes
   void *user = nullptr;
 
-  std::unordered_map<uint64_t, NodePtr> hm;
+  std::deque<Node> pool;
+  NodeMap hm;
   OpenList pq;
   PlanResult last;
 
@@ -294,6 +353,7 @@ class Planner {
     last = PlanResult();
     t_succ = t_provider = t_fill = t_pick = 0;
     hm.clear();
+    pool.clear();
     pq = OpenList();
     if (!single && !batched) return -1;
     int pn[3];
@@ -302,8 +362,9 @@ class Planner {
     const int f = F();
     if (is_goal(start, goal)) { last.ok = true; last.cost = 0; return 0; }
 
-    NodePtr curr = std::make_shared<Node>();
-    curr->coord.assign(start, start + f);
+    pool.emplace_back();
+    NodePtr curr = &pool.back();
+    std::copy(start, start + f, curr->coord);
     curr->key = lattice_hash(dim, control, start);
     curr->g = 0;
     curr->h = eps == 0 ? 0 : heur(start, goal);
@@ -333,14 +394,13 @@ class Planner {
         const uint64_t key = have_keys ? keys[(size_t)s] : lattice_hash(dim, control, sc);
         NodePtr &child = hm[key];
         if (!child) {
-          child = std::make_shared<Node>();
-          child->coord.assign(sc, sc + f);
+          pool.emplace_back();
+          child = &pool.back();
+          std::copy(sc, sc + f, child->coord);
           child->key = key;
           child->h = eps == 0 ? 0 : heur_keyed(sc, key, goal, goal_key);
         }
-        child->pred_key.push_back(curr->key);
-        child->pred_cost.push_back(cost[(size_t)s]);
-        child->pred_action.push_back(act[(size_t)s]);
+        child->pred.push_back({curr->key, cost[(size_t)s], act[(size_t)s]});
         const double tentative = curr->g + cost[(size_t)s];
         if (tentative < child->g) {
           child->g = tentative;
@@ -353,7 +413,7 @@ class Planner {
           }
         }
       }
-      if (is_goal(curr->coord.data(), goal)) { reached = true; break; }
+      if (is_goal(curr->coord, goal)) { reached = true; break; }
       if (max_expand > 0 && expand_iteration >= max_expand) break;
       if (pq.empty()) break;
     }
@@ -362,9 +422,9 @@ class Planner {
               t_succ, t_provider, t_fill, t_pick);
     last.expansions = expand_iteration;
     last.nodes = (int)hm.size();
-    for (const auto &it : hm) {
-      if (it.second->closed) last.closed++;
-      else if (it.second->opened) last.opened++;
+    for (const Node &nd : pool) {
+      if (nd.closed) last.closed++;
+      else if (nd.opened) last.opened++;
     }
     if (!reached) return 0;
     if (recover(curr, start)) { last.ok = true; last.cost = curr->g; }
@@ -383,7 +443,7 @@ class Planner {
     if (batch <= 1 || (!batched && !lists)) {
       last.device_launches++;
       last.pairs += nU;
-      if (single) return single(user, curr->coord.data(), succ, cost, act, n_succ);
+      if (single) return single(user, curr->coord, succ, cost, act, n_succ);
       return run_batch({curr}), fetch(curr, succ, cost, act, keys, have_keys, n_succ);
     }
     if (!curr->cached) {
@@ -498,21 +558,21 @@ class Planner {
     std::vector<std::vector<double>> from;
     std::vector<int32_t> acts;
     bool found = false;
-    while (!curr->pred_key.empty()) {
+    while (!curr->pred.empty()) {
       int min_id = -1;
       double min_rhs = kInf, min_g = kInf;
-      for (size_t i = 0; i < curr->pred_key.size(); i++) {
-        const NodePtr &p = hm[curr->pred_key[i]];
-        const double v = p->g + curr->pred_cost[i];
+      for (size_t i = 0; i < curr->pred.size(); i++) {
+        const NodePtr &p = hm[curr->pred[i].key];
+        const double v = p->g + curr->pred[i].cost;
         if (min_rhs > v) { min_rhs = v; min_g = p->g; min_id = (int)i; }
-        else if (!std::isinf(curr->pred_cost[i]) && min_rhs == v) {
+        else if (!std::isinf(curr->pred[i].cost) && min_rhs == v) {
           if (min_g < p->g) { min_g = p->g; min_id = (int)i; }
         }
       }
       if (min_id < 0) break;
-      const int a = curr->pred_action[(size_t)min_id];
-      curr = hm[curr->pred_key[(size_t)min_id]];
-      from.push_back(curr->coord);
+      const int a = curr->pred[(size_t)min_id].action;
+      curr = hm[curr->pred[(size_t)min_id].key];
+      from.push_back(std::vector<double>(curr->coord, curr->coord + f));
       acts.push_back(a);
       if (curr->key == start_key) { found = true; break; }
     }

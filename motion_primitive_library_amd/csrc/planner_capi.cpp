@@ -167,10 +167,10 @@ int mplx_planner_trajectory(mplx_planner *p, double *nodes, int32_t *actions, in
 int mplx_planner_closed_set(mplx_planner *p, double *pos, int32_t cap, int32_t *n) {
   if (!p || !n) return MPLX_ERR_ARG;
   int32_t m = 0;
-  for (const auto &it : p->pl.hm) {
-    if (!it.second->closed) continue;
+  for (const mplx::host::Node &nd : p->pl.pool) {
+    if (!nd.closed) continue;
     if (pos && m < cap)
-      for (int i = 0; i < p->pl.dim; i++) pos[(size_t)m * p->pl.dim + i] = it.second->coord[(size_t)i];
+      for (int i = 0; i < p->pl.dim; i++) pos[(size_t)m * p->pl.dim + i] = nd.coord[(size_t)i];
     m++;
   }
   *n = m;
