@@ -42,7 +42,7 @@ struct mplx_ctx {
   // per-axis factorisation of the control table (expand_grid_kernel.hip)
   mplx_detail::DevBuf uvals, uidx, blk;
   mplx_detail::DevBuf e_parents, e_action, e_free, e_cost, e_cells, e_count;  // edge re-validation staging
-  mplx_detail::DevBuf post_keys, post_vals;      // node-identity table (post_api.cpp)
+  mplx_detail::DevBuf post_keys;                 // node-identity table (post_api.cpp)
   mplx_detail::DevBuf prep_lut, prep_a, prep_b;  // map preprocessing scratch (map_prep_api.cpp)
   bool blk_ok = false;   // blocked-bit map matches the current map + region
   bool u_factored = false;

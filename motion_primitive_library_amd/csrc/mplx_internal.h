@@ -158,8 +158,8 @@ struct PostArgs {
   double *heur;            // outputs, any may be null
   uint8_t *flags;
   int32_t *canon;
-  uint64_t *keys;          // identity table: cap keys (+1 unused), cap + 1 values; cap a power of two
-  int32_t *vals;
+  struct Slot { uint64_t key; uint32_t val; uint32_t pad; };
+  Slot *keys;              // identity table: cap + 1 slots, cap a power of two; key = ~0 empty, val = smallest index
   uint64_t cap;
 };
 hipError_t launch_post_lists(int dim, const PostArgs &args, hipStream_t s);

@@ -42,13 +42,12 @@ extern "C" int mplx_post_lists_device(mplx_ctx *c, const mplx_succ_lists *d_list
   a.canon = d_out->canon;
   if (d_out->canon) {
     uint64_t cap = 1024;
-    while (cap < 2 * (uint64_t)n_nodes * (uint64_t)c->nU) cap <<= 1;  // load factor <= 0.5 whatever is emitted
-    if (int rc = ensure(c, c->post_keys, (cap + 1) * 8)) return rc;
-    if (int rc = ensure(c, c->post_vals, (cap + 1) * 4)) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->post_keys.p, 0xff, (cap + 1) * 8, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->post_vals.p, 0x7f, (cap + 1) * 4, c->stream));
-    a.keys = (uint64_t *)c->post_keys.p;
-    a.vals = (int32_t *)c->post_vals.p;
+    while (cap < (uint64_t)n_nodes * (uint64_t)c->nU) cap <<= 1;  // >= the emitted successors whatever the frontier
+    if (cap < 2 * (uint64_t)n_nodes * (uint64_t)c->nU && cap < (1ull << 27)) cap <<= 1;
+    if (int rc = ensure(c, c->post_keys, (cap + 1) * sizeof(mplx::PostArgs::Slot))) return rc;
+    // all bytes 0xff: key = ~0 (empty), val = 0xffffffff (above every list index, unsigned atomicMin)
+    HIP_TRY(c, hipMemsetAsync(c->post_keys.p, 0xff, (cap + 1) * sizeof(mplx::PostArgs::Slot), c->stream));
+    a.keys = (mplx::PostArgs::Slot *)c->post_keys.p;
     a.cap = cap;
   }
   HIP_TRY(c, mplx::launch_post_lists(D, a, c->stream));

@@ -16,7 +16,8 @@
 //                   as edges.  Deterministic: the canonical duplicate is the one
 //                   with the smallest list index.
 // The identity pass is an open-addressing table in HBM keyed by the 64-bit lattice
-// hash (linear probing, 64-bit CAS for the key, 32-bit atomicMin for the index).
+// hash (linear probing, 64-bit CAS for the key, 32-bit atomicMin for the index;
+// key and index share one 16-byte slot, so each successor touches one line per pass).
 #include "mplx_internal.h"
 
 namespace mplx {
@@ -71,16 +72,16 @@ __global__ __launch_bounds__(256) void post_lists_kernel(const PostArgs A) {
     A.flags[g] = (uint8_t)((goaled ? 1 : 0) | (is_goal_state ? 2 : 0));
   }
   if (A.keys) {
-    if (h == kEmpty) {  // the one hash the key array cannot hold: a dedicated slot past the table
-      atomicMin(&A.vals[A.cap], (int)g);
+    if (h == kEmpty) {  // the one hash the key field cannot hold: a dedicated slot past the table
+      atomicMin(&A.keys[A.cap].val, (uint32_t)g);
     } else {
       uint64_t s = mix(h) & (A.cap - 1);
       while (true) {
-        const uint64_t old = atomicCAS((unsigned long long *)&A.keys[s], (unsigned long long)kEmpty, (unsigned long long)h);
+        const uint64_t old = atomicCAS((unsigned long long *)&A.keys[s].key, (unsigned long long)kEmpty, (unsigned long long)h);
         if (old == kEmpty || old == h) break;
         s = (s + 1) & (A.cap - 1);
       }
-      atomicMin(&A.vals[s], (int)g);
+      atomicMin(&A.keys[s].val, (uint32_t)g);
     }
   }
 }
@@ -95,9 +96,9 @@ __global__ __launch_bounds__(256) void post_canon_kernel(const PostArgs A) {
   uint64_t s = A.cap;
   if (h != kEmpty) {
     s = mix(h) & (A.cap - 1);
-    while (A.keys[s] != h) s = (s + 1) & (A.cap - 1);
+    while (A.keys[s].key != h) s = (s + 1) & (A.cap - 1);
   }
-  const int c = A.vals[s];
+  const int c = (int)A.keys[s].val;
   A.canon[g] = c;
   if (A.flags && c == (int)g) A.flags[g] |= 4;  // first occurrence of this lattice state in the batch
 }
