@@ -489,16 +489,25 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         const int n = (f0 & f1 & 2) ? 0 : (n0 > n1 ? n0 : n1);
         const bool mine = act && (n ? ((sub >> n) & 1ull) != 0ull : pass == 0);
         const int64_t idx = node * A.l_nstride + e;
-        if (mine && !(A.dbg & 2)) {
+        // Line padding (off unless MPLX_LINE_PAD is set): a list that ends inside a 128-byte line leaves a
+        // partial-line write in every output row.  In a store-only kernel those are expensive (C4's lists:
+        // 3.5-4 TB/s with them, 6+ TB/s when every list ends on a line, profiles/micro/write_pattern.hip), so
+        // the lanes just past the end of the list can be made to complete the lines (unspecified values,
+        // inside the node's own region).  In THIS kernel it changed nothing (0.793 vs 0.799 ms on C4): the
+        // stores are not limited by the memory system but by waves stalling at issue during their store
+        // bursts, so it stays off and the lists stay exactly count[k] entries long.
+        const bool pad16 = A.l_pad && !act && pass == 0 && e < ((E + 15) & ~15);  // 8-byte entries
+        const bool pad32 = A.l_pad && !act && pass == 0 && e < ((E + 31) & ~31);  // 4-byte entries
+        if ((mine || pad32) && !(A.dbg & 2)) {
           uint64_t h = s_hp[px];
           const int4 q = *(const int4 *)(s_eq + en[D - 1] * 4);
           fold(h, q.x);
           if (K >= 2) fold(h, q.y);
           if (K >= 3) fold(h, q.z);
           if (K >= 4) fold(h, q.w);
-          if (A.l_action) A.l_action[idx] = ci;
-          if (A.l_hash) A.l_hash[idx] = h;
-          if (A.l_state) {
+          if (A.l_action) A.l_action[idx] = mine ? ci : -1;
+          if (A.l_hash && (mine || pad16)) A.l_hash[idx] = h;
+          if (A.l_state && (mine || pad16)) {
             double *o = A.l_state + idx;
             const int64_t ss = A.l_stride;
 #pragma unroll
@@ -606,13 +615,13 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
           }
         }
         // ---- cost (env_map.h:162-169) and iteration count
-        if (mine && !(A.dbg & 4)) {
+        if ((mine || pad32) && !(A.dbg & 4)) {
           const bool blocked = fb >= 0;
           double J = 0;
 #pragma unroll
           for (int i = 0; i < D; i++) J += s_eJ[en[i]];
           const double cost = blocked ? INFINITY : 0.0 + (J + A.w * A.dt);
-          if (A.l_cost) A.l_cost[idx] = cost;
+          if (A.l_cost && (mine || pad16)) A.l_cost[idx] = cost;
           if (A.l_iters) A.l_iters[idx] = blocked ? fb + 1 : cntl;
         }
       }

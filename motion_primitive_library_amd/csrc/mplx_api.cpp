@@ -460,6 +460,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.l_count = o->count; a.l_action = o->action; a.l_cost = o->cost; a.l_hash = o->hash;
     a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
     a.l_nstride = o->node_stride ? o->node_stride : c->nU;
+    a.l_pad = (a.l_nstride % 32 == 0 && getenv("MPLX_LINE_PAD")) ? 1 : 0;  // tuning only, see expand_grid_kernel.hip
     HIP_TRY(c, mplx::launch_expand_grid(c->dim, c->prm.control, a, c->stream));
     c->last_route = MPLX_ROUTE_GRID;
     return MPLX_OK;

@@ -74,6 +74,7 @@ struct TileArgs {
   int64_t l_stride;
   int32_t *l_iters;
   int64_t l_nstride;  // entries reserved per node (>= nU)
+  int32_t l_pad;      // 1: complete the last 128-byte line of every list row (node stride is a multiple of 32)
 };
 
 size_t tile_lds_bytes(int tile_pairs, int npb, int wl_cap, int n_max, int n_fields, int u_doubles,
@@ -116,6 +117,7 @@ struct GridArgs {
   int64_t l_stride;
   int32_t *l_iters;
   int64_t l_nstride;  // entries reserved per node (>= nU)
+  int32_t l_pad;      // 1: complete the last 128-byte line of every list row (node stride is a multiple of 32)
 };
 size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap);
 int grid_waves_per_block();
@@ -191,6 +193,7 @@ struct CompactArgs {
   int64_t l_stride;
   int32_t *l_iters;
   int64_t l_nstride;  // entries reserved per node (>= nU)
+  int32_t l_pad;      // 1: complete the last 128-byte line of every list row (node stride is a multiple of 32)
 };
 hipError_t launch_compact_lists(const CompactArgs &args, hipStream_t stream);
 

@@ -141,8 +141,9 @@ class Lists:
 
     def __init__(self, env, n_nodes, nU, want_state=True, want_iters=False, want_hash=True, stride=None):
         self.n_nodes, self.nU = int(n_nodes), int(nU)
-        # entries reserved per node: a multiple of 16 keeps every 64-successor store on 128-byte lines
-        self.stride = (self.nU + 15) & ~15 if stride is None else int(stride)
+        # entries reserved per node: a multiple of 32 keeps every node's rows on 128-byte lines (and lets the
+        # kernel complete the last line of each list instead of leaving a partial-line store)
+        self.stride = (self.nU + 31) & ~31 if stride is None else int(stride)
         self.n_slots = self.n_nodes * self.stride
         self.n_fields = env.n_fields
         n = max(self.n_slots, 1)

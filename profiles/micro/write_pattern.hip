@@ -16,12 +16,12 @@ __global__ __launch_bounds__(256) void pattern(double *rows, int *act, long stri
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long wstride = (long)gridDim.x * 4;
-  const int G = (mode >= 5 && mode <= 7) ? (mode - 3) : 1;  // modes 5, 6, 7: a wave takes 2, 3, 4 consecutive nodes at a time
+  const int G = (mode >= 5 && mode <= 7) ? (mode - 3) : (mode == 9 ? 2 : mode == 10 ? 4 : mode == 11 ? 8 : 1);  // modes 5, 6, 7: a wave takes 2, 3, 4 consecutive nodes at a time
   for (long it = wave; it * G < n_nodes; it += wstride)
   for (int gi = 0; gi < G; gi++) {
     const long node = it * G + gi;
     if (node >= n_nodes) break;
-    const long base = mode == 1 ? offs[node] : node * (long)S;
+    const long base = (mode == 1 || mode >= 9) ? offs[node] : node * (long)S;
     for (int e0 = 0; e0 < count; e0 += 64) {
       const int e = e0 + lane;
       if (e < count) {
@@ -69,7 +69,8 @@ __global__ void fill(double *p, long n) {
 }
 
 int main(int argc, char **argv) {
-  const int n_nodes = 65536, S = 736, count = 311;
+  const int n_nodes = 65536, S = 736;
+  const int count = argc > 3 ? atoi(argv[3]) : 311;
   const long pad = argc > 1 ? atol(argv[1]) : 0;
   const int wgs_per_cu = argc > 2 ? atoi(argv[2]) : 4;  // 4 waves each  // extra doubles between rows (de-aligns the 2^24-byte row stride)
   const long stride = (long)n_nodes * S + pad;
@@ -86,7 +87,7 @@ int main(int argc, char **argv) {
   hipEvent_t a, b;
   (void)hipEventCreate(&a);
   (void)hipEventCreate(&b);
-  for (int mode = 0; mode < 9; mode++) {
+  for (int mode = 0; mode < 12; mode++) {
     const int cnt = mode == 3 ? S : count;
     const double bytes = (double)n_nodes * cnt * (16 * 8 + 4);
     float best = 1e9;
