@@ -23,6 +23,16 @@
 //     PlannerBase::plan calls the virtual ENV_->is_free(start.pos) first
 //     (planner_base.h:283), which marks them stale.  Call notify_map_changed()
 //     after editing the MapUtil in place outside of these paths.
+// Speculative batching (set_batch(n), n > 1).  Astar asks for one node at a time
+// (graph_search.h:75), which costs one launch + round trip per expansion.  get_succ
+// is a pure function of the node, so the adapter may compute lists ahead of time: on
+// a miss it expands the requested node TOGETHER with the most promising successors
+// it has handed out and that have not been asked for yet (ranked by g + h like the
+// search's own open list, with g accumulated along the edges it returned and h =
+// get_heur), in one mplx_expand_lists call, and serves later requests from that
+// cache.  The lists returned are identical with and without batching; only the
+// number of launches changes.  The cache is dropped whenever parameters, controls or
+// maps change, and at the start of every plan().
 // Errors never throw: a failed device call prints the engine's message and
 // returns an empty successor list (the reference's own error convention is
 // printf + sentinel, graph_search.h:149-161).  There is no CPU fallback.
@@ -35,6 +45,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <queue>
+#include <unordered_map>
 #include <vector>
 
 #include "mplx.h"
@@ -56,6 +68,9 @@ class env_map_hip : public env_map<Dim> {
   env_map_hip &operator=(const env_map_hip &) = delete;
 
   bool ok() const { return ctx_ != nullptr; }
+  /// Nodes per device launch (1 = one launch per get_succ, the default).
+  void set_batch(int n) { batch_ = n < 1 ? 1 : n; drop_cache(); }
+  int launches() const { return launches_; }
   /// Re-upload the map / potential / region before the next expansion.
   void notify_map_changed() { maps_stale_ = true; }
 
@@ -83,13 +98,48 @@ class env_map_hip : public env_map<Dim> {
     const int nU = (int)this->U_.size();
     double node[F];
     pack(curr, node);
-    buf_succ_.resize((size_t)nU * F);
-    buf_cost_.resize((size_t)nU);
-    buf_act_.resize((size_t)nU);
     int32_t n = 0;
-    if (mplx_get_succ(ctx_, node, buf_succ_.data(), buf_cost_.data(), buf_act_.data(), &n) != MPLX_OK) {
-      printf(ANSI_COLOR_RED "[env_map_hip] get_succ: %s\n" ANSI_COLOR_RESET, mplx_last_error(ctx_));
-      return;
+    if (batch_ > 1) {
+      const uint64_t key = lattice_hash(curr.control, node);
+      auto it = cache_.find(key);
+      if (it == cache_.end()) {
+        if (!expand_group(curr.control, key, node)) return;
+        it = cache_.find(key);
+      }
+      Cached &c = it->second;
+      n = (int32_t)c.act.size();
+      buf_succ_.swap(c.succ);
+      buf_cost_.swap(c.cost);
+      buf_act_.swap(c.act);
+      // its successors become candidates for the next speculative launch
+      const double g = c.g;
+      for (int m = 0; m < n; m++) {
+        if (std::isinf(buf_cost_[(size_t)m])) continue;
+        const uint64_t ck = c.keys[(size_t)m];
+        const double cg = g + buf_cost_[(size_t)m];
+        auto gi = g_est_.find(ck);
+        if (gi != g_est_.end() && gi->second <= cg) continue;
+        g_est_[ck] = cg;
+        Waypoint<Dim> tn(curr.control);
+        unpack(&buf_succ_[(size_t)m * F], tn);
+        Cand cand;
+        cand.f = cg + this->get_heur(tn);
+        cand.g = cg;
+        cand.key = ck;
+        std::memcpy(cand.row, &buf_succ_[(size_t)m * F], sizeof(double) * F);
+        shadow_.push(cand);
+      }
+      cache_.erase(it);
+      asked_[key] = true;
+    } else {
+      buf_succ_.resize((size_t)nU * F);
+      buf_cost_.resize((size_t)nU);
+      buf_act_.resize((size_t)nU);
+      launches_++;
+      if (mplx_get_succ(ctx_, node, buf_succ_.data(), buf_cost_.data(), buf_act_.data(), &n) != MPLX_OK) {
+        printf(ANSI_COLOR_RED "[env_map_hip] get_succ: %s\n" ANSI_COLOR_RESET, mplx_last_error(ctx_));
+        return;
+      }
     }
     for (int m = 0; m < n; m++) {
       Waypoint<Dim> tn(curr.control);
@@ -161,6 +211,96 @@ class env_map_hip : public env_map<Dim> {
   }
 
  private:
+  struct Cached {
+    std::vector<double> succ, cost;  // succ: [n][4D+2]
+    std::vector<int32_t> act;
+    std::vector<uint64_t> keys;
+    double g = 0;
+  };
+  struct Cand {
+    double f, g;
+    uint64_t key;
+    double row[4 * Dim + 2];
+    bool operator<(const Cand &o) const { return f > o.f; }  // smallest f on top
+  };
+
+  // the engine's lattice hash (waypoint.h:93-125 with the classic hash_combine), for cache keys only
+  static uint64_t lattice_hash(int control, const double *w) {
+    uint64_t h = 0;
+    auto fold = [&h](int id) { h ^= (uint64_t)(int64_t)id + 0x9e3779b9ULL + (h << 6) + (h >> 2); };
+    for (int i = 0; i < Dim; i++) {
+      if (control & 1) fold((int)std::round(w[0 * Dim + i] / 0.01));
+      if (control & 2) fold((int)std::round(w[1 * Dim + i] / 0.1));
+      if (control & 4) fold((int)std::round(w[2 * Dim + i] / 0.1));
+      if (control & 8) fold((int)std::round(w[3 * Dim + i] / 0.1));
+    }
+    if (control & 16) fold((int)std::round(w[4 * Dim] / 0.1));
+    return h;
+  }
+
+  void drop_cache() const {
+    cache_.clear();
+    g_est_.clear();
+    asked_.clear();
+    shadow_ = std::priority_queue<Cand>();
+  }
+
+  // one launch: the requested node plus the best candidates that have no list yet
+  bool expand_group(int control, uint64_t key, const double *node) const {
+    constexpr int F = 4 * Dim + 2;
+    const int nU = (int)this->U_.size();
+    std::vector<uint64_t> gk{key};
+    std::vector<double> rows(node, node + F), gg;
+    {
+      auto gi = g_est_.find(key);
+      gg.push_back(gi == g_est_.end() ? 0.0 : gi->second);
+    }
+    while ((int)gk.size() < batch_ && !shadow_.empty()) {
+      const Cand c = shadow_.top();
+      shadow_.pop();
+      auto gi = g_est_.find(c.key);
+      if (gi != g_est_.end() && gi->second < c.g) continue;             // superseded by a better path
+      if (c.key == key || asked_.count(c.key) || cache_.count(c.key)) continue;  // already served / cached
+      gk.push_back(c.key);
+      gg.push_back(c.g);
+      rows.insert(rows.end(), c.row, c.row + F);
+    }
+    const int64_t n = (int64_t)gk.size(), slots = n * nU;
+    nodes_fm_.resize((size_t)F * n);
+    for (int64_t k = 0; k < n; k++)
+      for (int f = 0; f < F; f++) nodes_fm_[(size_t)f * n + k] = rows[(size_t)k * F + f];
+    l_count_.resize((size_t)n);
+    l_act_.resize((size_t)slots);
+    l_cost_.resize((size_t)slots);
+    l_hash_.resize((size_t)slots);
+    l_state_.resize((size_t)F * slots);
+    mplx_succ_lists o{};
+    o.count = l_count_.data();
+    o.action = l_act_.data();
+    o.cost = l_cost_.data();
+    o.hash = l_hash_.data();
+    o.state = l_state_.data();
+    o.state_stride = slots;
+    launches_++;
+    if (mplx_expand_lists(ctx_, nodes_fm_.data(), n, n, &o) != MPLX_OK) return complain();
+    for (int64_t k = 0; k < n; k++) {
+      Cached &c = cache_[gk[(size_t)k]];
+      const int32_t m = l_count_[(size_t)k];
+      const int64_t base = k * nU;
+      c.g = gg[(size_t)k];
+      c.succ.resize((size_t)m * F);
+      for (int f = 0; f < F; f++) {
+        const double *row = l_state_.data() + (size_t)f * slots + base;
+        for (int32_t j = 0; j < m; j++) c.succ[(size_t)j * F + f] = row[j];
+      }
+      c.cost.assign(l_cost_.begin() + base, l_cost_.begin() + base + m);
+      c.act.assign(l_act_.begin() + base, l_act_.begin() + base + m);
+      c.keys.assign(l_hash_.begin() + base, l_hash_.begin() + base + m);
+    }
+    (void)control;
+    return true;
+  }
+
   static void pack(const Waypoint<Dim> &w, double *row) {
     for (int i = 0; i < Dim; i++) {
       row[0 * Dim + i] = w.pos(i);
@@ -184,6 +324,7 @@ class env_map_hip : public env_map<Dim> {
 
   bool sync_maps() const {
     if (maps_stale_) {
+      drop_cache();
       const Veci<Dim> dim = this->map_util_->getDim();
       const Vecf<Dim> ori = this->map_util_->getOrigin();
       const Tmap cells = this->map_util_->getMap();
@@ -219,6 +360,7 @@ class env_map_hip : public env_map<Dim> {
     p.potential_weight = this->potential_weight_;
     p.gradient_weight = this->gradient_weight_;
     if (!have_params_ || std::memcmp(&p, &params_, sizeof p) != 0) {
+      drop_cache();
       if (mplx_set_params(ctx_, &p) != MPLX_OK) return complain();
       params_ = p;
       have_params_ = true;
@@ -229,6 +371,7 @@ class env_map_hip : public env_map<Dim> {
     for (int i = 0; i < nU; i++)
       for (int k = 0; k < udim; k++) flatU_[(size_t)i * udim + k] = this->U_[i](k);
     if (flatU_ != sentU_) {
+      drop_cache();
       if (nU == 0 || mplx_set_controls(ctx_, flatU_.data(), nU, udim) != MPLX_OK) return complain();
       sentU_ = flatU_;
     }
@@ -244,6 +387,16 @@ class env_map_hip : public env_map<Dim> {
   mutable mplx_params params_{};
   mutable std::vector<double> flatU_, sentU_, buf_succ_, buf_cost_;
   mutable std::vector<int32_t> buf_act_;
+  // speculative batching
+  int batch_ = 1;
+  mutable int launches_ = 0;
+  mutable std::unordered_map<uint64_t, Cached> cache_;
+  mutable std::unordered_map<uint64_t, double> g_est_;
+  mutable std::unordered_map<uint64_t, bool> asked_;
+  mutable std::priority_queue<Cand> shadow_;
+  mutable std::vector<double> nodes_fm_, l_cost_, l_state_;
+  mutable std::vector<int32_t> l_count_, l_act_;
+  mutable std::vector<uint64_t> l_hash_;
 };
 
 /// MapPlanner whose ENV_ expands successors on the GPU; everything else is the
@@ -252,12 +405,21 @@ class env_map_hip : public env_map<Dim> {
 template <int Dim>
 class GpuMapPlanner : public MapPlanner<Dim> {
  public:
-  explicit GpuMapPlanner(bool verbose = false, int device = 0) : MapPlanner<Dim>(verbose), device_(device) {}
+  explicit GpuMapPlanner(bool verbose = false, int device = 0, int batch = 1)
+      : MapPlanner<Dim>(verbose), device_(device), batch_(batch) {}
 
   void setMapUtil(const std::shared_ptr<MapUtil<Dim>> &map_util) override {
-    this->ENV_.reset(new env_map_hip<Dim>(map_util, device_));
+    env_map_hip<Dim> *env = new env_map_hip<Dim>(map_util, device_);
+    env->set_batch(batch_);
+    this->ENV_.reset(env);
     this->map_util_ = map_util;
   }
+  /// Nodes per device launch of the speculative batching (see the file header); 1 = off.
+  void setBatch(int n) {
+    batch_ = n;
+    if (this->ENV_) static_cast<env_map_hip<Dim> *>(this->ENV_.get())->set_batch(n);
+  }
+  int deviceLaunches() const { return this->ENV_ ? static_cast<env_map_hip<Dim> *>(this->ENV_.get())->launches() : 0; }
 
   /// Shadows MapPlanner::updatePotentialMap (not virtual in the reference): same result, the
   /// dilation runs on the GPU (mplx_update_potential_map).
@@ -278,6 +440,7 @@ class GpuMapPlanner : public MapPlanner<Dim> {
 
  private:
   int device_;
+  int batch_ = 1;
 };
 
 typedef GpuMapPlanner<2> GpuOccMapPlanner;

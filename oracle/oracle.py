@@ -260,13 +260,13 @@ def ref_plan(env, start_row, goal_row, use_gpu=False, epsilon=1.0, reps=1):
     g = np.ascontiguousarray(goal_row, dtype=np.float64)
     out = RefPlanOut()
     ce = env._c()
-    rc = _LIBS["ref_planner"].mpl_ref_plan(C.byref(ce), s.ctypes.data, g.ctypes.data, int(bool(use_gpu)),
+    rc = _LIBS["ref_planner"].mpl_ref_plan(C.byref(ce), s.ctypes.data, g.ctypes.data, int(use_gpu),  # > 1: batch size
                                             float(epsilon), int(reps), C.byref(out))
     if rc != 0:
         raise RuntimeError("mpl_ref_plan failed: %d" % rc)
     return {"ok": bool(out.ok), "closed": out.closed, "opened": out.opened, "expansions": out.expansions,
             "segments": out.segments, "cost": out.cost, "total_time": out.total_time, "J": list(out.J),
-            "wall_ms": out.wall_ms}
+            "wall_ms": out.wall_ms, "device_launches": out.hm_size}
 
 
 # ---- map preprocessing: restatement, and the reference's own MapPlanner via the shim

@@ -44,7 +44,7 @@ int run_plan(const mpl_oracle_env *e, const double *start_row, const double *goa
   mu->setMap(ori, dim, MPL::Tmap(e->map, e->map + n), e->res);
 
   std::unique_ptr<MPL::MapPlanner<D>> planner;
-  if (use_gpu) planner.reset(new MPL::GpuMapPlanner<D>(false, 0));
+  if (use_gpu) planner.reset(new MPL::GpuMapPlanner<D>(false, 0, use_gpu > 1 ? use_gpu : 1));  // use_gpu > 1: speculative batch size
   else planner.reset(new MPL::MapPlanner<D>(false));
   planner->setMapUtil(mu);
   planner->setVmax(e->v_max);
@@ -93,7 +93,7 @@ int run_plan(const mpl_oracle_env *e, const double *start_row, const double *goa
   out->J[2] = traj.J(Control::JRK);
   out->J[3] = traj.J(Control::SNP);
   out->cost = planner->getTrajCost();
-  out->hm_size = 0;
+  out->hm_size = use_gpu ? static_cast<MPL::GpuMapPlanner<D> *>(planner.get())->deviceLaunches() : 0;  // device launches
   return 0;
 }
 

@@ -67,6 +67,14 @@ if not args.skip_adapter:
     out["reference_planner_gpu_get_succ"] = {"wall_ms": gpu["wall_ms"], "ok": gpu["ok"], "cost": gpu["cost"],
                                              "expansions": gpu["expansions"]}
     assert gpu["ok"] == cpu["ok"] and gpu["cost"] == cpu["cost"] and gpu["expansions"] == cpu["expansions"]
+    out["reference_planner_gpu_speculative"] = []
+    for b in (16, 64, 256):
+        r = O.ref_plan(oenv, start.to_row(), goal.to_row(), use_gpu=b, epsilon=args.eps, reps=1)
+        out["reference_planner_gpu_speculative"].append({"batch": b, "wall_ms": r["wall_ms"], "launches": r["device_launches"],
+                                                         "cost": r["cost"], "expansions": r["expansions"]})
+        print("reference planner + adapter, speculative batch %d: %.1f ms, %d launches" % (b, r["wall_ms"], r["device_launches"]),
+              file=sys.stderr)
+        assert r["ok"] == cpu["ok"] and r["cost"] == cpu["cost"] and r["expansions"] == cpu["expansions"]
 
 out["engine_batched"] = []
 for batch in (1, 16, 64, 256, 1024):

@@ -66,3 +66,11 @@ def test_c1_reference_planner_with_dropin_adapter(engine):
     for k in ("ok", "closed", "opened", "expansions", "segments", "cost", "total_time", "J"):
         assert gpu[k] == cpu[k], k
     assert gpu["closed"] == 615 and gpu["total_time"] == 35.0 and gpu["J"][:2] == [36.75, 1.5]
+    assert gpu["device_launches"] == 2 * 615  # reps=2, one launch per expansion
+    # the adapter's speculative batching: same search, far fewer launches
+    for batch in (8, 64):
+        b = O.ref_plan(oenv, start, goal, use_gpu=batch, reps=1)
+        print("  batch %d: %.2f ms, %d launches" % (batch, b["wall_ms"], b["device_launches"]))
+        for k in ("ok", "closed", "opened", "expansions", "segments", "cost", "total_time", "J"):
+            assert b[k] == cpu[k], (batch, k)
+        assert b["device_launches"] < 615 // 2
