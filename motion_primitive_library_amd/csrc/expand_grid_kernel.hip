@@ -150,6 +150,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   int *s_eflag = (int *)(wb + L.w_eflag);
   int *s_fp = (int *)(wb + L.w_fp);
   unsigned int *s_box = (unsigned int *)(wb + L.w_box);
+  int *s_rb = (int *)(wb + L.w_box);  // [EN][2] reach ranges of the entries (live between T1 and the box query)
   double *s_trow = (double *)(wb + L.w_box);  // [RM][tts] sample times, live only while the rows are built
   int *s_misc = (int *)(wb + L.w_misc);
   unsigned char *s_rowmap = wb + L.w_rowmap;
@@ -225,6 +226,22 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         s_eq[lane * 4 + 3] = (K >= 4) ? quantise(nj_, 0.1, A.R01) : 0;
         s_eJ[lane] = u * u * T;  // Primitive::J of a forward primitive (see expand_kernel.hip)
         flag = (valid ? 1 : 0) | ((p == np_) ? 2 : 0) | (n << 8);
+        if (A.sat != nullptr && valid) {
+          // range of p(t) over [0, T] of this entry, as cells with one cell of slack on both sides
+          // (free-box shortcut below); K = 1, 2: exact extrema; K = 3: |p - p0| <= max_vel * T
+          double pmin = p < np_ ? p : np_, pmax = p < np_ ? np_ : p;
+          if (K == 2 && u != 0) {
+            const double ts = -v / u;
+            if (ts > 0 && ts < T) {
+              const double pe = q.template pos<false>(ts);
+              pmin = pe < pmin ? pe : pmin;
+              pmax = pe > pmax ? pe : pmax;
+            }
+          }
+          if (K >= 3) { pmin = p - mv * T; pmax = p + mv * T; }
+          s_rb[lane * 2 + 0] = (int)floor((pmin - org[ax]) / A.res) - 1;
+          s_rb[lane * 2 + 1] = (int)floor((pmax - org[ax]) / A.res) + 1;
+        }
         if (jv == 0) {
           // the node's own cell on this axis (map_util.h:103-108); the codes are offsets from it.
           // Every negative cell is outside the map alike, so -1 stands for all of them.
@@ -301,6 +318,40 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       if (K >= 3) fold(hcur, q.z);
       if (K >= 4) fold(hcur, q.w);
     }
+    // ---- free-box shortcut: the summed-area table of the blocked-bit map answers "is the whole box the
+    // node can reach in T free?" with 2^D look-ups.  If it is, every sample of every valid pair is free and
+    // rows, box staging and the sample loops are skipped for this node.  The loads are issued here and
+    // consumed after phase A.
+    unsigned int sat_v = 0;
+    bool sat_inside = false;
+    if (A.sat != nullptr) {
+      int rlo[3] = {0, 0, 0}, rhi[3] = {0, 0, 0};
+      bool inside = true;
+#pragma unroll
+      for (int i = 0; i < D; i++) {
+        int lo_ = 0x7fffffff, hi_ = -0x7fffffff;
+        const int nv = s_misc[M_NV + i];
+        const unsigned char *vl = (const unsigned char *)(s_misc + M_VL) + i * 16;
+        for (int j = 0; j < nv; j++) {  // uniform loop, broadcast LDS reads
+          const int en_ = i * ndp + (int)vl[j];
+          const int a = s_rb[en_ * 2 + 0], b = s_rb[en_ * 2 + 1];
+          lo_ = a < lo_ ? a : lo_;
+          hi_ = b > hi_ ? b : hi_;
+        }
+        rlo[i] = lo_;
+        rhi[i] = hi_;
+        inside = inside && nv > 0 && lo_ >= 0 && hi_ < dims[i];
+      }
+      sat_inside = inside;
+      if (inside && lane < (1 << D)) {
+        // corner `lane` of the inclusion-exclusion sum over [rlo, rhi] (table has a zero border at index 0)
+        const int cx = (lane & 1) ? rhi[0] + 1 : rlo[0];
+        const int cy = (lane & 2) ? rhi[1] + 1 : rlo[1];
+        const int cz = (D == 3) ? ((lane & 4) ? rhi[2] + 1 : rlo[2]) : 1;  // 2D: the one real plane sits above the border plane
+        const int64_t idx = cx + (int64_t)(dims[0] + 1) * (cy + (int64_t)(dims[1] + 1) * cz);
+        sat_v = A.sat[idx];
+      }
+    }
     const double node_t = s_node[4 * D + 1];
     int base_c[3];
 #pragma unroll
@@ -341,12 +392,23 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
     unsigned long long nm = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(s_misc[M_NMASK]) |
                             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(s_misc[M_NMASK + 1]) << 32);
     if (A.dbg & 1) nm = 0;  // timing ablation: no sampling
+    bool safe = false;  // the node's whole reach box is free (uniform)
+    if (A.sat != nullptr) {
+      // inclusion-exclusion: + for corners with an even number of low coordinates
+      unsigned int term = (lane < (1 << D)) ? sat_v : 0u;  // modulo 2^32 throughout: the box sum itself is small
+      if ((D - __popc((unsigned)lane & ((1u << D) - 1u))) & 1) term = 0u - term;
+#pragma unroll
+      for (int d = 1; d < (1 << D); d <<= 1) term += (unsigned int)__shfl_xor((int)term, d, 64);
+      safe = sat_inside && __builtin_amdgcn_readfirstlane((int)term) == 0;
+    }
 
     // ---- rounds of up to RM sample counts
     for (int pass = 0; pass == 0 || nm != 0ull; pass++) {
       // this round's sample counts and their rows
       unsigned long long sub = 0;
-      {
+      if (safe) {
+        sub = ~0ull;  // nothing to sample: every successor is handled in this one pass
+      } else {
         unsigned long long t = nm;
         for (int r = 0; r < RM && t; r++) {
           sub |= t & (~t + 1ull);
@@ -356,7 +418,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       nm &= ~sub;
       wave_sync();
       s_rowmap[lane] = ((sub >> lane) & 1ull) ? (unsigned char)__popcll(sub & ((1ull << lane) - 1ull)) : 0xff;
-      {
+      if (!safe) {
         // the accumulated sample times of this pass' rows: one global round trip for all of them
         const int n_sub = __popcll(sub);
         for (int i = lane; i < n_sub * tts; i += 64) {
@@ -374,7 +436,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       bool ovf = false;
       {
         int row = 0;
-        for (unsigned long long t = sub; t; t &= t - 1ull, row++) {
+        for (unsigned long long t = safe ? 0ull : sub; t; t &= t - 1ull, row++) {
           const int nn = __ffsll((long long)t) - 1;
           const int cn = (int)s_tc[nn];
           const float inv_cn = 1.0f / (float)cn;
@@ -434,8 +496,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       const int WX = (nb[0] + 31) >> 5;
       const int n_rows = nb[1] * nb[2];
       const bool direct = (__ballot(ovf) != 0ull) || (A.dbg & 64);  // dbg 64: test hook, force direct evaluation
-      const bool fits = !direct && have_box && n_rows * WX <= A.boxcap;
-      if (fits && sub) {
+      const bool fits = !safe && !direct && have_box && n_rows * WX <= A.boxcap;
+      if (fits && sub) {  // (never for a safe node)
         const float inv_ny = 1.0f / (float)nb[1];
         const int ax0 = base_c[0] + lo[0] - half;
         constexpr int SU = 4;  // rows per lane with their loads in flight together
@@ -489,13 +551,13 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         const int n = (f0 & f1 & 2) ? 0 : (n0 > n1 ? n0 : n1);
         const bool mine = act && (n ? ((sub >> n) & 1ull) != 0ull : pass == 0);
         const int64_t idx = node * A.l_nstride + e;
-        // Line padding (off unless MPLX_LINE_PAD is set): a list that ends inside a 128-byte line leaves a
-        // partial-line write in every output row.  In a store-only kernel those are expensive (C4's lists:
-        // 3.5-4 TB/s with them, 6+ TB/s when every list ends on a line, profiles/micro/write_pattern.hip), so
-        // the lanes just past the end of the list can be made to complete the lines (unspecified values,
-        // inside the node's own region).  In THIS kernel it changed nothing (0.793 vs 0.799 ms on C4): the
-        // stores are not limited by the memory system but by waves stalling at issue during their store
-        // bursts, so it stays off and the lists stay exactly count[k] entries long.
+        // Line padding (when the node stride is a multiple of 32; MPLX_NO_LINE_PAD turns it off): a list that
+        // ends inside a 128-byte line leaves a partial-line write in every output row, and those cost far
+        // more than their bytes (a store-only kernel writing C4's lists: 3.5-4 TB/s with them, 6+ TB/s when
+        // every list ends on a line, profiles/micro/write_pattern.hip).  The lanes just past the end of the
+        // list therefore store too (unspecified values, inside the node's own region), completing the lines:
+        // +2.7 % bytes, -9 % kernel time on C4 once the kernel is store bound (it made no difference while
+        // the kernel was still compute bound).
         const bool pad16 = A.l_pad && !act && pass == 0 && e < ((E + 15) & ~15);  // 8-byte entries
         const bool pad32 = A.l_pad && !act && pass == 0 && e < ((E + 31) & ~31);  // 4-byte entries
         if ((mine || pad32) && !(A.dbg & 2)) {
@@ -532,7 +594,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
           int ptr[3] = {0, 0, 0};
 #pragma unroll
           for (int i = 0; i < D; i++) ptr[i] = __umul24(__umul24(en[i], RM) + r, tts);
-          bool done = !smp;
+          bool done = !smp || safe;  // a node whose whole reach box is free has nothing to look up
           if (fits) {
             for (int k0 = 0; __ballot(!done) != 0ull; k0 += kUB) {
               unsigned int m = 0;
@@ -629,6 +691,62 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   }
 }
 
+// Summed-area table of the blocked-bit map: sat[z][y][x] (sizes d+1, zero border at index 0) = number of
+// blocked cells with coordinates < (x, y, z).  Built once per map / region change.
+__global__ void sat_seed_kernel(const uint32_t *blk, int d0, int d1, int d2, uint32_t *sat) {
+  const int64_t n = (int64_t)d0 * d1 * d2;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const int x = (int)(g % d0);
+  const int64_t r = g / d0;
+  const int y = (int)(r % d1), z = (int)(r / d1);
+  sat[((int64_t)(z + 1) * (d1 + 1) + (y + 1)) * (d0 + 1) + (x + 1)] = (blk[g >> 5] >> (g & 31)) & 1u;
+}
+// x: one wave per (y, z) row, 64 cells per step, wave-level inclusive scan
+__global__ __launch_bounds__(256) void sat_scan_x_kernel(int d0, int64_t n_rows_with_border, uint32_t *sat) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows_with_border) return;
+  uint32_t *r = sat + row * (d0 + 1) + 1;
+  uint32_t carry = 0;
+  for (int x0 = 0; x0 < d0; x0 += 64) {
+    const int x = x0 + lane;
+    uint32_t v = x < d0 ? r[x] : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+      if (lane >= d) v += o;
+    }
+    v += carry;
+    if (x < d0) r[x] = v;
+    carry = (uint32_t)__shfl((int)v, 63, 64);
+  }
+}
+// y (and z): one thread per column, consecutive threads on consecutive x
+__global__ void sat_scan_y_kernel(int d0, int d1, int d2p, uint32_t *sat) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)(d0 + 1) * d2p) return;
+  const int x = (int)(g % (d0 + 1));
+  const int64_t z = g / (d0 + 1);
+  uint32_t *c = sat + z * (int64_t)(d1 + 1) * (d0 + 1) + x;
+  uint32_t acc = 0;
+  for (int y = 1; y <= d1; y++) {
+    acc += c[(int64_t)y * (d0 + 1)];
+    c[(int64_t)y * (d0 + 1)] = acc;
+  }
+}
+__global__ void sat_scan_z_kernel(int d0, int d1, int d2, uint32_t *sat) {
+  const int64_t plane = (int64_t)(d0 + 1) * (d1 + 1);
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= plane) return;
+  uint32_t *c = sat + g;
+  uint32_t acc = 0;
+  for (int z = 1; z <= d2; z++) {
+    acc += c[(int64_t)z * plane];
+    c[(int64_t)z * plane] = acc;
+  }
+}
+
 // Blocked-bit map: 1 bit per cell in the map's own order (x fastest), 1 = occupied
 // (map == 100) or outside the search region.
 __global__ void build_blocked_bits_kernel(const int8_t *map, const uint32_t *region, int64_t n_cells, int64_t n_words,
@@ -674,6 +792,25 @@ hipError_t launch_build_blocked_bits(const int8_t *map, const uint32_t *region, 
   const int64_t n_words = (n_cells + 31) >> 5;
   const unsigned blocks = (unsigned)((n_words + 255) / 256);
   hipLaunchKernelGGL(build_blocked_bits_kernel, dim3(blocks), dim3(256), 0, stream, map, region, n_cells, n_words, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_sat(int dim, const uint32_t *blk, const int32_t *mdim, uint32_t *sat, hipStream_t stream) {
+  const int d0 = mdim[0], d1 = mdim[1], d2 = dim == 3 ? mdim[2] : 1;
+  const int d2p = dim == 3 ? d2 + 1 : 2;  // planes incl. the zero border plane (2D: border + the one real plane)
+  const int64_t total = (int64_t)(d0 + 1) * (d1 + 1) * d2p;
+  hipError_t e = hipMemsetAsync(sat, 0, (size_t)total * 4, stream);
+  if (e != hipSuccess) return e;
+  const int64_t n = (int64_t)d0 * d1 * d2;
+  hipLaunchKernelGGL(sat_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, blk, d0, d1, d2, sat);
+  const int64_t rows = (int64_t)(d1 + 1) * d2p;
+  hipLaunchKernelGGL(sat_scan_x_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, d0, rows, sat);
+  const int64_t cols = (int64_t)(d0 + 1) * d2p;
+  hipLaunchKernelGGL(sat_scan_y_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, d0, d1, d2p, sat);
+  if (dim == 3) {
+    const int64_t plane = (int64_t)(d0 + 1) * (d1 + 1);
+    hipLaunchKernelGGL(sat_scan_z_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, stream, d0, d1, d2, sat);
+  }
   return hipGetLastError();
 }
 

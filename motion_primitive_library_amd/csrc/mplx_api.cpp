@@ -118,7 +118,7 @@ void mplx_destroy(mplx_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->map, &c->pot, &c->region_bits, &c->region_bytes, &c->U, &c->s_nodes, &c->s_status,
                     &c->s_cost, &c->s_hash, &c->s_state, &c->s_iters, &c->s_count, &c->s_action, &c->tables,
-                    &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx, &c->blk, &c->prep_lut, &c->prep_a, &c->prep_b, &c->post_keys, &c->e_parents, &c->e_action, &c->e_free, &c->e_cost, &c->e_cells, &c->e_count})
+                    &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx, &c->blk, &c->sat, &c->prep_lut, &c->prep_a, &c->prep_b, &c->post_keys, &c->e_parents, &c->e_action, &c->e_free, &c->e_cost, &c->e_cells, &c->e_count})
     release(*b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -354,7 +354,7 @@ TilePlan plan_tile(const mplx_ctx *c) {
 
 struct GridPlan {
   bool ok = false;
-  int ndp = 1, n_max = 0, rmax = 0, boxcap = 0, grid = 0;
+  int ndp = 1, n_max = 0, rmax = 0, boxcap = 0, grid = 0, order = 0;
 };
 
 // Does the factorised kernel cover the current configuration, and how is it sized?
@@ -395,6 +395,7 @@ GridPlan plan_grid(const mplx_ctx *c) {
   g.n_max = n_max;
   g.rmax = rmax;
   g.boxcap = boxcap;
+  g.order = order;
   g.grid = c->n_cus * per_cu;
   if (const char *e = getenv("MPLX_GRID_BLOCKS")) g.grid = atoi(e) > 0 ? atoi(e) : g.grid;  // tuning only
   return g;
@@ -407,6 +408,16 @@ int ensure_blocked_bits(mplx_ctx *c) {
   HIP_TRY(c, mplx::launch_build_blocked_bits((const int8_t *)c->map.p,
                                              c->has_region ? (const uint32_t *)c->region_bits.p : nullptr, c->n_cells,
                                              (uint32_t *)c->blk.p, c->stream));
+  // summed-area table for the free-box shortcut of the grid kernel (skipped for maps where it would not
+  // fit an unsigned count or 16 GiB; the kernel then samples every node)
+  c->sat_ok = false;
+  const int d2p = c->dim == 3 ? c->mdim[2] + 1 : 2;
+  const int64_t sat_n = (int64_t)(c->mdim[0] + 1) * (c->mdim[1] + 1) * d2p;
+  if (!getenv("MPLX_GRID_NOSAT") && sat_n * 4 <= (16LL << 30)) {
+    if (int rc = ensure(c, c->sat, (size_t)sat_n * 4)) return rc;
+    HIP_TRY(c, mplx::launch_build_sat(c->dim, (const uint32_t *)c->blk.p, c->mdim, (uint32_t *)c->sat.p, c->stream));
+    c->sat_ok = true;
+  }
   c->blk_ok = true;
   return MPLX_OK;
 }
@@ -441,6 +452,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     if (int rc = ensure_blocked_bits(c)) return rc;
     a.blk = (const uint32_t *)c->blk.p;
     a.blk_words = (c->n_cells + 31) >> 5;
+    a.sat = (c->sat_ok && gp.order <= 3 && !getenv("MPLX_GRID_NOSAT")) ? (const uint32_t *)c->sat.p : nullptr;
     a.dim0 = c->mdim[0]; a.dim1 = c->mdim[1]; a.dim2 = c->mdim[2];
     a.org0 = c->origin[0]; a.org1 = c->origin[1]; a.org2 = c->origin[2];
     a.res = c->res;
@@ -460,7 +472,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.l_count = o->count; a.l_action = o->action; a.l_cost = o->cost; a.l_hash = o->hash;
     a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
     a.l_nstride = o->node_stride ? o->node_stride : c->nU;
-    a.l_pad = (a.l_nstride % 32 == 0 && getenv("MPLX_LINE_PAD")) ? 1 : 0;  // tuning only, see expand_grid_kernel.hip
+    a.l_pad = (a.l_nstride % 32 == 0 && !getenv("MPLX_NO_LINE_PAD")) ? 1 : 0;  // see expand_grid_kernel.hip
     HIP_TRY(c, mplx::launch_expand_grid(c->dim, c->prm.control, a, c->stream));
     c->last_route = MPLX_ROUTE_GRID;
     return MPLX_OK;

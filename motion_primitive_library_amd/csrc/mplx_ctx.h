@@ -40,7 +40,8 @@ struct mplx_ctx {
   int32_t nU = 0, udim = 0;
   double u_absmax = 0;  // max |u| over the spatial control entries
   // per-axis factorisation of the control table (expand_grid_kernel.hip)
-  mplx_detail::DevBuf uvals, uidx, blk;
+  mplx_detail::DevBuf uvals, uidx, blk, sat;
+  bool sat_ok = false;   // summed-area table of blk is current
   mplx_detail::DevBuf e_parents, e_action, e_free, e_cost, e_cells, e_count;  // edge re-validation staging
   mplx_detail::DevBuf post_keys;                 // node-identity table (post_api.cpp)
   mplx_detail::DevBuf prep_lut, prep_a, prep_b;  // map preprocessing scratch (map_prep_api.cpp)

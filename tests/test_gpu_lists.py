@@ -125,6 +125,27 @@ def test_grid_kernel_small_lds_budgets(engine, oracle_lib, monkeypatch, rmax, bo
             rmax, boxcap, dim, control))
 
 
+@pytest.mark.parametrize("nosat", [False, True])
+def test_free_box_shortcut_and_full_sampling_agree(engine, oracle_lib, monkeypatch, nosat):
+    """Nodes whose whole reach box is free skip the sample loops (summed-area table look-up); a map with a
+    large free region makes most nodes take the shortcut, MPLX_GRID_NOSAT makes none take it.  Same lists,
+    same iteration counts, in 2D and 3D; list tails past count[k] are never read by the comparison."""
+    if nosat:
+        monkeypatch.setenv("MPLX_GRID_NOSAT", "1")
+    for dim, control in ((3, 0x03), (2, 0x03), (3, 0x07), (2, 0x01)):
+        wl = _small_world(engine, dim, control, seed=5200 + dim + control, n_nodes=150, edge=72)
+        g = wl.grid.reshape([72] * dim)
+        g[tuple([slice(0, 44)] * dim)] = 0          # a free corner region: nodes there see no obstacle
+        wl.nodes[:dim, :80] = np.round(np.random.default_rng(dim).uniform(1.6, 2.8, size=(dim, 80)), 2)
+        ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+        assert np.count_nonzero(ref["status"] == 2) > 50  # and the rest still has blocked edges
+        env = engine_env(engine, wl)
+        env.set_lists_route("grid")
+        got = env.expand_lists(wl.nodes, stride=(wl.U.shape[0] + 31) & ~31)
+        env.close()
+        assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="sat=%s dim%d ctrl0x%x" % (not nosat, dim, control))
+
+
 def test_node_stride_smaller_than_the_control_table_is_rejected(engine):
     wl = _small_world(engine, 2, 0x03, seed=6, n_nodes=8)
     env = engine_env(engine, wl)
