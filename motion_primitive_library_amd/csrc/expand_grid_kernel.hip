@@ -578,8 +578,10 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               const double uK = 0.0 + s_uval[en[i]];
               o[(0 * D + i) * ss] = st[0];
               o[(1 * D + i) * ss] = (K >= 2) ? st[1] : uK;
-              o[(2 * D + i) * ss] = (K >= 3) ? st[2] : (K == 2 ? uK : 0.0);
-              o[(3 * D + i) * ss] = (K >= 4) ? st[3] : (K == 3 ? uK : 0.0);
+              if (!(A.dbg & 128)) {  // dbg 128: timing ablation, half of the state rows
+                o[(2 * D + i) * ss] = (K >= 3) ? st[2] : (K == 2 ? uK : 0.0);
+                o[(3 * D + i) * ss] = (K >= 4) ? st[3] : (K == 3 ? uK : 0.0);
+              }
             }
             o[(4 * D) * ss] = 0.0;                // Waypoint::yaw of a control without yaw (primitive.h:322)
             o[(4 * D + 1) * ss] = node_t + A.dt;  // env_map.h:161
