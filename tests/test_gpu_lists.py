@@ -155,6 +155,32 @@ def test_node_stride_smaller_than_the_control_table_is_rejected(engine):
     env.close()
 
 
+def test_control_tables_larger_than_a_workgroup_tile(engine, oracle_lib):
+    """|U| = 11^3 = 1331 > 1024: neither list kernel tiles it, the dense kernel + compaction serves it;
+    |U| = 1024 = 32 x 32 (2D) is the largest table the factorised kernel takes."""
+    W = engine.workloads
+    wl = _small_world(engine, 3, 0x03, seed=8100, n_nodes=40)
+    wl.U = W.grid_controls(np.linspace(-1.0, 1.0, 11), 3)
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+    env = engine_env(engine, wl)
+    got = env.expand_lists(wl.nodes)
+    assert env.last_lists_route() == "dense"
+    env.close()
+    assert_lists_equal(got, ref, wl.n_nodes, 1331, what="|U| = 1331")
+    wl2 = _small_world(engine, 2, 0x03, seed=8101, n_nodes=40)
+    rng = np.random.default_rng(8102)
+    vals = np.linspace(-1.0, 1.0, 16)
+    wl2.U = np.stack([rng.choice(vals, 1024), rng.choice(vals, 1024)], axis=1)
+    wl2.U[:16, 0] = vals
+    wl2.U[:16, 1] = vals
+    ref2 = oracle_lib.expand(oracle_env(wl2), wl2.nodes, threads=8)
+    env = engine_env(engine, wl2)
+    got2 = env.expand_lists(wl2.nodes)
+    assert env.last_lists_route() == "grid"
+    env.close()
+    assert_lists_equal(got2, ref2, wl2.n_nodes, 1024, what="|U| = 1024")
+
+
 def test_forcing_a_route_outside_its_scope_fails_loudly(engine):
     wl = _small_world(engine, 2, 0x13, seed=5, n_nodes=8)  # yaw: only the dense kernel covers it
     env = engine_env(engine, wl)
