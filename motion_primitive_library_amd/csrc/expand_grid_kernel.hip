@@ -181,6 +181,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   const int64_t wave_stride = (int64_t)gridDim.x * kWPB;
   double nxt = 0.0;  // lanes < F: one field of the next node (prefetched)
   if (wave_id < A.n_nodes && lane < F) nxt = A.nodes[(int64_t)lane * A.node_stride + wave_id];
+  asm volatile("" ::"v"(nxt));  // arrived before the loop: no wait for it at the loop head (see the pin after phase A)
 
   for (int64_t node = wave_id; node < A.n_nodes; node += wave_stride) {
     // ---- phase 0: node state into LDS, prefetch of the next node
@@ -392,6 +393,10 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
     unsigned long long nm = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(s_misc[M_NMASK]) |
                             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(s_misc[M_NMASK + 1]) << 32);
     if (A.dbg & 1) nm = 0;  // timing ablation: no sampling
+    // The next node's state (issued at the top of this node) has certainly arrived by now; pin that here,
+    // where only loads are in flight, so that the wait does not end up at the top of the next node behind
+    // this node's ~90 stores (vmcnt retires in order: waiting there means waiting for every store's ack).
+    asm volatile("" ::"v"(nxt));
     bool safe = false;  // the node's whole reach box is free (uniform)
     if (A.sat != nullptr) {
       // inclusion-exclusion: + for corners with an even number of low coordinates
