@@ -70,29 +70,28 @@ struct GridLds {
   // shared by the workgroup (read-only after set-up)
   int o_uval, o_uidx, o_tc, o_wave0;
   // per wave, relative to the wave's block
-  int w_node, w_est, w_eJ, w_hp, w_eq, w_eflag, w_fp, w_box, w_misc, w_rowmap, w_list, w_cell, wave_bytes;
+  int w_node, w_est, w_hp, w_eq, w_eflag, w_box, w_misc, w_rowmap, w_list, w_cell, wave_bytes;
   int total;
-  int F, EN, PN, tts;
+  int F, EN, PN, tts, KQ;
   __host__ __device__ GridLds(int D, int K, int waves, int nU, int ndp, int n_max, int rmax, int boxcap) {
     F = 4 * D + 2;
     EN = D * ndp;
     PN = (D == 3) ? ndp * ndp : ndp;
     tts = n_max + 1;
+    KQ = K == 3 ? 4 : K;
     int b = 0;
     o_uval = b; b += EN * 8;
-    o_uidx = b; b += nU * 4;
+    o_uidx = b; b += ((nU + 1) & ~1) * 2;  // 4 bits per axis
     o_tc = b; b += 64;
     b = (b + 15) & ~15;
     o_wave0 = b;
     int w = 0;
     w_node = w; w += F * 8;
-    w_est = w; w += EN * K * 8;  // end-state fields of order < K (the rest follow from u)
-    w_eJ = w; w += EN * 8;
+    w_est = w; w += EN * (K - 1) * 8;  // end-state fields of order < K - 1 (the rest follow from u and the node)
     w_hp = w; w += PN * 8;
     w = (w + 15) & ~15;
-    w_eq = w; w += EN * 4 * 4;
+    w_eq = w; w += EN * KQ * 4;  // lattice integers of order < K (KQ = K rounded up to 1, 2 or 4 for aligned vector loads)
     w_eflag = w; w += EN * 4;
-    w_fp = w; w += PN * 4;
     w = (w + 7) & ~7;
     w_box = w; w += (boxcap * 4 > rmax * tts * 8) ? boxcap * 4 : rmax * tts * 8;  // also the sample times while rows are built
     w = (w + 15) & ~15;
@@ -127,6 +126,37 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Folds the lattice integers (order < K) of axis entry `e` into a hash, one aligned vector load.
+template <int K>
+__device__ __forceinline__ void fold_entry(uint64_t &h, const int *s_eq, int e) {
+  if (K == 1) {
+    fold(h, s_eq[e]);
+  } else if (K == 2) {
+    const int2 q = *(const int2 *)(s_eq + e * 2);
+    fold(h, q.x);
+    fold(h, q.y);
+  } else {
+    const int4 q = *(const int4 *)(s_eq + e * 4);
+    fold(h, q.x);
+    fold(h, q.y);
+    fold(h, q.z);
+    if (K >= 4) fold(h, q.w);
+  }
+}
+
+// valid / same-position bits (AND) and sample count (max) of a pair from its axis entries' flags
+template <int D>
+__device__ __forceinline__ int pair_flags(const int *s_eflag, int ndp, int j0, int j1, int j2) {
+  const int f0 = s_eflag[j0], f1 = s_eflag[ndp + j1];
+  int fl = f0 & f1 & 3, n = max(f0 >> 8, f1 >> 8);
+  if (D == 3) {
+    const int f2 = s_eflag[2 * ndp + j2];
+    fl &= f2;
+    n = max(n, f2 >> 8);
+  }
+  return fl | (n << 8);
+}
+
 // misc words of a wave
 enum { M_BASE = 0, M_NMASK = 4, M_NV = 6, M_NODEQ = 12, M_VL = 24 };  // NV: valid entries per axis; NODEQ: [D][4]; VL: [D][16] bytes
 
@@ -139,16 +169,14 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const double *s_uval = (const double *)(smem + L.o_uval);
-  const unsigned int *s_uidx = (const unsigned int *)(smem + L.o_uidx);
+  const unsigned short *s_uidx = (const unsigned short *)(smem + L.o_uidx);
   const unsigned char *s_tc = smem + L.o_tc;
   unsigned char *wb = smem + L.o_wave0 + wv * L.wave_bytes;
   double *s_node = (double *)(wb + L.w_node);
   double *s_est = (double *)(wb + L.w_est);
-  double *s_eJ = (double *)(wb + L.w_eJ);
   uint64_t *s_hp = (uint64_t *)(wb + L.w_hp);
   int *s_eq = (int *)(wb + L.w_eq);
   int *s_eflag = (int *)(wb + L.w_eflag);
-  int *s_fp = (int *)(wb + L.w_fp);
   unsigned int *s_box = (unsigned int *)(wb + L.w_box);
   int *s_rb = (int *)(wb + L.w_box);  // [EN][2] reach ranges of the entries (live between T1 and the box query)
   double *s_trow = (double *)(wb + L.w_box);  // [RM][tts] sample times, live only while the rows are built
@@ -158,6 +186,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   unsigned char *s_cell = wb + L.w_cell;
 
   const int tts = L.tts, EN = L.EN, PN = L.PN;
+  constexpr int KQ = K == 3 ? 4 : K;
   const int half = A.n_max + 2;  // cell-offset code = offset from the node's cell + half
   const double T = A.dt;
   const double org[3] = {A.org0, A.org1, A.org2};
@@ -171,8 +200,11 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       const int ax = i / ndp, j = i - ax * ndp;
       uv[i] = A.uvals[ax * 16 + j];
     }
-    unsigned int *ui = (unsigned int *)(smem + L.o_uidx);
-    for (int i = threadIdx.x; i < nU; i += kBT) ui[i] = A.uidx[i];
+    unsigned short *ui = (unsigned short *)(smem + L.o_uidx);
+    for (int i = threadIdx.x; i < nU; i += kBT) {
+      const unsigned int pk = A.uidx[i];  // j0 | j1 << 8 | j2 << 16, each < 16
+      ui[i] = (unsigned short)((pk & 15u) | (((pk >> 8) & 15u) << 4) | (((pk >> 16) & 15u) << 8));
+    }
     if (threadIdx.x < 64) smem[L.o_tc + threadIdx.x] = A.tcnt[threadIdx.x];
   }
   __syncthreads();  // the only workgroup barrier
@@ -216,16 +248,15 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         const double nv_ = q.template vel<true>(T);
         const double na_ = q.template acc<true>(T);
         const double nj_ = q.template jrk<true>(T);
-        // fields of order < K; order K is 0.0 + u and the higher ones are 0 (primitive.h:128-145)
-        s_est[lane * K + 0] = np_;
-        if (K >= 2) s_est[lane * K + 1] = nv_;
-        if (K >= 3) s_est[lane * K + 2] = na_;
-        if (K >= 4) s_est[lane * K + 3] = nj_;
-        s_eq[lane * 4 + 0] = quantise(np_, 0.01, A.R001);
-        s_eq[lane * 4 + 1] = (K >= 2) ? quantise(nv_, 0.1, A.R01) : 0;
-        s_eq[lane * 4 + 2] = (K >= 3) ? quantise(na_, 0.1, A.R01) : 0;
-        s_eq[lane * 4 + 3] = (K >= 4) ? quantise(nj_, 0.1, A.R01) : 0;
-        s_eJ[lane] = u * u * T;  // Primitive::J of a forward primitive (see expand_kernel.hip)
+        // fields of order < K - 1; order K - 1 is (0.0 + u*T) + x0, order K is 0.0 + u, higher ones are 0
+        // (primitive.h:128-145; the same expressions Ax<K>::pos/vel/acc/jrk<true> evaluate)
+        if (K >= 2) s_est[lane * (K - 1) + 0] = np_;
+        if (K >= 3) s_est[lane * (K - 1) + 1] = nv_;
+        if (K >= 4) s_est[lane * (K - 1) + 2] = na_;
+        s_eq[lane * KQ + 0] = quantise(np_, 0.01, A.R001);
+        if (K >= 2) s_eq[lane * KQ + 1] = quantise(nv_, 0.1, A.R01);
+        if (K >= 3) s_eq[lane * KQ + 2] = quantise(na_, 0.1, A.R01);
+        if (K >= 4) s_eq[lane * KQ + 3] = quantise(nj_, 0.1, A.R01);
         flag = (valid ? 1 : 0) | ((p == np_) ? 2 : 0) | (n << 8);
         if (A.sat != nullptr && valid) {
           // range of p(t) over [0, T] of this entry, as cells with one cell of slack on both sides
@@ -286,26 +317,9 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       }
       if (ok) {
         uint64_t h = 0;
-        int f = s_eflag[e0];
-        {
-          const int4 q = *(const int4 *)(s_eq + e0 * 4);
-          fold(h, q.x);
-          if (K >= 2) fold(h, q.y);
-          if (K >= 3) fold(h, q.z);
-          if (K >= 4) fold(h, q.w);
-        }
-        if (D == 3) {
-          const int4 q = *(const int4 *)(s_eq + e1 * 4);
-          fold(h, q.x);
-          if (K >= 2) fold(h, q.y);
-          if (K >= 3) fold(h, q.z);
-          if (K >= 4) fold(h, q.w);
-          const int f1 = s_eflag[e1];
-          const int n0 = f >> 8, n1 = f1 >> 8;
-          f = (f & f1 & 3) | ((n0 > n1 ? n0 : n1) << 8);
-        }
+        fold_entry<K>(h, s_eq, e0);
+        if (D == 3) fold_entry<K>(h, s_eq, e1);
         s_hp[x] = h;
-        s_fp[x] = f;
       }
     }
     wave_sync();
@@ -366,19 +380,13 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       int n = 0;
       if (ci < nU) {
         const unsigned int pk = s_uidx[ci];
-        const int j0 = pk & 255, j1 = (pk >> 8) & 255, j2 = (pk >> 16) & 255;
+        const int j0 = pk & 15, j1 = (pk >> 4) & 15, j2 = (pk >> 8) & 15;
         const int px = (D == 3) ? __umul24(j0, ndp) + j1 : j0;
         const int eL = (D - 1) * ndp + ((D == 3) ? j2 : j1);
         uint64_t h = s_hp[px];
-        const int4 q = *(const int4 *)(s_eq + eL * 4);
-        fold(h, q.x);
-        if (K >= 2) fold(h, q.y);
-        if (K >= 3) fold(h, q.z);
-        if (K >= 4) fold(h, q.w);
-        const int f0 = s_fp[px], f1 = s_eflag[eL];
-        const int fl = f0 & f1;
-        const int n0 = f0 >> 8, n1 = f1 >> 8;
-        n = (fl & 2) ? 0 : (n0 > n1 ? n0 : n1);  // unchanged position: not traversed (env_map.h:163)
+        fold_entry<K>(h, s_eq, eL);
+        const int fl = pair_flags<D>(s_eflag, ndp, j0, j1, j2);
+        n = (fl & 2) ? 0 : (fl >> 8);  // unchanged position: not traversed (env_map.h:163)
         emit = (fl & 1) && (h != hcur);          // env_map.h:158: `tn == curr` is a hash comparison
       }
       const unsigned long long m = __ballot(emit);
@@ -548,12 +556,11 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         const bool act = e < E;
         const int ci = act ? (int)s_list[e] : 0;
         const unsigned int pk = s_uidx[ci];
-        const int j0 = pk & 255, j1 = (pk >> 8) & 255, j2 = (pk >> 16) & 255;
+        const int j0 = pk & 15, j1 = (pk >> 4) & 15, j2 = (pk >> 8) & 15;
         const int en[3] = {j0, ndp + j1, 2 * ndp + j2};
         const int px = (D == 3) ? __umul24(j0, ndp) + j1 : j0;
-        const int f0 = s_fp[px], f1 = s_eflag[en[D - 1]];
-        const int n0 = f0 >> 8, n1 = f1 >> 8;
-        const int n = (f0 & f1 & 2) ? 0 : (n0 > n1 ? n0 : n1);
+        const int fl = pair_flags<D>(s_eflag, ndp, j0, j1, j2);
+        const int n = (fl & 2) ? 0 : (fl >> 8);
         const bool mine = act && (n ? ((sub >> n) & 1ull) != 0ull : pass == 0);
         const int64_t idx = node * A.l_nstride + e;
         // Line padding (when the node stride is a multiple of 32; MPLX_NO_LINE_PAD turns it off): a list that
@@ -567,11 +574,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         const bool pad32 = A.l_pad && !act && pass == 0 && e < ((E + 31) & ~31);  // 4-byte entries
         if ((mine || pad32) && !(A.dbg & 2)) {
           uint64_t h = s_hp[px];
-          const int4 q = *(const int4 *)(s_eq + en[D - 1] * 4);
-          fold(h, q.x);
-          if (K >= 2) fold(h, q.y);
-          if (K >= 3) fold(h, q.z);
-          if (K >= 4) fold(h, q.w);
+          fold_entry<K>(h, s_eq, en[D - 1]);
           if (A.l_action) A.l_action[idx] = mine ? ci : -1;
           if (A.l_hash && (mine || pad16)) A.l_hash[idx] = h;
           if (A.l_state && (mine || pad16)) {
@@ -579,14 +582,14 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
             const int64_t ss = A.l_stride;
 #pragma unroll
             for (int i = 0; i < D; i++) {
-              const double *st = s_est + en[i] * K;
-              const double uK = 0.0 + s_uval[en[i]];
-              o[(0 * D + i) * ss] = st[0];
-              o[(1 * D + i) * ss] = (K >= 2) ? st[1] : uK;
-              if (!(A.dbg & 128)) {  // dbg 128: timing ablation, half of the state rows
-                o[(2 * D + i) * ss] = (K >= 3) ? st[2] : (K == 2 ? uK : 0.0);
-                o[(3 * D + i) * ss] = (K >= 4) ? st[3] : (K == 3 ? uK : 0.0);
-              }
+              const double *st = s_est + en[i] * (K - 1);
+              const double u = s_uval[en[i]];
+              const double uK = 0.0 + u;                                     // field of order K
+              const double top = (0.0 + u * T) + s_node[(K - 1) * D + i];    // field of order K - 1
+              o[(0 * D + i) * ss] = (K >= 2) ? st[0] : top;
+              o[(1 * D + i) * ss] = (K >= 3) ? st[1] : (K == 2 ? top : uK);
+              o[(2 * D + i) * ss] = (K >= 4) ? st[2] : (K == 3 ? top : (K == 2 ? uK : 0.0));
+              o[(3 * D + i) * ss] = (K == 4) ? top : (K == 3 ? uK : 0.0);
             }
             o[(4 * D) * ss] = 0.0;                // Waypoint::yaw of a control without yaw (primitive.h:322)
             o[(4 * D + 1) * ss] = node_t + A.dt;  // env_map.h:161
@@ -688,7 +691,10 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
           const bool blocked = fb >= 0;
           double J = 0;
 #pragma unroll
-          for (int i = 0; i < D; i++) J += s_eJ[en[i]];
+          for (int i = 0; i < D; i++) {  // Primitive::J of a forward primitive: u*u*T per axis (see expand_kernel.hip)
+            const double u = s_uval[en[i]];
+            J += u * u * T;
+          }
           const double cost = blocked ? INFINITY : 0.0 + (J + A.w * A.dt);
           if (A.l_cost && (mine || pad16)) A.l_cost[idx] = cost;
           if (A.l_iters) A.l_iters[idx] = blocked ? fb + 1 : cntl;

@@ -389,7 +389,9 @@ GridPlan plan_grid(const mplx_ctx *c) {
   if (lds > 160 * 1024) return g;
   int per_cu = (int)((160 * 1024) / lds);
   const int wpb = mplx::grid_waves_per_block();
-  if (per_cu * wpb > 32) per_cu = 32 / wpb;
+  // 16 waves per CU is the measured optimum on C4: 20 fit the LDS, but the kernel needs 105 VGPRs (4 waves per
+  // SIMD), and capped to 96 VGPRs with 20 waves resident it is 7-15 % slower (profiles/README.md)
+  if (per_cu * wpb > 16) per_cu = 16 / wpb;
   g.ok = true;
   g.ndp = ndp;
   g.n_max = n_max;
