@@ -575,8 +575,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         if ((mine || pad32) && !(A.dbg & 2)) {
           uint64_t h = s_hp[px];
           fold_entry<K>(h, s_eq, en[D - 1]);
-          if (A.l_action) A.l_action[idx] = mine ? ci : -1;
-          if (A.l_hash && (mine || pad16)) A.l_hash[idx] = h;
+          if (A.l_action) __builtin_nontemporal_store(mine ? ci : -1, &A.l_action[idx]);
+          if (A.l_hash && (mine || pad16)) __builtin_nontemporal_store(h, &A.l_hash[idx]);
           if (A.l_state && (mine || pad16)) {
             double *o = A.l_state + idx;
             const int64_t ss = A.l_stride;
@@ -586,13 +586,13 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               const double u = s_uval[en[i]];
               const double uK = 0.0 + u;                                     // field of order K
               const double top = (0.0 + u * T) + s_node[(K - 1) * D + i];    // field of order K - 1
-              o[(0 * D + i) * ss] = (K >= 2) ? st[0] : top;
-              o[(1 * D + i) * ss] = (K >= 3) ? st[1] : (K == 2 ? top : uK);
-              o[(2 * D + i) * ss] = (K >= 4) ? st[2] : (K == 3 ? top : (K == 2 ? uK : 0.0));
-              o[(3 * D + i) * ss] = (K == 4) ? top : (K == 3 ? uK : 0.0);
+              __builtin_nontemporal_store((double)((K >= 2) ? st[0] : top), &o[(0 * D + i) * ss]);
+              __builtin_nontemporal_store((double)((K >= 3) ? st[1] : (K == 2 ? top : uK)), &o[(1 * D + i) * ss]);
+              __builtin_nontemporal_store((double)((K >= 4) ? st[2] : (K == 3 ? top : (K == 2 ? uK : 0.0))), &o[(2 * D + i) * ss]);
+              __builtin_nontemporal_store((double)((K == 4) ? top : (K == 3 ? uK : 0.0)), &o[(3 * D + i) * ss]);
             }
-            o[(4 * D) * ss] = 0.0;                // Waypoint::yaw of a control without yaw (primitive.h:322)
-            o[(4 * D + 1) * ss] = node_t + A.dt;  // env_map.h:161
+            __builtin_nontemporal_store(0.0, &o[(4 * D) * ss]);  // Waypoint::yaw of a control without yaw (primitive.h:322)
+            __builtin_nontemporal_store(node_t + A.dt, &o[(4 * D + 1) * ss]);  // env_map.h:161
           }
         }
         // ---- the sample loop of traverse_primitive (env_map.h:97-120)
@@ -696,8 +696,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
             J += u * u * T;
           }
           const double cost = blocked ? INFINITY : 0.0 + (J + A.w * A.dt);
-          if (A.l_cost && (mine || pad16)) A.l_cost[idx] = cost;
-          if (A.l_iters) A.l_iters[idx] = blocked ? fb + 1 : cntl;
+          if (A.l_cost && (mine || pad16)) __builtin_nontemporal_store(cost, &A.l_cost[idx]);
+          if (A.l_iters) __builtin_nontemporal_store(blocked ? fb + 1 : cntl, &A.l_iters[idx]);
         }
       }
     }
