@@ -34,6 +34,12 @@ namespace {
 
 constexpr int kBlock = 256;
 
+template <typename T>
+__device__ __forceinline__ void st_out(T *p, T v, bool stream) {
+  if (stream) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 // ---------------------------------------------------------------- lattice hash
 // boost::hash_combine in its classic (< 1.81) form with hash_value(int) =
 // sign-extending conversion; reference include/mpl_basis/waypoint.h:93-125.
@@ -364,22 +370,24 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs A) {
   }
 
   // ---- dense, coalesced slot writes
-  if (A.status) A.status[slot] = st;
-  if (A.cost) A.cost[slot] = cost;
-  if (A.hash) A.hash[slot] = h_next;
-  if (A.iters) A.iters[slot] = iters;
+  // final outputs stream past L2 (never re-read by this kernel); scratch for the compaction stays cached
+  const bool stream = A.stream_out != 0;
+  if (A.status) st_out(&A.status[slot], st, stream);
+  if (A.cost) st_out(&A.cost[slot], cost, stream);
+  if (A.hash) st_out(&A.hash[slot], h_next, stream);
+  if (A.iters) st_out(&A.iters[slot], iters, stream);
   if (A.state) {
     double *o = A.state + slot;
     const int64_t ss = A.state_stride;
 #pragma unroll
     for (int i = 0; i < D; i++) {
-      o[(0 * D + i) * ss] = npos[i];
-      o[(1 * D + i) * ss] = nvel[i];
-      o[(2 * D + i) * ss] = nacc[i];
-      o[(3 * D + i) * ss] = njrk[i];
+      st_out(&o[(0 * D + i) * ss], npos[i], stream);
+      st_out(&o[(1 * D + i) * ss], nvel[i], stream);
+      st_out(&o[(2 * D + i) * ss], nacc[i], stream);
+      st_out(&o[(3 * D + i) * ss], njrk[i], stream);
     }
-    o[(4 * D) * ss] = nyaw;
-    o[(4 * D + 1) * ss] = ct + A.dt;  // env_map.h:161
+    st_out(&o[(4 * D) * ss], nyaw, stream);
+    st_out(&o[(4 * D + 1) * ss], ct + A.dt, stream);  // env_map.h:161
   }
 }
 
@@ -459,12 +467,13 @@ __global__ __launch_bounds__(256) void compact_lists_kernel(const CompactArgs A)
     __syncthreads();
     if (emit) {
       const int64_t idx = node * A.l_nstride + emitted + pre + within;
-      if (A.l_action) A.l_action[idx] = ci;
-      if (A.l_cost) A.l_cost[idx] = A.cost[slot];
-      if (A.l_hash) A.l_hash[idx] = A.hash[slot];
-      if (A.l_iters && A.iters) A.l_iters[idx] = A.iters[slot];
+      if (A.l_action) __builtin_nontemporal_store(ci, &A.l_action[idx]);
+      if (A.l_cost) __builtin_nontemporal_store(A.cost[slot], &A.l_cost[idx]);
+      if (A.l_hash) __builtin_nontemporal_store(A.hash[slot], &A.l_hash[idx]);
+      if (A.l_iters && A.iters) __builtin_nontemporal_store(A.iters[slot], &A.l_iters[idx]);
       if (A.l_state)
-        for (int f = 0; f < A.n_fields; f++) A.l_state[(int64_t)f * A.l_stride + idx] = A.state[(int64_t)f * A.chunk_slots + slot];
+        for (int f = 0; f < A.n_fields; f++)
+          __builtin_nontemporal_store(A.state[(int64_t)f * A.chunk_slots + slot], &A.l_state[(int64_t)f * A.l_stride + idx]);
     }
     emitted += tot;
   }

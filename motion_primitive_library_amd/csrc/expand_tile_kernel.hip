@@ -273,20 +273,20 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A) {
         s_j[v] = (unsigned short)j;
         const int64_t idx = (node0 + nl) * A.l_nstride + j;
         const bool wr = !(A.dbg & 2);  // timing ablation only
-        if (wr && A.l_action) A.l_action[idx] = ci;
-        if (wr && A.l_hash) A.l_hash[idx] = h_next;
+        if (wr && A.l_action) __builtin_nontemporal_store(ci, &A.l_action[idx]);  // outputs are never re-read here: stream past L2
+        if (wr && A.l_hash) __builtin_nontemporal_store(h_next, &A.l_hash[idx]);
         if (wr && A.l_state) {
           double *o = A.l_state + idx;
           const int64_t ss = A.l_stride;
 #pragma unroll
           for (int i = 0; i < D; i++) {
-            o[(0 * D + i) * ss] = npos[i];
-            o[(1 * D + i) * ss] = nvel[i];
-            o[(2 * D + i) * ss] = nacc[i];
-            o[(3 * D + i) * ss] = njrk[i];
+            __builtin_nontemporal_store(npos[i], &o[(0 * D + i) * ss]);
+            __builtin_nontemporal_store(nvel[i], &o[(1 * D + i) * ss]);
+            __builtin_nontemporal_store(nacc[i], &o[(2 * D + i) * ss]);
+            __builtin_nontemporal_store(njrk[i], &o[(3 * D + i) * ss]);
           }
-          o[(4 * D) * ss] = 0.0;            // Waypoint::yaw of a control without yaw (primitive.h:322)
-          o[(4 * D + 1) * ss] = ct + A.dt;  // env_map.h:161
+          __builtin_nontemporal_store(0.0, &o[(4 * D) * ss]);  // Waypoint::yaw of a control without yaw (primitive.h:322)
+          __builtin_nontemporal_store(ct + A.dt, &o[(4 * D + 1) * ss]);  // env_map.h:161
         }
         if (!ONE) atomicAdd(&s_ncnt[nl], 1);
       } else {
@@ -443,8 +443,8 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A) {
     for (int i = 0; i < D; i++) J += u[i] * u[i] * T;  // Primitive::J of a forward primitive (see expand_kernel.hip)
     const double cost = blocked ? INFINITY : 0.0 + (J + A.w * A.dt);
     const int64_t idx = (node0 + nl) * A.l_nstride + j;
-    if (A.l_cost) A.l_cost[idx] = cost;
-    if (A.l_iters) A.l_iters[idx] = iters;
+    if (A.l_cost) __builtin_nontemporal_store(cost, &A.l_cost[idx]);
+    if (A.l_iters) __builtin_nontemporal_store(iters, &A.l_iters[idx]);
   }
   // ---- successors per node
   for (int nl = tid; nl < nn; nl += kBT)

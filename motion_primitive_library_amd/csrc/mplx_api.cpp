@@ -257,6 +257,7 @@ int mplx_expand_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int6
                 (long long)d_out->state_stride, (long long)n_slots);
   if (int rc = bind_device(c)) return rc;
   mplx::ExpandArgs a = make_args(c, d_nodes, n_nodes, node_stride, d_out);
+  a.stream_out = 1;
   HIP_TRY(c, mplx::launch_expand(c->dim, c->prm.control, a, c->stream));
   return MPLX_OK;
 }
@@ -289,6 +290,7 @@ int mplx_expand(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t nod
     d.state_stride = n_slots;
   }
   mplx::ExpandArgs a = make_args(c, (const double *)c->s_nodes.p, n_nodes, n_nodes, &d);
+  a.stream_out = 1;
   HIP_TRY(c, mplx::launch_expand(c->dim, c->prm.control, a, c->stream));
   if (h_out->status) HIP_TRY(c, hipMemcpyAsync(h_out->status, d.status, (size_t)n_slots, hipMemcpyDeviceToHost, c->stream));
   if (h_out->cost) HIP_TRY(c, hipMemcpyAsync(h_out->cost, d.cost, (size_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));

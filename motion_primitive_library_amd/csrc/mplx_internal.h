@@ -37,6 +37,7 @@ struct ExpandArgs {
   double *state;
   int64_t state_stride;
   int32_t *iters;
+  int32_t stream_out;  // 1: the slots are final outputs (non-temporal stores); 0: scratch that is re-read soon
 };
 
 // Arguments of the tiled, list-producing kernel (expand_tile_kernel.hip).
