@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="map edge scale (debug only; invalidates the metric)")
     ap.add_argument("--nodes", type=int, default=None, help="frontier size override (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frontier", default="random", choices=["random", "wavefront"],
+                    help="random: SURVEY 8(d)'s uniformly scattered frontier (the headline); wavefront: the open list of "
+                         "an eps = 0 search from the map centre (realistic locality; reported in profiles/README.md)")
     ap.add_argument("--output", default="lists", choices=["lists", "dense", "dense-compact"],
                     help="lists: per-node successor lists, the reference's output shape (count, action, cost, hash, "
                          "full Waypoint) -- default; dense: one 129-B slot per pair; dense-compact: status+cost+hash only")
@@ -128,6 +131,8 @@ def main():
         seed = {"C2": 2002, "C3": 2003, "C4": 2004, "C5": 2005}[args.workload] + 100 * rank
         kw = {"C2": (2.0, 0.5), "C3": (3.0, 0.5, 2.0, 1.0), "C4": (2.0, 0.5), "C5": (2.0, 0.5)}[args.workload]
         wl.nodes = m.workloads.random_frontier(wl.grid, wl.origin, wl.res, wl.n_nodes, seed, wl.control, *kw)
+    if args.frontier == "wavefront":
+        wl.nodes = m.workloads.wavefront_frontier(wl, wl.n_nodes, local_rank)
     t_gen = time.time() - t_gen
 
     env = m.EnvMap(wl.dim, local_rank)
@@ -198,7 +203,7 @@ def main():
             "config": {
                 "workload": WORKLOAD_DESC[args.workload] + ("" if args.scale == 1.0 and args.nodes is None else
                                                            " [DEBUG scale=%g nodes=%s]" % (args.scale, args.nodes)),
-                "frontier_nodes_per_gpu": wl.n_nodes, "controls": int(wl.U.shape[0]), "dim": wl.dim,
+                "frontier": args.frontier, "frontier_nodes_per_gpu": wl.n_nodes, "controls": int(wl.U.shape[0]), "dim": wl.dim,
                 "pairs_per_step_per_gpu": wl.n_pairs, "map_cells": int(wl.grid.size),
                 "output": {"lists": "per-node successor lists: count + action + cost + hash + full Waypoint (4D+2 doubles), emitted successors only",
                            "dense": "dense slots: status + cost + hash + full Waypoint for every pair",

@@ -317,6 +317,9 @@ int mplx_planner_trajectory(mplx_planner *p, double *nodes, int32_t *actions, in
 /* Closed-set positions of the last plan (PlannerBase::getCloseSet): fills up
  * to cap points of D doubles; *n receives the closed-set size.               */
 int mplx_planner_closed_set(mplx_planner *p, double *pos, int32_t cap, int32_t *n);
+/* Open-set states of the last plan (PlannerBase::getOpenSet returns their positions): fills up to
+ * cap rows of 4D+2 doubles; *n receives the open-set size.                    */
+int mplx_planner_open_set(mplx_planner *p, double *states, int32_t cap, int32_t *n);
 const char *mplx_planner_last_error(const mplx_planner *p);
 
 /* ---- diagnostics -------------------------------------------------------- */

@@ -177,4 +177,18 @@ int mplx_planner_closed_set(mplx_planner *p, double *pos, int32_t cap, int32_t *
   return MPLX_OK;
 }
 
+int mplx_planner_open_set(mplx_planner *p, double *states, int32_t cap, int32_t *n) {
+  if (!p || !n) return MPLX_ERR_ARG;
+  const int f = p->pl.F();
+  int32_t m = 0;
+  for (const mplx::host::Node &nd : p->pl.pool) {
+    if (!nd.opened || nd.closed) continue;
+    if (states && m < cap)
+      for (int i = 0; i < f; i++) states[(size_t)m * f + i] = nd.coord[(size_t)i];
+    m++;
+  }
+  *n = m;
+  return MPLX_OK;
+}
+
 }  // extern "C"

@@ -153,6 +153,15 @@ class MapPlanner:
         self._check(self._L.mplx_planner_closed_set(self._p, pts.ctypes.data, n.value, C.byref(n)))
         return pts
 
+    def getOpenStates(self):
+        """Full states (rows of 4D+2) of the open set of the last plan (PlannerBase::getOpenSet gives positions)."""
+        n = C.c_int32()
+        self._check(self._L.mplx_planner_open_set(self._p, None, 0, C.byref(n)))
+        f = 4 * self.dim + 2
+        rows = np.empty((n.value, f), dtype=np.float64)
+        self._check(self._L.mplx_planner_open_set(self._p, rows.ctypes.data, n.value, C.byref(n)))
+        return rows
+
     def getTraj(self):
         o = self._summary
         f = 4 * self.dim + 2

@@ -238,3 +238,51 @@ def make(name, scale=1.0, n_nodes=None):
                         {"v_max": 2.0, "yaw_max": 0.5, "potential_weight": 0.5, "gradient_weight": 0.0},
                         potential=pot)
     raise ValueError("unknown workload %r" % name)
+
+
+def wavefront_frontier(wl, n_nodes, device=0):
+    """SURVEY.md 8(d)'s second synthetic frontier: the open list of an eps = 0 (uniform-cost) search grown from a
+    free start cell until it holds n_nodes states -- realistic spatial locality and lattice velocities, unlike
+    the uniformly scattered default.  The search is run by the engine's own host A* (needs a GPU).  Returns
+    field-major [4D+2][n_nodes]; deterministic for a given workload."""
+    from .planner import MapPlanner, MapUtil
+    from .env import Waypoint
+    dim = wl.dim
+    flat = wl.grid.ravel()
+    centre = [d // 2 for d in wl.map_dim]
+    start = None
+    for r in range(0, max(wl.map_dim)):
+        for off in itertools.product(range(-r, r + 1), repeat=dim):
+            c = [centre[i] + off[i] for i in range(dim)]
+            if all(0 <= c[i] < wl.map_dim[i] for i in range(dim)):
+                idx = c[0] + wl.map_dim[0] * (c[1] + (wl.map_dim[1] * c[2] if dim == 3 else 0))
+                if flat[idx] == 0:
+                    start = [wl.origin[i] + (c[i] + 0.5) * wl.res for i in range(dim)]
+                    break
+        if start:
+            break
+    goal = [wl.origin[i] + (wl.map_dim[i] - 0.5) * wl.res for i in range(dim)]  # far corner: never reached in time
+    rows = None
+    expansions = max(64, n_nodes // 64)
+    for _ in range(12):
+        pl = MapPlanner(dim, device=device)
+        mu = MapUtil(dim)
+        mu.setMap(wl.origin, wl.map_dim, flat, wl.res)
+        pl.setMapUtil(mu)
+        for name, setter in (("v_max", pl.setVmax), ("a_max", pl.setAmax), ("j_max", pl.setJmax)):
+            if name in wl.params:
+                setter(wl.params[name])
+        pl.setDt(wl.params.get("dt", 1.0))
+        pl.setU(wl.U)
+        pl.setEpsilon(0.0)
+        pl.setMaxNum(expansions)
+        pl.setBatch(256)
+        pl.plan(Waypoint(dim, wl.control, pos=start), Waypoint(dim, wl.control, pos=goal))
+        rows = pl.getOpenStates()
+        pl.close()
+        if rows.shape[0] >= n_nodes:
+            break
+        expansions *= 2
+    if rows is None or rows.shape[0] < n_nodes:
+        raise RuntimeError("wavefront frontier: open list has only %d states" % (0 if rows is None else rows.shape[0]))
+    return np.ascontiguousarray(rows[:n_nodes].T)

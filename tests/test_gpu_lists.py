@@ -146,6 +146,19 @@ def test_free_box_shortcut_and_full_sampling_agree(engine, oracle_lib, monkeypat
         assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="sat=%s dim%d ctrl0x%x" % (not nosat, dim, control))
 
 
+def test_wavefront_frontier_expands_like_the_oracle(engine, oracle_lib):
+    """The open list of an eps = 0 search as frontier (workloads.wavefront_frontier): clustered nodes with
+    lattice velocities and many shared successors."""
+    wl = engine.workloads.make("C4", scale=0.125, n_nodes=64)
+    wl.nodes = engine.workloads.wavefront_frontier(wl, 400)
+    assert wl.nodes.shape == (14, 400) and np.unique(wl.nodes[:3].T, axis=0).shape[0] > 50
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+    env = engine_env(engine, wl)
+    got = env.expand_lists(wl.nodes)
+    env.close()
+    assert_lists_equal(got, ref, 400, wl.U.shape[0], what="wavefront frontier")
+
+
 def test_node_stride_smaller_than_the_control_table_is_rejected(engine):
     wl = _small_world(engine, 2, 0x03, seed=6, n_nodes=8)
     env = engine_env(engine, wl)
