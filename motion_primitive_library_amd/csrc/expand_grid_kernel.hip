@@ -509,7 +509,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       const int WX = (nb[0] + 31) >> 5;
       const int n_rows = nb[1] * nb[2];
       const bool direct = (__ballot(ovf) != 0ull) || (A.dbg & 64);  // dbg 64: test hook, force direct evaluation
-      const bool fits = !safe && !direct && have_box && n_rows * WX <= A.boxcap;
+      const bool fits = !safe && !direct && A.pot == nullptr && have_box && n_rows * WX <= A.boxcap;
       if (fits && sub) {  // (never for a safe node)
         const float inv_ny = 1.0f / (float)nb[1];
         const int ax0 = base_c[0] + lo[0] - half;
@@ -599,13 +599,49 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         const bool smp = mine && n != 0;
         const int cntl = smp ? (int)s_tc[n] : 0;  // iterations of `for (t = 0; t < T; t += T/n)`
         int fb = -1;                              // first blocked sample
+        double csum = 0.0;                        // traverse_primitive's accumulated cost (potential maps)
         {
           const int r = smp ? (int)s_rowmap[n] : 0;
           int ptr[3] = {0, 0, 0};
 #pragma unroll
           for (int i = 0; i < D; i++) ptr[i] = __umul24(__umul24(en[i], RM) + r, tts);
           bool done = !smp || safe;  // a node whose whole reach box is free has nothing to look up
-          if (fits) {
+          if (A.pot != nullptr) {
+            // potential map (env_map.h:113-118; gradient_weight == 0 on this route): the values are needed, not
+            // just a bit, so the samples read the int8 cells from HBM / L2 (8 in flight per lane) and the cost is
+            // accumulated in the reference's order
+            const double sdt = smp ? T / n : 0.0;  // env_map.h:96
+            for (int k0 = 0; __ballot(!done) != 0ull; k0 += kUB) {
+              int val[kUB];
+              bool bad[kUB];
+#pragma unroll
+              for (int q = 0; q < kUB; q++) {
+                int k = k0 + q;
+                k = k < cntl ? k : (cntl > 0 ? cntl - 1 : 0);
+                bool inside = !done;
+                int64_t cell = 0, mul = 1;
+#pragma unroll
+                for (int i = 0; i < D; i++) {
+                  const int c = base_c[i] + (done ? 0 : (int)s_cell[ptr[i] + k]) - half;
+                  inside = inside && c >= 0 && c < dims[i];
+                  cell += mul * c;
+                  mul *= dims[i];
+                }
+                const int64_t ci_ = inside ? cell : 0;
+                const bool in_reg = A.region == nullptr || ((A.region[ci_ >> 5] >> (ci_ & 31)) & 1u);
+                val[q] = A.pot[ci_];
+                bad[q] = !inside || !in_reg;
+              }
+#pragma unroll
+              for (int q = 0; q < kUB; q++) {
+                if (!done && k0 + q < cntl) {
+                  if (bad[q] || val[q] >= 100) { fb = k0 + q; done = true; }
+                  else if (val[q] > 0) csum += sdt * (A.pot_w * val[q]);
+                }
+              }
+              if (k0 + kUB >= cntl) done = true;
+            }
+          } else if (fits) {
             for (int k0 = 0; __ballot(!done) != 0ull; k0 += kUB) {
               unsigned int m = 0;
               if (WX == 1) {  // the box is at most 32 cells wide: one word per (y, z) row
@@ -695,7 +731,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
             const double u = s_uval[en[i]];
             J += u * u * T;
           }
-          const double cost = blocked ? INFINITY : 0.0 + (J + A.w * A.dt);
+          const double cost = blocked ? INFINITY : csum + (J + A.w * A.dt);
           if (A.l_cost && (mine || pad16)) __builtin_nontemporal_store(cost, &A.l_cost[idx]);
           if (A.l_iters) __builtin_nontemporal_store(blocked ? fb + 1 : cntl, &A.l_iters[idx]);
         }
@@ -763,14 +799,15 @@ __global__ void sat_scan_z_kernel(int d0, int d1, int d2, uint32_t *sat) {
 // Blocked-bit map: 1 bit per cell in the map's own order (x fastest), 1 = occupied
 // (map == 100) or outside the search region.
 __global__ void build_blocked_bits_kernel(const int8_t *map, const uint32_t *region, int64_t n_cells, int64_t n_words,
-                                          uint32_t *out) {
+                                          int potential, uint32_t *out) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_words) return;
   uint32_t bits = 0;
   const uint32_t reg = region ? region[g] : 0xffffffffu;
   for (int b = 0; b < 32; b++) {
     const int64_t idx = g * 32 + b;
-    const bool blocked = idx >= n_cells || map[idx] == 100 || !((reg >> b) & 1u);
+    // occupancy: blocked cells; potential map: every cell that blocks OR costs (value > 0, env_map.h:113-118)
+    const bool blocked = idx >= n_cells || (potential ? map[idx] > 0 : map[idx] == 100) || !((reg >> b) & 1u);
     bits |= (blocked ? 1u : 0u) << b;
   }
   out[g] = bits;
@@ -800,11 +837,11 @@ size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, 
 }
 int grid_waves_per_block() { return kWPB; }
 
-hipError_t launch_build_blocked_bits(const int8_t *map, const uint32_t *region, int64_t n_cells, uint32_t *out,
-                                     hipStream_t stream) {
+hipError_t launch_build_blocked_bits(const int8_t *map, const uint32_t *region, int64_t n_cells, int potential,
+                                     uint32_t *out, hipStream_t stream) {
   const int64_t n_words = (n_cells + 31) >> 5;
   const unsigned blocks = (unsigned)((n_words + 255) / 256);
-  hipLaunchKernelGGL(build_blocked_bits_kernel, dim3(blocks), dim3(256), 0, stream, map, region, n_cells, n_words, out);
+  hipLaunchKernelGGL(build_blocked_bits_kernel, dim3(blocks), dim3(256), 0, stream, map, region, n_cells, n_words, potential, out);
   return hipGetLastError();
 }
 

@@ -159,13 +159,14 @@ int mplx_set_map(mplx_ctx *c, const int8_t *cells, const int32_t *dim, const dou
 
 int mplx_set_potential(mplx_ctx *c, const int8_t *cells) {
   if (!c) return MPLX_ERR_ARG;
-  if (!cells) { c->has_pot = false; return MPLX_OK; }
+  if (!cells) { c->blk_ok = c->blk_ok && !c->has_pot; c->has_pot = false; return MPLX_OK; }
   if (!c->has_map) return fail(c, MPLX_ERR_STATE, "mplx_set_potential: set the map first");
   if (int rc = bind_device(c)) return rc;
   if (int rc = ensure(c, c->pot, (size_t)c->n_cells)) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->pot.p, cells, (size_t)c->n_cells, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->has_pot = true;
+  c->blk_ok = false;
   return MPLX_OK;
 }
 
@@ -364,7 +365,7 @@ GridPlan plan_grid(const mplx_ctx *c) {
   GridPlan g;
   const mplx_params &p = c->prm;
   if (p.control & 0x10) return g;
-  if (c->has_pot) return g;
+  if (c->has_pot && c->prm.gradient_weight != 0) return g;  // |vel| per sample: lane-per-pair kernel
   if (!c->u_factored || c->nU > 1024 || c->nU < 1) return g;
   double vbound;
   if ((p.control & 0x0f) == MPLX_VEL) vbound = c->u_absmax;
@@ -409,9 +410,9 @@ int ensure_blocked_bits(mplx_ctx *c) {
   if (c->blk_ok) return MPLX_OK;
   const int64_t words = (c->n_cells + 31) >> 5;
   if (int rc = ensure(c, c->blk, (size_t)words * 4)) return rc;
-  HIP_TRY(c, mplx::launch_build_blocked_bits((const int8_t *)c->map.p,
+  HIP_TRY(c, mplx::launch_build_blocked_bits((const int8_t *)(c->has_pot ? c->pot.p : c->map.p),
                                              c->has_region ? (const uint32_t *)c->region_bits.p : nullptr, c->n_cells,
-                                             (uint32_t *)c->blk.p, c->stream));
+                                             c->has_pot ? 1 : 0, (uint32_t *)c->blk.p, c->stream));
   // summed-area table for the free-box shortcut of the grid kernel (skipped for maps where it would not
   // fit an unsigned count or 16 GiB; the kernel then samples every node)
   c->sat_ok = false;
@@ -456,6 +457,9 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     if (int rc = ensure_blocked_bits(c)) return rc;
     a.blk = (const uint32_t *)c->blk.p;
     a.blk_words = (c->n_cells + 31) >> 5;
+    a.pot = c->has_pot ? (const int8_t *)c->pot.p : nullptr;
+    a.region = c->has_region ? (const uint32_t *)c->region_bits.p : nullptr;
+    a.pot_w = c->prm.potential_weight;
     a.sat = (c->sat_ok && gp.order <= 3 && !getenv("MPLX_GRID_NOSAT")) ? (const uint32_t *)c->sat.p : nullptr;
     a.dim0 = c->mdim[0]; a.dim1 = c->mdim[1]; a.dim2 = c->mdim[2];
     a.org0 = c->origin[0]; a.org1 = c->origin[1]; a.org2 = c->origin[2];

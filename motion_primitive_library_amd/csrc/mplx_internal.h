@@ -90,6 +90,9 @@ hipError_t launch_expand_tile(int dim, int control, const TileArgs &args, hipStr
 struct GridArgs {
   const uint32_t *blk;   // blocked-bit map, 1 bit per cell, x fastest (launch_build_blocked_bits)
   int64_t blk_words;
+  const int8_t *pot;     // potential map (then blk / sat describe "potential > 0 or outside the region") or null
+  const uint32_t *region; // search region bits (read by the potential path only; folded into blk otherwise)
+  double pot_w;
   const uint32_t *sat;   // summed-area table of blk, sizes dim+1 with a zero border (launch_build_sat), or null
   int32_t dim0, dim1, dim2;
   double org0, org1, org2;
@@ -128,8 +131,8 @@ hipError_t launch_expand_grid(int dim, int control, const GridArgs &args, hipStr
 // region; (n_cells + 31) / 32 dwords.
 // Summed-area table of the blocked bits: (d0+1)(d1+1)(d2+1) uint32 (2D: (d0+1)(d1+1)*2).
 hipError_t launch_build_sat(int dim, const uint32_t *blk, const int32_t *mdim, uint32_t *sat, hipStream_t stream);
-hipError_t launch_build_blocked_bits(const int8_t *map, const uint32_t *region, int64_t n_cells, uint32_t *out,
-                                     hipStream_t stream);
+hipError_t launch_build_blocked_bits(const int8_t *map, const uint32_t *region, int64_t n_cells, int potential,
+                                     uint32_t *out, hipStream_t stream);
 
 // Batched edge re-validation (edge_kernel.hip).
 struct EdgeArgs {

@@ -194,6 +194,46 @@ def test_control_tables_larger_than_a_workgroup_tile(engine, oracle_lib):
     assert_lists_equal(got2, ref2, wl2.n_nodes, 1024, what="|U| = 1024")
 
 
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("control", [0x01, 0x03, 0x07])
+@pytest.mark.parametrize("nosat", [False, True])
+def test_potential_map_on_the_factorised_kernel(engine, oracle_lib, monkeypatch, dim, control, nosat):
+    """Potential maps with gradient_weight == 0 (env_map.h:113-118 reduces to dt * w_p * value per sample) stay on
+    the factorised kernel: per-sample values from the int8 map, costs accumulated in the reference's order (bit-exact),
+    the free-box shortcut now meaning "zero potential in the whole reach box".  With a search region on top, and
+    dropping back to the lane-per-pair kernel when gradient_weight != 0."""
+    if nosat:
+        monkeypatch.setenv("MPLX_GRID_NOSAT", "1")
+    wl = _small_world(engine, dim, control, seed=7100 + 10 * dim + control, potential=True, region=True, n_nodes=120,
+                      edge=64)
+    wl.params["gradient_weight"] = 0.0
+    g = wl.potential.reshape([64] * dim)
+    g[tuple([slice(8, 30)] * dim)] = 0              # a zero-potential pocket inside the region
+    wl.grid = wl.potential
+    wl.nodes[:dim, :40] = np.round(np.random.default_rng(dim).uniform(1.4, 2.4, size=(dim, 40)), 2)
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+    fin = np.isfinite(ref["cost"]) & (ref["status"] >= 1)
+    assert np.count_nonzero(ref["status"] == 2) > 50 and np.count_nonzero(fin) > 200
+    env = engine_env(engine, wl)
+    got = env.expand_lists(wl.nodes)
+    assert env.last_lists_route() == "grid"
+    assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="potential on grid dim%d ctrl0x%x" % (dim, control))
+    env.set_gradient_weight(0.25)
+    env.expand_lists(wl.nodes)
+    assert env.last_lists_route() == "dense"
+    # switching back to a plain occupancy query on the same context rebuilds the blocked bits
+    env.set_gradient_weight(0.0)
+    env.set_potential_map(None)
+    got2 = env.expand_lists(wl.nodes)
+    assert env.last_lists_route() == "grid"
+    wl2 = engine.workloads.Workload("small", dim, control, wl.grid, [0.0] * dim, wl.res, wl.U, wl.nodes,
+                                    {k: v for k, v in wl.params.items() if "weight" not in k}, potential=None,
+                                    region=wl.region)
+    ref2 = oracle_lib.expand(oracle_env(wl2), wl.nodes, threads=8)
+    env.close()
+    assert_lists_equal(got2, ref2, wl.n_nodes, wl.U.shape[0], what="potential removed dim%d ctrl0x%x" % (dim, control))
+
+
 def test_forcing_a_route_outside_its_scope_fails_loudly(engine):
     wl = _small_world(engine, 2, 0x13, seed=5, n_nodes=8)  # yaw: only the dense kernel covers it
     env = engine_env(engine, wl)
