@@ -58,8 +58,17 @@
 // and ceil are monotone; everything else is the same per-axis arithmetic as the
 // other kernels, evaluated once instead of once per pair.
 //
-// Scope: controls without yaw, no potential map, v_max > 0 (or VEL), Dim 2/3,
-// K = 1..4, n_max <= 61.
+// Yaw controls (VELxYAW .. JRKxYAW): the yaw rate is one more factor of the
+// control table.  Per node and yaw value: yaw(T), its lattice integer, cos / sin;
+// per (x entry, y entry): the 16-bit set of yaw values whose heading constraint
+// holds at both ends (primitive.h:504-525); per (yaw value, sample) cos / sin and
+// per (x / y entry, sample) the velocity, so that the per-sample heading cost of
+// traverse_primitive (env_map.h:121-129) is table look-ups, one sqrt and two
+// divisions.  Potential maps with gradient_weight == 0 read the int8 values per
+// sample (env_map.h:113-118).
+//
+// Scope: v_max > 0 (or VEL), Dim 2/3, K = 1..4 (K <= 3 with yaw or a potential
+// map), gradient_weight == 0, n_max <= 61.
 #include "mplx_internal.h"
 #include "mplx_device_common.h"
 
@@ -71,9 +80,12 @@ struct GridLds {
   int o_uval, o_uidx, o_tc, o_wave0;
   // per wave, relative to the wave's block
   int w_node, w_est, w_hp, w_eq, w_eflag, w_box, w_misc, w_rowmap, w_list, w_cell, wave_bytes;
+  int o_uyaw, w_yaw, w_ycs, w_yq, w_hmask, w_vs, w_ycsr;  // yaw controls only
   int total;
   int F, EN, PN, tts, KQ;
-  __host__ __device__ GridLds(int D, int K, int waves, int nU, int ndp, int n_max, int rmax, int boxcap) {
+  // ym: 0 = no yaw, 1 = yaw, 2 = yaw with the per-sample heading cost (wyaw > 0); ndy = distinct yaw rates
+  __host__ __device__ GridLds(int D, int K, int waves, int nU, int ndp, int n_max, int rmax, int boxcap, int ym,
+                              int ndy) {
     F = 4 * D + 2;
     EN = D * ndp;
     PN = (D == 3) ? ndp * ndp : ndp;
@@ -83,6 +95,7 @@ struct GridLds {
     o_uval = b; b += EN * 8;
     o_uidx = b; b += ((nU + 1) & ~1) * 2;  // 4 bits per axis
     o_tc = b; b += 64;
+    o_uyaw = b; b += ym ? 16 * 8 : 0;
     b = (b + 15) & ~15;
     o_wave0 = b;
     int w = 0;
@@ -95,10 +108,18 @@ struct GridLds {
     w = (w + 7) & ~7;
     w_box = w; w += (boxcap * 4 > rmax * tts * 8) ? boxcap * 4 : rmax * tts * 8;  // also the sample times while rows are built
     w = (w + 15) & ~15;
-    w_misc = w; w += 36 * 4;
+    w_misc = w; w += 40 * 4;
     w_rowmap = w; w += 64;
     w_list = w; w += ((nU + 1) & ~1) * 2;
     w_cell = w; w += EN * rmax * tts + 8;  // + 8: the sample loop reads up to 7 codes past a row
+    w = (w + 15) & ~15;
+    w_yaw = w; w += ym ? 16 * 8 : 0;            // yaw(T) per yaw value
+    w_ycs = w; w += ym ? 16 * 16 : 0;           // cos, sin of yaw(T)
+    w_yq = w; w += ym ? 16 * 4 : 0;             // lattice integer of yaw(T)
+    w_hmask = w; w += ym ? ndp * ndp * 2 : 0;   // per (x entry, y entry): yaw values passing the heading limit
+    w = (w + 15) & ~15;
+    w_vs = w; w += ym == 2 ? 2 * ndp * rmax * tts * 8 : 0;   // velocity of the x / y entries at the sample times
+    w_ycsr = w; w += ym == 2 ? ndy * rmax * tts * 16 : 0;    // cos, sin of the yaw at the sample times
     wave_bytes = (w + 15) & ~15;
     total = o_wave0 + waves * wave_bytes;
   }
@@ -158,14 +179,23 @@ __device__ __forceinline__ int pair_flags(const int *s_eflag, int ndp, int j0, i
 }
 
 // misc words of a wave
-enum { M_BASE = 0, M_NMASK = 4, M_NV = 6, M_NODEQ = 12, M_VL = 24 };  // NV: valid entries per axis; NODEQ: [D][4]; VL: [D][16] bytes
+enum { M_BASE = 0, M_NMASK = 4, M_NV = 6, M_NODEQ = 12, M_VL = 24, M_YQ = 36 };  // NV: valid entries per axis; NODEQ: [D][4]; VL: [D][16] bytes; YQ: the node's yaw integer
 
-template <int D, int K>
+// reference include/mpl_basis/math.h:15-19
+__device__ __forceinline__ double wrap_angle(double a) {
+  while (a > M_PI) a -= 2.0 * M_PI;
+  while (a < -M_PI) a += 2.0 * M_PI;
+  return a;
+}
+
+template <int D, int K, bool YAW>
 __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int F = 4 * D + 2;
   const int nU = A.nU, ndp = A.ndp, RM = A.rmax;
-  const GridLds L(D, K, kWPB, nU, ndp, A.n_max, RM, A.boxcap);
+  const bool ycost = YAW && A.wyaw > 0;  // env_map.h:121: per-sample heading cost
+  const int ndy = YAW ? A.ndy : 0;
+  const GridLds L(D, K, kWPB, nU, ndp, A.n_max, RM, A.boxcap, YAW ? (ycost ? 2 : 1) : 0, ndy);
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const double *s_uval = (const double *)(smem + L.o_uval);
@@ -184,6 +214,13 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   unsigned char *s_rowmap = wb + L.w_rowmap;
   unsigned short *s_list = (unsigned short *)(wb + L.w_list);
   unsigned char *s_cell = wb + L.w_cell;
+  const double *s_uyaw = (const double *)(smem + L.o_uyaw);
+  double *s_yawT = (double *)(wb + L.w_yaw);
+  double *s_ycs = (double *)(wb + L.w_ycs);
+  int *s_yq = (int *)(wb + L.w_yq);
+  unsigned short *s_hmask = (unsigned short *)(wb + L.w_hmask);
+  double *s_vs = (double *)(wb + L.w_vs);
+  double *s_ycsr = (double *)(wb + L.w_ycsr);
 
   const int tts = L.tts, EN = L.EN, PN = L.PN;
   constexpr int KQ = K == 3 ? 4 : K;
@@ -203,12 +240,15 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
     unsigned short *ui = (unsigned short *)(smem + L.o_uidx);
     for (int i = threadIdx.x; i < nU; i += kBT) {
       const unsigned int pk = A.uidx[i];  // j0 | j1 << 8 | j2 << 16, each < 16
-      ui[i] = (unsigned short)((pk & 15u) | (((pk >> 8) & 15u) << 4) | (((pk >> 16) & 15u) << 8));
+      ui[i] = (unsigned short)((pk & 15u) | (((pk >> 8) & 15u) << 4) | (((pk >> 16) & 15u) << 8) |
+                               (((pk >> 24) & 15u) << 12));  // bits 12..15: the yaw value
     }
+    if (YAW && threadIdx.x < ndy) ((double *)(smem + L.o_uyaw))[threadIdx.x] = A.uvals[3 * 16 + threadIdx.x];
     if (threadIdx.x < 64) smem[L.o_tc + threadIdx.x] = A.tcnt[threadIdx.x];
   }
   __syncthreads();  // the only workgroup barrier
 
+  const double cos_lim = (YAW && A.yaw_max > 0) ? cos(A.yaw_max) : 0.0;  // primitive.h:521
   const int64_t wave_id = (int64_t)blockIdx.x * kWPB + wv;
   const int64_t wave_stride = (int64_t)gridDim.x * kWPB;
   double nxt = 0.0;  // lanes < F: one field of the next node (prefetched)
@@ -290,6 +330,21 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         s_misc[M_NODEQ + i * 4 + f] = f == 0 ? quantise(x, 0.01, A.R001) : quantise(x, 0.1, A.R01);
       }
     }
+    if (YAW) {
+      // per yaw value: yaw(T) = wrap(p(T)) of the yaw polynomial (primitive.h:329), its lattice integer
+      // (waypoint.h:113-116) and, for the heading limit, its cos / sin
+      const double cyaw = s_node[4 * D];
+      if (lane < ndy) {
+        const double yT = wrap_angle((0.0 + s_uyaw[lane] * T) + cyaw);
+        s_yawT[lane] = yT;
+        s_yq[lane] = quantise(yT, 0.1, A.R01);
+        if (A.yaw_max > 0) {
+          s_ycs[lane * 2 + 0] = cos(yT);
+          s_ycs[lane * 2 + 1] = sin(yT);
+        }
+      }
+      if (lane == 63) s_misc[M_YQ] = quantise(cyaw, 0.1, A.R01);
+    }
     {
       // per axis, the values that pass the limits, in order: the only entries whose samples are ever needed
       const unsigned long long vm = __ballot((flag & 1) != 0);
@@ -322,6 +377,39 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         s_hp[x] = h;
       }
     }
+    if (YAW) {
+      // validate_yaw (primitive.h:504-525) at t = 0 and t = T for every (x entry, y entry): the set of yaw
+      // values whose heading stays within yaw_max of the velocity direction
+      const bool lim = A.yaw_max > 0;
+      const double y0 = wrap_angle((0.0 + 0.0) + s_node[4 * D]);  // yaw polynomial at t = 0: (0.0 + u_yaw * 0.0) + yaw
+      const double c0 = lim ? cos(y0) : 0.0, s0 = lim ? sin(y0) : 0.0;
+      const float inv_n1 = 1.0f / (float)nd[1];
+      for (int x = lane; x < nd[0] * nd[1]; x += 64) {
+        const int j0 = (int)(((float)x + 0.5f) * inv_n1), j1 = x - j0 * nd[1];
+        unsigned int mask = 0xffffu;
+        if (lim) {
+          Ax<K> qx, qy;
+          qx.init(s_node[0], (K >= 2) ? s_node[1 * D] : 0.0, (K >= 3) ? s_node[2 * D] : 0.0, 0.0, s_uval[j0]);
+          qy.init(s_node[1], (K >= 2) ? s_node[1 * D + 1] : 0.0, (K >= 3) ? s_node[2 * D + 1] : 0.0, 0.0, s_uval[ndp + j1]);
+          const double vx0 = qx.template vel<true>(0.0), vy0 = qy.template vel<true>(0.0);
+          if (vx0 != 0 || vy0 != 0) {
+            const double sn = sqrt(vx0 * vx0 + vy0 * vy0);
+            const double d = vx0 / sn * c0 + vy0 / sn * s0;
+            if (d < cos_lim) mask = 0;
+          }
+          const double vxT = qx.template vel<true>(T), vyT = qy.template vel<true>(T);
+          if (vxT != 0 || vyT != 0) {
+            const double sn = sqrt(vxT * vxT + vyT * vyT);
+            const double nx = vxT / sn, ny = vyT / sn;
+            for (int jy = 0; jy < ndy; jy++) {
+              const double d = nx * s_ycs[jy * 2] + ny * s_ycs[jy * 2 + 1];
+              if (d < cos_lim) mask &= ~(1u << jy);
+            }
+          }
+        }
+        s_hmask[j0 * ndp + j1] = (unsigned short)mask;
+      }
+    }
     wave_sync();
 
     uint64_t hcur = 0;  // hash of the node, folded by every lane alike (no divergence)
@@ -333,6 +421,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       if (K >= 3) fold(hcur, q.z);
       if (K >= 4) fold(hcur, q.w);
     }
+    if (YAW) fold(hcur, s_misc[M_YQ]);
     // ---- free-box shortcut: the summed-area table of the blocked-bit map answers "is the whole box the
     // node can reach in T free?" with 2^D look-ups.  If it is, every sample of every valid pair is free and
     // rows, box staging and the sample loops are skipped for this node.  The loads are issued here and
@@ -385,9 +474,15 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         const int eL = (D - 1) * ndp + ((D == 3) ? j2 : j1);
         uint64_t h = s_hp[px];
         fold_entry<K>(h, s_eq, eL);
+        bool head = true;
+        if (YAW) {
+          const int jy = (pk >> 12) & 15;
+          fold(h, s_yq[jy]);
+          head = (s_hmask[__umul24(j0, ndp) + j1] >> jy) & 1;
+        }
         const int fl = pair_flags<D>(s_eflag, ndp, j0, j1, j2);
         n = (fl & 2) ? 0 : (fl >> 8);  // unchanged position: not traversed (env_map.h:163)
-        emit = (fl & 1) && (h != hcur);          // env_map.h:158: `tn == curr` is a hash comparison
+        emit = (fl & 1) && head && (h != hcur);  // env_map.h:158: `tn == curr` is a hash comparison
       }
       const unsigned long long m = __ballot(emit);
       if (emit) {
@@ -412,7 +507,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       if ((D - __popc((unsigned)lane & ((1u << D) - 1u))) & 1) term = 0u - term;
 #pragma unroll
       for (int d = 1; d < (1 << D); d <<= 1) term += (unsigned int)__shfl_xor((int)term, d, 64);
-      safe = sat_inside && __builtin_amdgcn_readfirstlane((int)term) == 0;
+      safe = sat_inside && !ycost && __builtin_amdgcn_readfirstlane((int)term) == 0;
     }
 
     // ---- rounds of up to RM sample counts
@@ -483,6 +578,20 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               s_cell[__umul24(__umul24(aj, RM) + row, tts) + k] = (unsigned char)code;
               lo_l[ax] = code < lo_l[ax] ? code : lo_l[ax];
               hi_l[ax] = code > hi_l[ax] ? code : hi_l[ax];
+              if (YAW && ax < 2 && ycost)  // Waypoint::vel of the sample (primitive.h:321-331), x and y
+                s_vs[__umul24(__umul24(aj, RM) + row, tts) + k] = q.template vel<false>(trow[k]);
+            }
+          }
+          if (YAW && ycost) {
+            // heading of every yaw value at the sample times: wrap(p_yaw(t)), then cos / sin once per node
+            const double cyaw = s_node[4 * D];
+            for (int x = lane; x < ndy * cn; x += 64) {
+              const int jy = (int)(((float)x + 0.5f) * inv_cn);
+              const int k = x - __umul24(jy, cn);
+              const double yw = wrap_angle(s_uyaw[jy] * trow[k] + cyaw);
+              double *o = s_ycsr + (__umul24(__umul24(jy, RM) + row, tts) + k) * 2;
+              o[0] = cos(yw);
+              o[1] = sin(yw);
             }
           }
         }
@@ -558,6 +667,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         const unsigned int pk = s_uidx[ci];
         const int j0 = pk & 15, j1 = (pk >> 4) & 15, j2 = (pk >> 8) & 15;
         const int en[3] = {j0, ndp + j1, 2 * ndp + j2};
+        const int jy = YAW ? (int)((pk >> 12) & 15) : 0;
         const int px = (D == 3) ? __umul24(j0, ndp) + j1 : j0;
         const int fl = pair_flags<D>(s_eflag, ndp, j0, j1, j2);
         const int n = (fl & 2) ? 0 : (fl >> 8);
@@ -575,6 +685,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         if ((mine || pad32) && !(A.dbg & 2)) {
           uint64_t h = s_hp[px];
           fold_entry<K>(h, s_eq, en[D - 1]);
+          if (YAW) fold(h, s_yq[jy]);
           if (A.l_action) __builtin_nontemporal_store(mine ? ci : -1, &A.l_action[idx]);
           if (A.l_hash && (mine || pad16)) __builtin_nontemporal_store(h, &A.l_hash[idx]);
           if (A.l_state && (mine || pad16)) {
@@ -591,7 +702,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               __builtin_nontemporal_store((double)((K >= 4) ? st[2] : (K == 3 ? top : (K == 2 ? uK : 0.0))), &o[(2 * D + i) * ss]);
               __builtin_nontemporal_store((double)((K == 4) ? top : (K == 3 ? uK : 0.0)), &o[(3 * D + i) * ss]);
             }
-            __builtin_nontemporal_store(0.0, &o[(4 * D) * ss]);  // Waypoint::yaw of a control without yaw (primitive.h:322)
+            // Waypoint::yaw: 0 for a control without yaw (primitive.h:322)
+            __builtin_nontemporal_store(YAW ? s_yawT[jy] : 0.0, &o[(4 * D) * ss]);
             __builtin_nontemporal_store(node_t + A.dt, &o[(4 * D + 1) * ss]);  // env_map.h:161
           }
         }
@@ -606,11 +718,21 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
 #pragma unroll
           for (int i = 0; i < D; i++) ptr[i] = __umul24(__umul24(en[i], RM) + r, tts);
           bool done = !smp || safe;  // a node whose whole reach box is free has nothing to look up
+          const double sdt = (smp && (A.pot != nullptr || ycost)) ? T / n : 0.0;  // env_map.h:96
+          // env_map.h:121-129: heading cost of sample k (after the potential term of the same sample)
+          const int pyr = YAW ? __umul24(__umul24(jy, RM) + r, tts) : 0;
+          auto heading_cost = [&](int k) {
+            const double vx = s_vs[ptr[0] + k], vy = s_vs[ptr[1] + k];
+            const double sn = sqrt(vx * vx + vy * vy);
+            if (sn > 1e-5) {
+              const double v_value = 1 - (vx / sn * s_ycsr[(pyr + k) * 2] + vy / sn * s_ycsr[(pyr + k) * 2 + 1]);
+              csum += A.wyaw * v_value * sdt;
+            }
+          };
           if (A.pot != nullptr) {
             // potential map (env_map.h:113-118; gradient_weight == 0 on this route): the values are needed, not
             // just a bit, so the samples read the int8 cells from HBM / L2 (8 in flight per lane) and the cost is
             // accumulated in the reference's order
-            const double sdt = smp ? T / n : 0.0;  // env_map.h:96
             for (int k0 = 0; __ballot(!done) != 0ull; k0 += kUB) {
               int val[kUB];
               bool bad[kUB];
@@ -636,7 +758,10 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               for (int q = 0; q < kUB; q++) {
                 if (!done && k0 + q < cntl) {
                   if (bad[q] || val[q] >= 100) { fb = k0 + q; done = true; }
-                  else if (val[q] > 0) csum += sdt * (A.pot_w * val[q]);
+                  else {
+                    if (val[q] > 0) csum += sdt * (A.pot_w * val[q]);
+                    if (YAW && ycost) heading_cost(k0 + q);
+                  }
                 }
               }
               if (k0 + kUB >= cntl) done = true;
@@ -718,6 +843,26 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
                 const bool blocked = !inside || ((A.blk[inside ? (cell >> 5) : 0] >> (cell & 31)) & 1u);
                 if (blocked) { fb = k; done = true; }
                 if (k + 1 >= cntl) done = true;
+              }
+            }
+          }
+        }
+        if (YAW && ycost && A.pot == nullptr) {
+          // occupancy map: the heading cost only matters for a primitive that is not blocked
+          const bool go = smp && fb < 0;
+          int ptr[3] = {0, 0, 0};
+          const int r = smp ? (int)s_rowmap[n] : 0;
+#pragma unroll
+          for (int i = 0; i < 2; i++) ptr[i] = __umul24(__umul24(en[i], RM) + r, tts);
+          const int pyr = __umul24(__umul24(jy, RM) + r, tts);
+          const double sdt = go ? T / n : 0.0;
+          for (int k = 0; __ballot(go && k < cntl) != 0ull; k++) {
+            if (go && k < cntl) {
+              const double vx = s_vs[ptr[0] + k], vy = s_vs[ptr[1] + k];
+              const double sn = sqrt(vx * vx + vy * vy);
+              if (sn > 1e-5) {
+                const double v_value = 1 - (vx / sn * s_ycsr[(pyr + k) * 2] + vy / sn * s_ycsr[(pyr + k) * 2 + 1]);
+                csum += A.wyaw * v_value * sdt;
               }
             }
           }
@@ -813,27 +958,27 @@ __global__ void build_blocked_bits_kernel(const int8_t *map, const uint32_t *reg
   out[g] = bits;
 }
 
-template <int D, int K>
+template <int D, int K, bool YAW>
 hipError_t launch_grid_inst(const GridArgs &a, hipStream_t stream) {
   if (a.n_nodes == 0) return hipSuccess;
   const int64_t n_wg = (a.n_nodes + kWPB - 1) / kWPB;
   const int64_t blocks = n_wg < (int64_t)a.grid_limit ? n_wg : (int64_t)a.grid_limit;
-  const size_t lds = grid_lds_bytes(D, K, a.nU, a.ndp, a.n_max, a.rmax, a.boxcap);
+  const size_t lds = grid_lds_bytes(D, K, a.nU, a.ndp, a.n_max, a.rmax, a.boxcap, YAW ? (a.wyaw > 0 ? 2 : 1) : 0, a.ndy);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)expand_grid_kernel<D, K>,
+    hipError_t e = hipFuncSetAttribute((const void *)expand_grid_kernel<D, K, YAW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((expand_grid_kernel<D, K>), dim3((unsigned)blocks), dim3(kBT), lds, stream, a);
+  hipLaunchKernelGGL((expand_grid_kernel<D, K, YAW>), dim3((unsigned)blocks), dim3(kBT), lds, stream, a);
   return hipGetLastError();
 }
 
 }  // namespace
 
-size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap) {
-  return (size_t)GridLds(dim, order, kWPB, nU, ndp, n_max, rmax, boxcap).total;
+size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap, int yaw_mode, int ndy) {
+  return (size_t)GridLds(dim, order, kWPB, nU, ndp, n_max, rmax, boxcap, yaw_mode, ndy).total;
 }
 int grid_waves_per_block() { return kWPB; }
 
@@ -867,17 +1012,23 @@ hipError_t launch_build_sat(int dim, const uint32_t *blk, const int32_t *mdim, u
 hipError_t launch_expand_grid(int dim, int control, const GridArgs &a, hipStream_t s) {
   if (dim == 2) {
     switch (control) {
-      case 0x01: return launch_grid_inst<2, 1>(a, s);
-      case 0x03: return launch_grid_inst<2, 2>(a, s);
-      case 0x07: return launch_grid_inst<2, 3>(a, s);
-      case 0x0f: return launch_grid_inst<2, 4>(a, s);
+      case 0x01: return launch_grid_inst<2, 1, false>(a, s);
+      case 0x03: return launch_grid_inst<2, 2, false>(a, s);
+      case 0x07: return launch_grid_inst<2, 3, false>(a, s);
+      case 0x0f: return launch_grid_inst<2, 4, false>(a, s);
+      case 0x11: return launch_grid_inst<2, 1, true>(a, s);
+      case 0x13: return launch_grid_inst<2, 2, true>(a, s);
+      case 0x17: return launch_grid_inst<2, 3, true>(a, s);
     }
   } else if (dim == 3) {
     switch (control) {
-      case 0x01: return launch_grid_inst<3, 1>(a, s);
-      case 0x03: return launch_grid_inst<3, 2>(a, s);
-      case 0x07: return launch_grid_inst<3, 3>(a, s);
-      case 0x0f: return launch_grid_inst<3, 4>(a, s);
+      case 0x01: return launch_grid_inst<3, 1, false>(a, s);
+      case 0x03: return launch_grid_inst<3, 2, false>(a, s);
+      case 0x07: return launch_grid_inst<3, 3, false>(a, s);
+      case 0x0f: return launch_grid_inst<3, 4, false>(a, s);
+      case 0x11: return launch_grid_inst<3, 1, true>(a, s);
+      case 0x13: return launch_grid_inst<3, 2, true>(a, s);
+      case 0x17: return launch_grid_inst<3, 3, true>(a, s);
     }
   }
   return hipErrorInvalidValue;

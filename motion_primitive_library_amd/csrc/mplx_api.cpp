@@ -216,22 +216,24 @@ int mplx_set_controls(mplx_ctx *c, const double *U, int32_t nU, int32_t udim) {
     }
   // distinct values per spatial axis (compared bit-for-bit so that signed zeros stay apart)
   c->u_factored = true;
-  double vals[3][16];
+  double vals[4][16] = {};
   std::vector<uint32_t> packed((size_t)nU, 0u);
-  for (int k = 0; k < c->dim && c->u_factored; k++) {
+  c->u_nd[3] = 0;
+  for (int k = 0; k < udim && c->u_factored; k++) {
+    const int slot = k < c->dim ? k : 3;  // the yaw rate (column dim of a yaw control table) is the fourth factor
     int n = 0;
     for (int32_t i = 0; i < nU; i++) {
       const double x = U[(size_t)i * udim + k];
       int j = 0;
       for (; j < n; j++)
-        if (std::memcmp(&vals[k][j], &x, sizeof x) == 0) break;
+        if (std::memcmp(&vals[slot][j], &x, sizeof x) == 0) break;
       if (j == n) {
         if (n == 16) { c->u_factored = false; break; }
-        vals[k][n++] = x;
+        vals[slot][n++] = x;
       }
-      packed[(size_t)i] |= (uint32_t)j << (8 * k);
+      packed[(size_t)i] |= (uint32_t)j << (8 * slot);
     }
-    c->u_nd[k] = n;
+    c->u_nd[slot] = n;
   }
   if (c->u_factored) {
     for (int k = c->dim; k < 3; k++) c->u_nd[k] = 0;
@@ -364,7 +366,8 @@ struct GridPlan {
 GridPlan plan_grid(const mplx_ctx *c) {
   GridPlan g;
   const mplx_params &p = c->prm;
-  if (p.control & 0x10) return g;
+  const bool yaw = (p.control & 0x10) != 0;
+  if (yaw && (c->udim != c->dim + 1 || c->u_nd[3] < 1)) return g;
   if (c->has_pot && c->prm.gradient_weight != 0) return g;  // |vel| per sample: lane-per-pair kernel
   if (!c->u_factored || c->nU > 1024 || c->nU < 1) return g;
   double vbound;
@@ -381,14 +384,18 @@ GridPlan plan_grid(const mplx_ctx *c) {
   // A box of (n_max + 3)^(D-1) rows covers every node whose per-axis velocities keep their sign.
   const int ctl = p.control & 0x0f;
   const int order = ctl == MPLX_VEL ? 1 : ctl == MPLX_ACC ? 2 : ctl == MPLX_JRK ? 3 : 4;
+  // SNP: the rare primitives whose cell codes leave their range are sampled by direct evaluation, which the
+  // kernel has for plain occupancy queries only
+  if (order == 4 && (yaw || c->has_pot)) return g;
+  const int ym = yaw ? (p.wyaw > 0 ? 2 : 1) : 0, ndy = yaw ? c->u_nd[3] : 0;
   int rmax = 4, boxcap = (c->dim == 3) ? (n_max + 3) * (n_max + 3) : 4 * (n_max + 3);
   if (boxcap < 64) boxcap = 64;
   if (boxcap > 1024) boxcap = 1024;
   if (const char *e = getenv("MPLX_GRID_RMAX")) rmax = atoi(e);      // tuning only
   if (const char *e = getenv("MPLX_GRID_BOXCAP")) boxcap = atoi(e);  // tuning only
   if (rmax < 1) rmax = 1;
-  while (rmax > 1 && mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rmax, boxcap) > 80 * 1024) rmax--;
-  const size_t lds = mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rmax, boxcap);
+  while (rmax > 1 && mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rmax, boxcap, ym, ndy) > 80 * 1024) rmax--;
+  const size_t lds = mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rmax, boxcap, ym, ndy);
   if (lds > 160 * 1024) return g;
   int per_cu = (int)((160 * 1024) / lds);
   const int wpb = mplx::grid_waves_per_block();
@@ -460,7 +467,11 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.pot = c->has_pot ? (const int8_t *)c->pot.p : nullptr;
     a.region = c->has_region ? (const uint32_t *)c->region_bits.p : nullptr;
     a.pot_w = c->prm.potential_weight;
-    a.sat = (c->sat_ok && gp.order <= 3 && !getenv("MPLX_GRID_NOSAT")) ? (const uint32_t *)c->sat.p : nullptr;
+    const bool yaw = (c->prm.control & 0x10) != 0;
+    // the free-box shortcut skips the sample loops, which a per-sample heading cost (wyaw > 0) still needs
+    a.sat = (c->sat_ok && gp.order <= 3 && !(yaw && c->prm.wyaw > 0) && !getenv("MPLX_GRID_NOSAT"))
+                ? (const uint32_t *)c->sat.p : nullptr;
+    a.yaw_max = c->prm.yaw_max; a.wyaw = c->prm.wyaw; a.ndy = yaw ? c->u_nd[3] : 0;
     a.dim0 = c->mdim[0]; a.dim1 = c->mdim[1]; a.dim2 = c->mdim[2];
     a.org0 = c->origin[0]; a.org1 = c->origin[1]; a.org2 = c->origin[2];
     a.res = c->res;

@@ -99,9 +99,11 @@ struct GridArgs {
   double res;
   double dt, w;
   double v_max, a_max, j_max;
-  const double *uvals;   // [3][16] distinct control values of each axis
+  double yaw_max, wyaw;  // yaw controls only
+  const double *uvals;   // [4][16] distinct control values of each axis; row 3 = yaw rates
   const uint32_t *uidx;  // [nU] packed per-axis value indices
   int32_t nd0, nd1, nd2; // number of distinct values per axis
+  int32_t ndy;           // distinct yaw rates (yaw controls)
   int32_t ndp;           // table stride over values (max nd)
   int32_t nU;
   const double *nodes;
@@ -124,7 +126,7 @@ struct GridArgs {
   int64_t l_nstride;  // entries reserved per node (>= nU)
   int32_t l_pad;      // 1: complete the last 128-byte line of every list row (node stride is a multiple of 32)
 };
-size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap);
+size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap, int yaw_mode, int ndy);
 int grid_waves_per_block();
 hipError_t launch_expand_grid(int dim, int control, const GridArgs &args, hipStream_t stream);
 // Blocked-bit map: 1 bit per cell in map order, 1 = occupied or outside the search

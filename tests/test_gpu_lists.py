@@ -234,8 +234,63 @@ def test_potential_map_on_the_factorised_kernel(engine, oracle_lib, monkeypatch,
     assert_lists_equal(got2, ref2, wl.n_nodes, wl.U.shape[0], what="potential removed dim%d ctrl0x%x" % (dim, control))
 
 
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("control", [0x11, 0x13, 0x17])
+@pytest.mark.parametrize("variant", ["heading_cost", "no_cost", "no_limit", "potential", "region"])
+def test_yaw_controls_on_the_factorised_kernel(engine, oracle_lib, dim, control, variant):
+    """Yaw controls (VELxYAW, ACCxYAW, JRKxYAW) with the yaw rate as a fourth factor of the control table: heading
+    limit at both ends (primitive.h:504-525), yaw in the lattice hash and the successor state, per-sample heading
+    cost (env_map.h:121-129) alone and on top of a potential map.  Same lists from the factorised kernel and from
+    the lane-per-pair kernel, both against the oracle; cos / sin differ from glibc's in the last place, hence the
+    cost tolerance."""
+    wl = _small_world(engine, dim, control, seed=8100 + 10 * dim + control, potential=(variant == "potential"),
+                      region=(variant == "region"), n_nodes=110, edge=56)
+    if control != 0x11:
+        # most headings roughly along the velocity, or the heading limit leaves almost nothing to traverse
+        rng = np.random.default_rng(dim + control)
+        along = np.arctan2(wl.nodes[dim + 1], wl.nodes[dim]) + rng.uniform(-0.4, 0.4, size=wl.n_nodes)
+        keep = np.arange(wl.n_nodes) % 5 == 0
+        wl.nodes[4 * dim] = np.where(keep, wl.nodes[4 * dim], along)
+    if variant == "potential":
+        wl.params["gradient_weight"] = 0.0
+    if variant == "no_cost":
+        wl.params["wyaw"] = 0.0
+    if variant == "no_limit":
+        wl.params["yaw_max"] = 0.0
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+    assert np.count_nonzero(ref["status"] == 1) > 100
+    assert variant == "no_limit" or np.count_nonzero(ref["status"] == 3) > 100  # the heading limit rejects some
+    env = engine_env(engine, wl)
+    for route in ("grid", "dense"):
+        env.set_lists_route(route)
+        got = env.expand_lists(wl.nodes)
+        assert env.last_lists_route() == route
+        assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], cost_rtol=YAW_COST_RTOL,
+                           what="yaw %s route %s dim%d ctrl0x%x" % (variant, route, dim, control))
+    env.close()
+
+
+def test_yaw_grid_and_dense_kernels_agree_bit_for_bit(engine):
+    """Same device cos / sin on the same arguments in both kernels: the two routes must agree exactly, costs
+    included (the tolerance above is only for glibc against the device library)."""
+    wl = engine.workloads.make("C5", scale=0.25, n_nodes=2000)
+    env = engine_env(engine, wl)
+    out = {}
+    for route in ("grid", "dense"):
+        env.set_lists_route(route)
+        out[route] = env.expand_lists(wl.nodes)
+    env.close()
+    a, b = out["grid"], out["dense"]
+    assert np.array_equal(a["count"], b["count"]) and a["stride"] == b["stride"] and a["count"].sum() > 5000
+    live = (np.arange(a["stride"])[None, :] < a["count"][:, None]).ravel()  # list tails are unspecified
+    for name in ("action", "hash", "iters", "cost"):
+        assert np.array_equal(a[name][live], b[name][live]), name
+    assert np.array_equal(a["state"][:, live].view(np.uint64), b["state"][:, live].view(np.uint64))
+    assert np.isfinite(a["cost"][live]).sum() > 1000
+
+
 def test_forcing_a_route_outside_its_scope_fails_loudly(engine):
-    wl = _small_world(engine, 2, 0x13, seed=5, n_nodes=8)  # yaw: only the dense kernel covers it
+    wl = _small_world(engine, 2, 0x1F, seed=5, n_nodes=8)  # SNPxYAW: only the dense kernel covers it
     env = engine_env(engine, wl)
     env.set_lists_route("grid")
     with pytest.raises(engine._abi.MplxError) as e:
