@@ -188,7 +188,7 @@ __device__ __forceinline__ double wrap_angle(double a) {
   return a;
 }
 
-template <int D, int K, bool YAW>
+template <int D, int K, bool YAW, bool POT>
 __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int F = 4 * D + 2;
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       const int WX = (nb[0] + 31) >> 5;
       const int n_rows = nb[1] * nb[2];
       const bool direct = (__ballot(ovf) != 0ull) || (A.dbg & 64);  // dbg 64: test hook, force direct evaluation
-      const bool fits = !safe && !direct && A.pot == nullptr && have_box && n_rows * WX <= A.boxcap;
+      const bool fits = !safe && !direct && !POT && have_box && n_rows * WX <= A.boxcap;
       if (fits && sub) {  // (never for a safe node)
         const float inv_ny = 1.0f / (float)nb[1];
         const int ax0 = base_c[0] + lo[0] - half;
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
 #pragma unroll
           for (int i = 0; i < D; i++) ptr[i] = __umul24(__umul24(en[i], RM) + r, tts);
           bool done = !smp || safe;  // a node whose whole reach box is free has nothing to look up
-          const double sdt = (smp && (A.pot != nullptr || ycost)) ? T / n : 0.0;  // env_map.h:96
+          const double sdt = (smp && (POT || ycost)) ? T / n : 0.0;  // env_map.h:96
           // env_map.h:121-129: heading cost of sample k (after the potential term of the same sample)
           const int pyr = YAW ? __umul24(__umul24(jy, RM) + r, tts) : 0;
           auto heading_cost = [&](int k) {
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               csum += A.wyaw * v_value * sdt;
             }
           };
-          if (A.pot != nullptr) {
+          if (POT) {
             // potential map (env_map.h:113-118; gradient_weight == 0 on this route): the values are needed, not
             // just a bit, so the samples read the int8 cells from HBM / L2 (8 in flight per lane) and the cost is
             // accumulated in the reference's order
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
             }
           }
         }
-        if (YAW && ycost && A.pot == nullptr) {
+        if (YAW && ycost && !POT) {
           // occupancy map: the heading cost only matters for a primitive that is not blocked
           const bool go = smp && fb < 0;
           int ptr[3] = {0, 0, 0};
@@ -958,7 +958,7 @@ __global__ void build_blocked_bits_kernel(const int8_t *map, const uint32_t *reg
   out[g] = bits;
 }
 
-template <int D, int K, bool YAW>
+template <int D, int K, bool YAW, bool POT>
 hipError_t launch_grid_inst(const GridArgs &a, hipStream_t stream) {
   if (a.n_nodes == 0) return hipSuccess;
   const int64_t n_wg = (a.n_nodes + kWPB - 1) / kWPB;
@@ -966,12 +966,12 @@ hipError_t launch_grid_inst(const GridArgs &a, hipStream_t stream) {
   const size_t lds = grid_lds_bytes(D, K, a.nU, a.ndp, a.n_max, a.rmax, a.boxcap, YAW ? (a.wyaw > 0 ? 2 : 1) : 0, a.ndy);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)expand_grid_kernel<D, K, YAW>,
+    hipError_t e = hipFuncSetAttribute((const void *)expand_grid_kernel<D, K, YAW, POT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((expand_grid_kernel<D, K, YAW>), dim3((unsigned)blocks), dim3(kBT), lds, stream, a);
+  hipLaunchKernelGGL((expand_grid_kernel<D, K, YAW, POT>), dim3((unsigned)blocks), dim3(kBT), lds, stream, a);
   return hipGetLastError();
 }
 
@@ -1012,23 +1012,23 @@ hipError_t launch_build_sat(int dim, const uint32_t *blk, const int32_t *mdim, u
 hipError_t launch_expand_grid(int dim, int control, const GridArgs &a, hipStream_t s) {
   if (dim == 2) {
     switch (control) {
-      case 0x01: return launch_grid_inst<2, 1, false>(a, s);
-      case 0x03: return launch_grid_inst<2, 2, false>(a, s);
-      case 0x07: return launch_grid_inst<2, 3, false>(a, s);
-      case 0x0f: return launch_grid_inst<2, 4, false>(a, s);
-      case 0x11: return launch_grid_inst<2, 1, true>(a, s);
-      case 0x13: return launch_grid_inst<2, 2, true>(a, s);
-      case 0x17: return launch_grid_inst<2, 3, true>(a, s);
+      case 0x01: return a.pot ? launch_grid_inst<2, 1, false, true>(a, s) : launch_grid_inst<2, 1, false, false>(a, s);
+      case 0x03: return a.pot ? launch_grid_inst<2, 2, false, true>(a, s) : launch_grid_inst<2, 2, false, false>(a, s);
+      case 0x07: return a.pot ? launch_grid_inst<2, 3, false, true>(a, s) : launch_grid_inst<2, 3, false, false>(a, s);
+      case 0x0f: return a.pot ? hipErrorInvalidValue : launch_grid_inst<2, 4, false, false>(a, s);
+      case 0x11: return a.pot ? launch_grid_inst<2, 1, true, true>(a, s) : launch_grid_inst<2, 1, true, false>(a, s);
+      case 0x13: return a.pot ? launch_grid_inst<2, 2, true, true>(a, s) : launch_grid_inst<2, 2, true, false>(a, s);
+      case 0x17: return a.pot ? launch_grid_inst<2, 3, true, true>(a, s) : launch_grid_inst<2, 3, true, false>(a, s);
     }
   } else if (dim == 3) {
     switch (control) {
-      case 0x01: return launch_grid_inst<3, 1, false>(a, s);
-      case 0x03: return launch_grid_inst<3, 2, false>(a, s);
-      case 0x07: return launch_grid_inst<3, 3, false>(a, s);
-      case 0x0f: return launch_grid_inst<3, 4, false>(a, s);
-      case 0x11: return launch_grid_inst<3, 1, true>(a, s);
-      case 0x13: return launch_grid_inst<3, 2, true>(a, s);
-      case 0x17: return launch_grid_inst<3, 3, true>(a, s);
+      case 0x01: return a.pot ? launch_grid_inst<3, 1, false, true>(a, s) : launch_grid_inst<3, 1, false, false>(a, s);
+      case 0x03: return a.pot ? launch_grid_inst<3, 2, false, true>(a, s) : launch_grid_inst<3, 2, false, false>(a, s);
+      case 0x07: return a.pot ? launch_grid_inst<3, 3, false, true>(a, s) : launch_grid_inst<3, 3, false, false>(a, s);
+      case 0x0f: return a.pot ? hipErrorInvalidValue : launch_grid_inst<3, 4, false, false>(a, s);
+      case 0x11: return a.pot ? launch_grid_inst<3, 1, true, true>(a, s) : launch_grid_inst<3, 1, true, false>(a, s);
+      case 0x13: return a.pot ? launch_grid_inst<3, 2, true, true>(a, s) : launch_grid_inst<3, 2, true, false>(a, s);
+      case 0x17: return a.pot ? launch_grid_inst<3, 3, true, true>(a, s) : launch_grid_inst<3, 3, true, false>(a, s);
     }
   }
   return hipErrorInvalidValue;
