@@ -120,6 +120,7 @@ void mplx_destroy(mplx_ctx *c) {
                     &c->s_cost, &c->s_hash, &c->s_state, &c->s_iters, &c->s_count, &c->s_action, &c->tables,
                     &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx, &c->blk, &c->sat, &c->prep_lut, &c->prep_a, &c->prep_b, &c->post_keys, &c->e_parents, &c->e_action, &c->e_free, &c->e_cost, &c->e_cells, &c->e_count})
     release(*b);
+  mplx_detail::release_copy_buffers(c);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -612,8 +613,9 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
   }
   d.node_stride = h_out->node_stride;
   if (int rc = lists_device(c, (const double *)c->s_nodes.p, n_nodes, n_nodes, &d)) return rc;
+  if (n_nodes > 1) return mplx_detail::copy_lists_to_host(c, d, h_out, n_nodes);  // used prefixes only, pipelined
   HIP_TRY(c, hipMemcpyAsync(h_out->count, d.count, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, c->stream));
-  if (n_nodes == 1) {
+  {
     // the get_succ case: copy back only the used prefix
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const size_t m = (size_t)h_out->count[0];
@@ -624,14 +626,6 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
     if (h_out->state && m)
       HIP_TRY(c, hipMemcpy2DAsync(h_out->state, (size_t)h_out->state_stride * 8, d.state, (size_t)n_slots * 8, m * 8, F,
                                   hipMemcpyDeviceToHost, c->stream));
-  } else {
-    if (h_out->action) HIP_TRY(c, hipMemcpyAsync(h_out->action, d.action, (size_t)n_slots * 4, hipMemcpyDeviceToHost, c->stream));
-    if (h_out->cost) HIP_TRY(c, hipMemcpyAsync(h_out->cost, d.cost, (size_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
-    if (h_out->hash) HIP_TRY(c, hipMemcpyAsync(h_out->hash, d.hash, (size_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
-    if (h_out->iters) HIP_TRY(c, hipMemcpyAsync(h_out->iters, d.iters, (size_t)n_slots * 4, hipMemcpyDeviceToHost, c->stream));
-    if (h_out->state)
-      HIP_TRY(c, hipMemcpy2DAsync(h_out->state, (size_t)h_out->state_stride * 8, d.state, (size_t)n_slots * 8,
-                                  (size_t)n_slots * 8, F, hipMemcpyDeviceToHost, c->stream));
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return MPLX_OK;

@@ -61,6 +61,12 @@ struct mplx_ctx {
   mplx_detail::DevBuf d_status, d_cost, d_hash, d_state, d_iters;
   // staging for the host-pointer entry points
   mplx_detail::DevBuf s_nodes, s_status, s_cost, s_hash, s_state, s_iters, s_count, s_action;
+  // pipelined copy back of the lists (lists_copy_api.cpp): packed chunks on the device, pinned landing buffers
+  mplx_detail::DevBuf pk_dev[2], pk_offs;
+  void *pk_pin[2] = {nullptr, nullptr};
+  size_t pk_pin_cap = 0;
+  hipEvent_t pk_ev[2] = {nullptr, nullptr};
+  std::vector<int64_t> pk_hoffs;
   std::vector<uint8_t> h_status;
   std::vector<double> h_cost, h_state;
 };
@@ -108,6 +114,10 @@ inline void release(DevBuf &b) {
   b.p = nullptr;
   b.cap = 0;
 }
+
+// lists_copy_api.cpp: device lists -> host lists, only the used prefixes, pipelined through pinned memory
+int copy_lists_to_host(mplx_ctx *c, const mplx_succ_lists &d, const mplx_succ_lists *h_out, int64_t n_nodes);
+void release_copy_buffers(mplx_ctx *c);
 
 }  // namespace mplx_detail
 #endif

@@ -126,6 +126,20 @@ struct GridArgs {
   int64_t l_nstride;  // entries reserved per node (>= nU)
   int32_t l_pad;      // 1: complete the last 128-byte line of every list row (node stride is a multiple of 32)
 };
+// Packing of the used list prefixes for the copy back to the host (pack_kernel.hip).
+constexpr int kPackRows = 24;
+struct PackArgs {
+  const void *src[kPackRows];   // device rows, [n_nodes * node_stride] elements each
+  int64_t dst_off[kPackRows];   // byte offset of the row's packed block inside dst
+  int32_t es[kPackRows];        // element size, 4 or 8
+  int32_t n_rows;
+  int64_t node_stride;
+  const int32_t *count;         // [n_nodes]
+  const int64_t *offs;          // [n_nodes] exclusive prefix sum of count
+  int64_t node0, off0;          // first node of the chunk and its offs
+  char *dst;
+};
+hipError_t launch_pack_rows(const PackArgs &args, int64_t n_nodes, hipStream_t stream);
 size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap, int yaw_mode, int ndy);
 int grid_waves_per_block();
 hipError_t launch_expand_grid(int dim, int control, const GridArgs &args, hipStream_t stream);

@@ -383,9 +383,11 @@ class EnvMap:
         _abi.check(self._ctx, _abi.lib().mplx_expand(self._ctx, nodes.ctypes.data, n, n, C.byref(s)))
         return out
 
-    def expand_lists(self, nodes, want_state=True, want_iters=True, stride=None):
+    def expand_lists(self, nodes, want_state=True, want_iters=True, stride=None, out=None):
         """Per-node successor lists of a host frontier [4D+2][N] (mplx_expand_lists).
-        `stride` = entries reserved per node (default nU; out["stride"] reports it)."""
+        `stride` = entries reserved per node (default nU; out["stride"] reports it).
+        `out` = the dict a previous call with the same shapes returned: its arrays are reused (a C caller
+        keeps its buffers too; fresh arrays cost one page fault per 4 KiB written)."""
         self._flush()
         nodes = np.ascontiguousarray(nodes, dtype=np.float64)
         if nodes.ndim != 2 or nodes.shape[0] != self.n_fields:
@@ -393,17 +395,25 @@ class EnvMap:
         n = nodes.shape[1]
         stride = self.nU if stride is None else int(stride)
         ns = n * stride
-        out = {"stride": stride, "count": np.zeros(n, np.int32), "action": np.zeros(ns, np.int32),
-               "cost": np.zeros(ns, np.float64), "hash": np.zeros(ns, np.uint64)}
+        reuse = out is not None
+        if reuse:
+            if out["stride"] != stride or out["count"].shape != (n,) or (want_state and "state" not in out) or (
+                    want_iters and "iters" not in out):
+                raise ValueError("out does not match this call")
+        else:
+            out = {"stride": stride, "count": np.zeros(n, np.int32), "action": np.zeros(ns, np.int32),
+                   "cost": np.zeros(ns, np.float64), "hash": np.zeros(ns, np.uint64)}
         s = _abi.SuccLists()
         s.node_stride = stride
         s.count, s.action = out["count"].ctypes.data, out["action"].ctypes.data
         s.cost, s.hash = out["cost"].ctypes.data, out["hash"].ctypes.data
         if want_state:
-            out["state"] = np.zeros((self.n_fields, ns), np.float64)
+            if not reuse:
+                out["state"] = np.zeros((self.n_fields, ns), np.float64)
             s.state, s.state_stride = out["state"].ctypes.data, ns
         if want_iters:
-            out["iters"] = np.zeros(ns, np.int32)
+            if not reuse:
+                out["iters"] = np.zeros(ns, np.int32)
             s.iters = out["iters"].ctypes.data
         _abi.check(self._ctx, _abi.lib().mplx_expand_lists(self._ctx, nodes.ctypes.data, n, n, C.byref(s)))
         return out

@@ -289,6 +289,42 @@ def test_yaw_grid_and_dense_kernels_agree_bit_for_bit(engine):
     assert np.isfinite(a["cost"][live]).sum() > 1000
 
 
+def test_host_pointer_lists_pipelined_copy_back(engine):
+    """mplx_expand_lists with host arrays: the used list prefixes are packed on the device, copied in chunks through
+    pinned buffers and scattered by helper threads (lists_copy_api.cpp).  Several chunks and threads here; the
+    result must equal the HBM-resident lists entry by entry, also when the caller's arrays are reused."""
+    wl = engine.workloads.make("C4", scale=0.125, n_nodes=1800)
+    nU = wl.U.shape[0]
+    env = engine_env(engine, wl)
+    fr = env.upload_frontier(wl.nodes)
+    lists = env.alloc_lists(wl.n_nodes, want_state=True, want_iters=True)
+    env.expand_lists_resident(fr, lists)
+    env.synchronize()
+    ref = lists.download()
+    lists.free()
+    fr.free()
+    assert int(ref["count"].sum()) * 136 > 2 * (32 << 20)  # three 32-MiB chunks
+    live = (np.arange(ref["stride"])[None, :] < ref["count"][:, None]).ravel()
+    got = env.expand_lists(wl.nodes, stride=ref["stride"])
+    for rep in range(2):
+        assert np.array_equal(got["count"], ref["count"])
+        for name in ("action", "hash", "iters", "cost"):
+            assert np.array_equal(got[name][live].view(np.uint64 if got[name].itemsize == 8 else np.int32),
+                                  ref[name][live].view(np.uint64 if ref[name].itemsize == 8 else np.int32)), name
+        assert np.array_equal(got["state"][:, live].view(np.uint64), ref["state"][:, live].view(np.uint64))
+        for name in ("action", "hash", "iters", "cost"):
+            got[name][:] = 0
+        got["state"][:] = 0
+        got = env.expand_lists(wl.nodes, stride=ref["stride"], out=got)
+    # a frontier in which most nodes emit nothing (empty chunks, zero-length prefixes)
+    far = wl.nodes.copy()
+    far[:3, 5:] = -50.0  # outside the map: every primitive is blocked at its first sample, but still emitted
+    far[3:6, 5:] = 9.0   # and beyond v_max: nothing emitted at all
+    got = env.expand_lists(far)
+    assert got["count"][5:].sum() == 0 and np.array_equal(got["count"][:5], ref["count"][:5])
+    env.close()
+
+
 def test_forcing_a_route_outside_its_scope_fails_loudly(engine):
     wl = _small_world(engine, 2, 0x1F, seed=5, n_nodes=8)  # SNPxYAW: only the dense kernel covers it
     env = engine_env(engine, wl)
