@@ -236,8 +236,24 @@ int mplx_set_controls(mplx_ctx *c, const double *U, int32_t nU, int32_t udim) {
     }
     c->u_nd[slot] = n;
   }
+  c->u_lex = false;
   if (c->u_factored) {
     for (int k = c->dim; k < 3; k++) c->u_nd[k] = 0;
+    // nested-loop tables (first axis slowest, yaw rate fastest): control i <-> the i-th index combination
+    int64_t prod = 1;
+    for (int k = 0; k < c->dim; k++) prod *= c->u_nd[k];
+    const int ny = udim > c->dim ? c->u_nd[3] : 1;
+    prod *= ny;
+    if (prod == nU) {
+      c->u_lex = true;
+      for (int32_t i = 0; i < nU && c->u_lex; i++) {
+        int32_t r = i;
+        uint32_t want = 0;
+        if (udim > c->dim) { want |= (uint32_t)(r % ny) << 24; r /= ny; }
+        for (int k = c->dim - 1; k >= 0; k--) { want |= (uint32_t)(r % c->u_nd[k]) << (8 * k); r /= c->u_nd[k]; }
+        c->u_lex = want == packed[(size_t)i];
+      }
+    }
     if (int rc = ensure(c, c->uvals, sizeof vals)) return rc;
     if (int rc = ensure(c, c->uidx, (size_t)nU * 4)) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->uvals.p, vals, sizeof vals, hipMemcpyHostToDevice, c->stream));
@@ -482,6 +498,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.uidx = (const uint32_t *)c->uidx.p;
     a.nd0 = c->u_nd[0]; a.nd1 = c->u_nd[1]; a.nd2 = c->u_nd[2];
     a.ndp = gp.ndp;
+    a.ulex = (c->u_lex && !getenv("MPLX_GRID_NOLEX")) ? 1 : 0;
     a.nU = c->nU;
     a.nodes = d_nodes; a.n_nodes = n_nodes; a.node_stride = node_stride;
     a.n_max = gp.n_max; a.rmax = gp.rmax; a.boxcap = gp.boxcap; a.grid_limit = gp.grid;

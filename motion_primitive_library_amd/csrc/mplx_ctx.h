@@ -47,6 +47,7 @@ struct mplx_ctx {
   mplx_detail::DevBuf prep_lut, prep_a, prep_b;  // map preprocessing scratch (map_prep_api.cpp)
   bool blk_ok = false;   // blocked-bit map matches the current map + region
   bool u_factored = false;
+  bool u_lex = false;    // the table is the full Cartesian product of its per-axis values in lexicographic order
   int32_t u_nd[4] = {0, 0, 0, 0};  // distinct control values per axis; [3] = yaw rates
   int lists_route = MPLX_ROUTE_AUTO;
   int last_route = MPLX_ROUTE_AUTO;

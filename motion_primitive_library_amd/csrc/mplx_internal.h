@@ -104,6 +104,7 @@ struct GridArgs {
   const uint32_t *uidx;  // [nU] packed per-axis value indices
   int32_t nd0, nd1, nd2; // number of distinct values per axis
   int32_t ndy;           // distinct yaw rates (yaw controls)
+  int32_t ulex;          // 1: control i is the i-th combination of the per-axis values in lexicographic order
   int32_t ndp;           // table stride over values (max nd)
   int32_t nU;
   const double *nodes;

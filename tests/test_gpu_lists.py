@@ -325,6 +325,41 @@ def test_host_pointer_lists_pipelined_copy_back(engine):
     env.close()
 
 
+@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5"])
+def test_lexicographic_enumeration_equals_the_table_walk(engine, monkeypatch, name):
+    """Nested-loop control tables let phase A of the factorised kernel enumerate only the combinations of axis
+    entries that pass the limits (A.ulex); MPLX_GRID_NOLEX walks the whole table instead.  Same lists."""
+    wl = engine.workloads.make(name, scale=0.125, n_nodes=600)
+    out = []
+    for nolex in (False, True):
+        if nolex:
+            monkeypatch.setenv("MPLX_GRID_NOLEX", "1")
+        env = engine_env(engine, wl)
+        out.append(env.expand_lists(wl.nodes))
+        assert env.last_lists_route() == "grid"
+        env.close()
+    a, b = out
+    assert np.array_equal(a["count"], b["count"]) and a["count"].sum() > 1000
+    live = (np.arange(a["stride"])[None, :] < a["count"][:, None]).ravel()
+    for key in ("action", "hash", "iters", "cost"):
+        assert np.array_equal(a[key][live], b[key][live]), key
+    assert np.array_equal(a["state"][:, live].view(np.uint64), b["state"][:, live].view(np.uint64))
+    # a shuffled copy of the same table is not in nested-loop order: the table walk serves it, same successors
+    perm = np.random.default_rng(3).permutation(wl.U.shape[0])
+    wl.U = np.ascontiguousarray(wl.U[perm])
+    monkeypatch.delenv("MPLX_GRID_NOLEX", raising=False)
+    env = engine_env(engine, wl)
+    c = env.expand_lists(wl.nodes)
+    env.close()
+    assert np.array_equal(c["count"], a["count"])
+    S = a["stride"]
+    for k in (0, 17, 333):
+        n = a["count"][k]
+        assert np.array_equal(np.sort(perm[c["action"][k * S:k * S + n]]), a["action"][k * S:k * S + n])
+        order = np.argsort(perm[c["action"][k * S:k * S + n]])
+        assert np.array_equal(c["hash"][k * S:k * S + n][order], a["hash"][k * S:k * S + n])
+
+
 def test_forcing_a_route_outside_its_scope_fails_loudly(engine):
     wl = _small_world(engine, 2, 0x1F, seed=5, n_nodes=8)  # SNPxYAW: only the dense kernel covers it
     env = engine_env(engine, wl)
