@@ -14,8 +14,9 @@ replica of the map -- no data-path collective -- so scaling is
 
 Rank 0 prints ONE JSON line (see the task contract) including
   roofline     : algorithmic bytes per launch / HIP-event kernel time vs 8 TB/s
-  cpu_baseline : the CPU oracle ("port") timed on this box's host cores on a
-                 bounded sample of the same workload.
+  cpu_baseline : the reference's own headers compiled into oracle/_ref ("reference";
+                 the CPU oracle, "port", when that build is absent) timed on this
+                 box's host cores on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -74,12 +75,27 @@ def cpu_baseline(wl, target_seconds=12.0):
     sec_all, st = O.time_expand(oenv, wl.nodes[:, :n], threads=cores, reps=2)
     n1 = int(max(8, min(n, n // cores)))
     sec_1, _ = O.time_expand(oenv, wl.nodes[:, :n1], threads=1, reps=1)
+    port = {"value": n * nU / sec_all, "cores": cores, "value_1thread": n1 * nU / sec_1}
+    sample = "first %d of %d frontier nodes x %d controls (%d pairs, %d map samples) of %s" % (
+        n, wl.n_nodes, nU, n * nU, st["samples"], wl.name)
+    if os.path.exists(O.REF_SO):
+        # the reference's own headers (env_map.h / primitive.h / map_util.h) compiled where they lay into
+        # oracle/_ref/libmpl_ref.so (prebuilt; Eigen / Boost replaced by the stand-in headers of oracle/stub_include,
+        # neither is installed): the reference's CPU path itself, one env_map per thread over one shared MapUtil
+        sec_r, _ = O.time_expand(oenv, wl.nodes[:, :n], threads=cores, reps=2, ref=True)
+        sec_r1, _ = O.time_expand(oenv, wl.nodes[:, :n1], threads=1, reps=1, ref=True)
+        return {
+            "value": n * nU / sec_r, "unit": "pairs/s", "cores": cores, "kind": "reference",
+            "sample": sample + " in %.2f s on %d threads (reference headers built against stand-in Eigen/Boost); "
+                               "1 thread: %.4g pairs/s on %d nodes" % (sec_r, cores, n1 * nU / sec_r1, n1),
+            "value_1thread": n1 * nU / sec_r1,
+            "port": port,
+        }, oenv, n
     return {
-        "value": n * nU / sec_all, "unit": "pairs/s", "cores": cores, "kind": "port",
-        "sample": "first %d of %d frontier nodes x %d controls (%d pairs, %d map samples) of %s in %.2f s on %d threads; "
-                  "1 thread: %.4g pairs/s on %d nodes" % (n, wl.n_nodes, nU, n * nU, st["samples"], wl.name, sec_all,
-                                                          cores, n1 * nU / sec_1, n1),
-        "value_1thread": n1 * nU / sec_1,
+        "value": port["value"], "unit": "pairs/s", "cores": cores, "kind": "port",
+        "sample": sample + " in %.2f s on %d threads; 1 thread: %.4g pairs/s on %d nodes" % (
+            sec_all, cores, port["value_1thread"], n1),
+        "value_1thread": port["value_1thread"],
     }, oenv, n
 
 

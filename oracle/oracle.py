@@ -243,6 +243,7 @@ class RefPlanOut(C.Structure):
                 ("J", C.c_double * 4), ("wall_ms", C.c_double)]
 
 
+REF_SO = os.path.join(HERE, "_ref", "libmpl_ref.so")
 REF_PLANNER_SO = os.path.join(HERE, "_ref", "libmpl_ref_planner.so")
 
 

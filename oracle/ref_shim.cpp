@@ -22,6 +22,7 @@
 #include <cmath>
 #include <limits>
 #include <memory>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -34,14 +35,22 @@ struct Rig {
   std::shared_ptr<MPL::MapUtil<D>> map_util;
   std::unique_ptr<MPL::env_map<D>> env;
 
-  explicit Rig(const mpl_oracle_env *e) {
-    map_util = std::make_shared<MPL::MapUtil<D>>();
+  static std::shared_ptr<MPL::MapUtil<D>> make_map(const mpl_oracle_env *e) {
+    auto mu = std::make_shared<MPL::MapUtil<D>>();
     Vecf<D> ori;
     Veci<D> dim;
     size_t n = 1;
     for (int i = 0; i < D; i++) { ori(i) = e->origin[i]; dim(i) = e->map_dim[i]; n *= (size_t)e->map_dim[i]; }
     MPL::Tmap cells(e->map, e->map + n);
-    map_util->setMap(ori, dim, cells, e->res);
+    mu->setMap(ori, dim, cells, e->res);
+    return mu;
+  }
+
+  /* `shared`: a MapUtil built once for all threads of a run (env_map only reads it, env_map.h:288) */
+  explicit Rig(const mpl_oracle_env *e, std::shared_ptr<MPL::MapUtil<D>> shared = nullptr) {
+    map_util = shared ? shared : make_map(e);
+    size_t n = 1;
+    for (int i = 0; i < D; i++) n *= (size_t)e->map_dim[i];
     env.reset(new MPL::env_map<D>(map_util));
     vec_E<VecDf> U;
     for (int i = 0; i < e->nU; i++) {
@@ -121,10 +130,22 @@ int count_iters(const mpl_oracle_env *e, const MPL::MapUtil<D> &mu_c, const Prim
   return it;
 }
 
+/* start gate of a timed run: the threads set their env up, then all start together */
+struct Gate {
+  std::atomic<int> ready{0};
+  std::atomic<bool> go{false};
+  void arrive_and_wait() {
+    ready.fetch_add(1);
+    while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+  }
+};
+
 template <int D>
 void expand_range(const mpl_oracle_env *e, const double *nodes, int64_t n_nodes, int64_t lo, int64_t hi,
-                  mpl_oracle_out *out, mpl_oracle_stats *st, bool dense) {
-  Rig<D> rig(e);
+                  mpl_oracle_out *out, mpl_oracle_stats *st, bool dense,
+                  std::shared_ptr<MPL::MapUtil<D>> shared_map = nullptr, Gate *gate = nullptr) {
+  Rig<D> rig(e, shared_map);
+  if (gate) gate->arrive_and_wait();
   const int64_t n_slots = n_nodes * e->nU;
   vec_E<Waypoint<D>> succ;
   std::vector<decimal_t> cost;
@@ -190,15 +211,30 @@ void run_threads(int64_t n, int threads, F f) {
   for (auto &th : pool) th.join();
 }
 
+/* `seconds` (optional): wall time of the expansion alone -- one MapUtil shared by all threads, per-thread
+ * env_map objects set up before the clock starts */
 int run(const mpl_oracle_env *env, const double *nodes, int64_t n_nodes, mpl_oracle_out *out, int threads,
-        mpl_oracle_stats *stats, bool dense) {
+        mpl_oracle_stats *stats, bool dense, double *seconds = nullptr) {
   if (!env || (env->dim != 2 && env->dim != 3) || !env->map || !env->U || env->nU <= 0 || n_nodes < 0) return -1;
   if (threads < 1) threads = 1;
+  if ((int64_t)threads > n_nodes) threads = (int)std::max<int64_t>(1, n_nodes);
   std::vector<mpl_oracle_stats> per((size_t)threads, mpl_oracle_stats{0, 0, 0, 0, 0, 0, 0.0});
-  run_threads(n_nodes, threads, [&](int t, int64_t lo, int64_t hi) {
-    if (env->dim == 2) expand_range<2>(env, nodes, n_nodes, lo, hi, out, &per[(size_t)t], dense);
-    else expand_range<3>(env, nodes, n_nodes, lo, hi, out, &per[(size_t)t], dense);
+  std::shared_ptr<MPL::MapUtil<2>> m2;
+  std::shared_ptr<MPL::MapUtil<3>> m3;
+  if (env->dim == 2) m2 = Rig<2>::make_map(env); else m3 = Rig<3>::make_map(env);
+  Gate gate;
+  std::chrono::steady_clock::time_point t0;
+  std::thread starter([&] {
+    while (gate.ready.load() < threads) std::this_thread::yield();
+    t0 = std::chrono::steady_clock::now();
+    gate.go.store(true, std::memory_order_release);
   });
+  run_threads(n_nodes, threads, [&](int t, int64_t lo, int64_t hi) {
+    if (env->dim == 2) expand_range<2>(env, nodes, n_nodes, lo, hi, out, &per[(size_t)t], dense, m2, &gate);
+    else expand_range<3>(env, nodes, n_nodes, lo, hi, out, &per[(size_t)t], dense, m3, &gate);
+  });
+  starter.join();
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (stats) {
     *stats = {0, 0, 0, 0, 0, 0, 0.0};
     for (auto &p : per) add_stats(*stats, p);
@@ -219,9 +255,9 @@ double mpl_oracle_time_expand(const mpl_oracle_env *env, const double *nodes, in
                               int reps, mpl_oracle_stats *stats) {
   double best = 1e300;
   for (int r = 0; r < (reps < 1 ? 1 : reps); r++) {
-    auto t0 = std::chrono::steady_clock::now();
-    if (run(env, nodes, n_nodes, nullptr, threads, stats, false) != 0) return -1.0;
-    best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    double sec = 0;
+    if (run(env, nodes, n_nodes, nullptr, threads, stats, false, &sec) != 0) return -1.0;
+    best = std::min(best, sec);
   }
   return best;
 }
