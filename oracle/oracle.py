@@ -270,6 +270,36 @@ def ref_plan(env, start_row, goal_row, use_gpu=False, epsilon=1.0, reps=1):
             "wall_ms": out.wall_ms, "device_launches": out.hm_size}
 
 
+def ref_distance_plan(env, start_row, goal_row, use_gpu=False, with_yaw=False):
+    """The reference's distance-map scenario end to end (test/test_distance_map_planner_2d.cpp and
+    ..._with_yaw.cpp): plan on the raw map, then a second MapPlanner with a search region around that trajectory
+    and a potential map (with yaw: iterativePlan over U x three yaw rates).  use_gpu: MPL::GpuMapPlanner instead of
+    MPL::MapPlanner in both stages (> 1: speculative batch size).  Returns the two stages' summaries."""
+    lib = _LIBS.setdefault("ref_planner", C.CDLL(REF_PLANNER_SO))
+    lib.mpl_ref_distance_plan.restype = C.c_int
+    lib.mpl_ref_distance_plan.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                          C.POINTER(RefPlanOut), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int64)]
+    s = np.ascontiguousarray(start_row, dtype=np.float64)
+    g = np.ascontiguousarray(goal_row, dtype=np.float64)
+    out = (RefPlanOut * 2)()
+    chk = (C.c_double * 2)()
+    region, pot = C.c_int64(0), C.c_int64(0)
+    ce = env._c()
+    rc = lib.mpl_ref_distance_plan(C.byref(ce), s.ctypes.data, g.ctypes.data, int(use_gpu), int(with_yaw), out, chk,
+                                   C.byref(region), C.byref(pot))
+    if rc != 0:
+        raise RuntimeError("mpl_ref_distance_plan failed: %d" % rc)
+    res = []
+    for i in range(2):
+        o = out[i]
+        res.append({"ok": bool(o.ok), "closed": o.closed, "opened": o.opened, "expansions": o.expansions,
+                    "segments": o.segments, "cost": o.cost, "total_time": o.total_time, "J": list(o.J),
+                    "wall_ms": o.wall_ms, "device_launches": o.hm_size, "traj_checksum": chk[i]})
+    res[1]["region_cells"], res[1]["potential_sum"] = region.value, pot.value
+    return res
+
+
 # ---- map preprocessing (SURVEY.md 8f-3): restatement, and the reference's own MapPlanner via the shim
 def _prep_lib(ref):
     """ref: False = the restatement, True = the reference's MapPlanner, "gpu" = the reference's

@@ -107,6 +107,144 @@ extern "C" int mpl_ref_plan(const mpl_oracle_env *env, const double *start, cons
   return -1;
 }
 
+/* ---- the reference's distance-map scenarios end to end (test/test_distance_map_planner_2d.cpp:48-98 and
+ * test/test_distance_map_planner_2d_with_yaw.cpp:48-104): plan on the raw map, then a second planner with a search
+ * region around that trajectory and a potential map; with yaw the second stage is iterativePlan over a control
+ * table extended by three yaw rates.  PlannerT = MPL::MapPlanner<D> (CPU) or MPL::GpuMapPlanner<D> (the drop-in:
+ * get_succ, updatePotentialMap and setSearchRegion on the device). ---- */
+namespace {
+
+template <int D> int planner_launches(MPL::MapPlanner<D> &);
+template <int D> int planner_launches(MPL::GpuMapPlanner<D> &);
+template <int D> void set_batch(MPL::MapPlanner<D> &, int);
+template <int D> void set_batch(MPL::GpuMapPlanner<D> &, int);
+
+template <int D>
+void fill_out(MPL::MapPlanner<D> &pl, bool ok, double ms, int launches, mpl_ref_plan_out *o, double *checksum) {
+  o->ok = ok ? 1 : 0;
+  o->wall_ms = ms;
+  o->closed = (int32_t)pl.getCloseSet().size();
+  o->opened = (int32_t)pl.getOpenSet().size();
+  o->expansions = pl.getExpandedNum();
+  const Trajectory<D> traj = pl.getTraj();
+  o->segments = (int32_t)traj.getPrimitives().size();
+  o->total_time = traj.getTotalTime();
+  o->J[0] = traj.J(Control::VEL);
+  o->J[1] = traj.J(Control::ACC);
+  o->J[2] = traj.J(Control::JRK);
+  o->J[3] = traj.J(Control::SNP);
+  o->cost = pl.getTrajCost();
+  o->hm_size = launches;
+  double c = 0;
+  int k = 1;
+  for (const auto &w : traj.getWaypoints()) {
+    for (int i = 0; i < D; i++) c += k * (w.pos(i) + 3.0 * w.vel(i));
+    c += 7.0 * k * w.yaw;
+    k++;
+  }
+  *checksum = c;
+}
+
+template <int D, class PlannerT>
+int run_distance(const mpl_oracle_env *e, const double *start_row, const double *goal_row, int with_yaw, int batch,
+                 mpl_ref_plan_out *out, double *checksum, int64_t *region_cells, int64_t *potential_sum) {
+  std::shared_ptr<MPL::MapUtil<D>> mu = std::make_shared<MPL::MapUtil<D>>();
+  Vecf<D> ori;
+  Veci<D> dim;
+  size_t n = 1;
+  for (int i = 0; i < D; i++) { ori(i) = e->origin[i]; dim(i) = e->map_dim[i]; n *= (size_t)e->map_dim[i]; }
+  mu->setMap(ori, dim, MPL::Tmap(e->map, e->map + n), e->res);
+  vec_E<VecDf> U, U_yaw;
+  for (int i = 0; i < e->nU; i++) {
+    VecDf u(D), uy(D + 1);
+    for (int k = 0; k < D; k++) u(k) = uy(k) = e->U[(size_t)i * e->udim + k];
+    U.push_back(u);
+    for (int y = -1; y <= 1; y++) { uy(D) = 0.5 * y; U_yaw.push_back(uy); }
+  }
+  auto load = [&](const double *r, int control) {
+    Waypoint<D> w((Control::Control)control);
+    for (int i = 0; i < D; i++) {
+      w.pos(i) = r[i]; w.vel(i) = r[D + i]; w.acc(i) = r[2 * D + i]; w.jrk(i) = r[3 * D + i];
+    }
+    w.yaw = r[4 * D];
+    w.t = r[4 * D + 1];
+    return w;
+  };
+  const int base = e->control & 0x0f;
+  Waypoint<D> start = load(start_row, base);
+  const Waypoint<D> goal = load(goal_row, base);  // the goal keeps the control without yaw (…_with_yaw.cpp:47, 97)
+  auto make = [&](PlannerT &pl, const vec_E<VecDf> &u) {
+    pl.setMapUtil(mu);
+    pl.setVmax(e->v_max);
+    pl.setAmax(e->a_max);
+    pl.setDt(e->dt);
+    pl.setU(u);
+  };
+  auto launches = [&](PlannerT &pl) { return planner_launches(pl); };
+  // stage 1
+  PlannerT first(false);
+  set_batch(first, batch);
+  make(first, U);
+  auto t0 = std::chrono::steady_clock::now();
+  bool ok = first.plan(start, goal);
+  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  fill_out<D>(first, ok, ms, launches(first), &out[0], &checksum[0]);
+  if (!ok) return 0;
+  const Trajectory<D> traj = first.getTraj();
+  vec_Vecf<D> path;
+  for (const auto &w : traj.getWaypoints()) path.push_back(w.pos);
+  // stage 2
+  PlannerT second(false);
+  set_batch(second, batch);
+  make(second, with_yaw ? U_yaw : U);
+  second.setEpsilon(1.0);
+  Vecf<D> rad;
+  for (int i = 0; i < D; i++) rad(i) = 0.5;
+  second.setSearchRadius(rad);
+  if (!with_yaw) second.setSearchRegion(path);
+  for (int i = 0; i < D; i++) rad(i) = 1.0;
+  second.setPotentialRadius(rad);
+  second.setPotentialWeight(0.5);
+  second.setGradientWeight(0);
+  second.updatePotentialMap(start.pos);
+  t0 = std::chrono::steady_clock::now();
+  if (with_yaw) {
+    start.use_yaw = true;
+    second.setYawmax(0.5);
+    ok = second.iterativePlan(start, goal, traj, 10);
+  } else {
+    ok = second.plan(start, goal);
+  }
+  ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  fill_out<D>(second, ok, ms, launches(second), &out[1], &checksum[1]);
+  *region_cells = (int64_t)second.getSearchRegion().size();
+  int64_t ps = 0;
+  for (const auto v : mu->getMap()) ps += v;  // updatePotentialMap rewrites the MapUtil's map (map_planner.cpp:387)
+  *potential_sum = ps;
+  return 0;
+}
+
+template <int D>
+int planner_launches(MPL::MapPlanner<D> &) { return 0; }
+template <int D>
+int planner_launches(MPL::GpuMapPlanner<D> &p) { return p.deviceLaunches(); }
+template <int D>
+void set_batch(MPL::MapPlanner<D> &, int) {}
+template <int D>
+void set_batch(MPL::GpuMapPlanner<D> &p, int b) { p.setBatch(b > 1 ? b : 1); }
+
+}  // namespace
+
+extern "C" int mpl_ref_distance_plan(const mpl_oracle_env *env, const double *start, const double *goal, int use_gpu,
+                                     int with_yaw, mpl_ref_plan_out *out2, double *checksum2, int64_t *region_cells,
+                                     int64_t *potential_sum) {
+  if (!env || !start || !goal || !out2 || env->dim != 2) return -1;
+  if (use_gpu)
+    return run_distance<2, MPL::GpuMapPlanner<2>>(env, start, goal, with_yaw, use_gpu, out2, checksum2, region_cells,
+                                                  potential_sum);
+  return run_distance<2, MPL::MapPlanner<2>>(env, start, goal, with_yaw, 1, out2, checksum2, region_cells, potential_sum);
+}
+
 /* ---- map preprocessing through the reference's own MapPlanner (map_planner.cpp:46-95, 246-391) ---- */
 namespace {
 
