@@ -270,14 +270,18 @@ def ref_plan(env, start_row, goal_row, use_gpu=False, epsilon=1.0, reps=1):
             "wall_ms": out.wall_ms, "device_launches": out.hm_size}
 
 
-def ref_distance_plan(env, start_row, goal_row, use_gpu=False, with_yaw=False):
-    """The reference's distance-map scenario end to end (test/test_distance_map_planner_2d.cpp and
-    ..._with_yaw.cpp): plan on the raw map, then a second MapPlanner with a search region around that trajectory
-    and a potential map (with yaw: iterativePlan over U x three yaw rates).  use_gpu: MPL::GpuMapPlanner instead of
-    MPL::MapPlanner in both stages (> 1: speculative batch size).  Returns the two stages' summaries."""
+SCENARIOS = {"distance": 0, "distance_yaw": 1, "distance_iterative": 2, "yaw": 3, "prior_traj": 4}
+
+
+def ref_scenario(env, start_row, goal_row, scenario, use_gpu=False):
+    """The scenarios of the reference's own test programs end to end, on the reference's MapPlanner:
+    "distance" (test_distance_map_planner_2d.cpp), "distance_yaw" (..._with_yaw.cpp), "distance_iterative"
+    (..._iterative.cpp), "yaw" (test_planner_2d_with_yaw.cpp; one stage), "prior_traj"
+    (test_planner_2d_with_prior_traj.cpp).  env.U must be the {-0.5, 0, 0.5}^2 table.  use_gpu: MPL::GpuMapPlanner
+    instead of MPL::MapPlanner in every stage (> 1: speculative batch size).  Returns the two stages' summaries."""
     lib = _LIBS.setdefault("ref_planner", C.CDLL(REF_PLANNER_SO))
-    lib.mpl_ref_distance_plan.restype = C.c_int
-    lib.mpl_ref_distance_plan.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+    lib.mpl_ref_scenario.restype = C.c_int
+    lib.mpl_ref_scenario.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                           C.POINTER(RefPlanOut), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                           C.POINTER(C.c_int64)]
     s = np.ascontiguousarray(start_row, dtype=np.float64)
@@ -286,10 +290,10 @@ def ref_distance_plan(env, start_row, goal_row, use_gpu=False, with_yaw=False):
     chk = (C.c_double * 2)()
     region, pot = C.c_int64(0), C.c_int64(0)
     ce = env._c()
-    rc = lib.mpl_ref_distance_plan(C.byref(ce), s.ctypes.data, g.ctypes.data, int(use_gpu), int(with_yaw), out, chk,
+    rc = lib.mpl_ref_scenario(C.byref(ce), s.ctypes.data, g.ctypes.data, int(use_gpu), SCENARIOS[scenario], out, chk,
                                    C.byref(region), C.byref(pot))
     if rc != 0:
-        raise RuntimeError("mpl_ref_distance_plan failed: %d" % rc)
+        raise RuntimeError("mpl_ref_scenario failed: %d" % rc)
     res = []
     for i in range(2):
         o = out[i]

@@ -107,8 +107,9 @@ extern "C" int mpl_ref_plan(const mpl_oracle_env *env, const double *start, cons
   return -1;
 }
 
-/* ---- the reference's distance-map scenarios end to end (test/test_distance_map_planner_2d.cpp:48-98 and
- * test/test_distance_map_planner_2d_with_yaw.cpp:48-104): plan on the raw map, then a second planner with a search
+/* ---- the scenarios of the reference's own tests end to end (test/test_distance_map_planner_2d.cpp:48-98,
+ * ..._with_yaw.cpp:48-104, ..._iterative.cpp:48-89, test_planner_2d_with_yaw.cpp:29-67,
+ * test_planner_2d_with_prior_traj.cpp:29-102): e.g. plan on the raw map, then a second planner with a search
  * region around that trajectory and a potential map; with yaw the second stage is iterativePlan over a control
  * table extended by three yaw rates.  PlannerT = MPL::MapPlanner<D> (CPU) or MPL::GpuMapPlanner<D> (the drop-in:
  * get_succ, updatePotentialMap and setSearchRegion on the device). ---- */
@@ -145,8 +146,10 @@ void fill_out(MPL::MapPlanner<D> &pl, bool ok, double ms, int launches, mpl_ref_
   *checksum = c;
 }
 
+/* mode: 0 test_distance_map_planner_2d, 1 ..._with_yaw, 2 ..._iterative, 3 test_planner_2d_with_yaw (one stage),
+ *       4 test_planner_2d_with_prior_traj (VEL plan, then JRK-state plan guided by it) */
 template <int D, class PlannerT>
-int run_distance(const mpl_oracle_env *e, const double *start_row, const double *goal_row, int with_yaw, int batch,
+int run_scenario(const mpl_oracle_env *e, const double *start_row, const double *goal_row, int mode, int batch,
                  mpl_ref_plan_out *out, double *checksum, int64_t *region_cells, int64_t *potential_sum) {
   std::shared_ptr<MPL::MapUtil<D>> mu = std::make_shared<MPL::MapUtil<D>>();
   Vecf<D> ori;
@@ -154,11 +157,12 @@ int run_distance(const mpl_oracle_env *e, const double *start_row, const double 
   size_t n = 1;
   for (int i = 0; i < D; i++) { ori(i) = e->origin[i]; dim(i) = e->map_dim[i]; n *= (size_t)e->map_dim[i]; }
   mu->setMap(ori, dim, MPL::Tmap(e->map, e->map + n), e->res);
-  vec_E<VecDf> U, U_yaw;
+  vec_E<VecDf> U, U_yaw, U_unit;
   for (int i = 0; i < e->nU; i++) {
-    VecDf u(D), uy(D + 1);
-    for (int k = 0; k < D; k++) u(k) = uy(k) = e->U[(size_t)i * e->udim + k];
+    VecDf u(D), uy(D + 1), u1(D);
+    for (int k = 0; k < D; k++) { u(k) = uy(k) = e->U[(size_t)i * e->udim + k]; u1(k) = 2.0 * u(k); }
     U.push_back(u);
+    U_unit.push_back(u1);  // {-1, 0, 1}^D when U is {-0.5, 0, 0.5}^D (test_planner_2d_with_prior_traj.cpp:47-52)
     for (int y = -1; y <= 1; y++) { uy(D) = 0.5 * y; U_yaw.push_back(uy); }
   }
   auto load = [&](const double *r, int control) {
@@ -171,8 +175,10 @@ int run_distance(const mpl_oracle_env *e, const double *start_row, const double 
     return w;
   };
   const int base = e->control & 0x0f;
-  Waypoint<D> start = load(start_row, base);
-  const Waypoint<D> goal = load(goal_row, base);  // the goal keeps the control without yaw (…_with_yaw.cpp:47, 97)
+  *region_cells = 0;
+  *potential_sum = 0;
+  out[0] = out[1] = mpl_ref_plan_out{};
+  checksum[0] = checksum[1] = 0;
   auto make = [&](PlannerT &pl, const vec_E<VecDf> &u) {
     pl.setMapUtil(mu);
     pl.setVmax(e->v_max);
@@ -180,15 +186,65 @@ int run_distance(const mpl_oracle_env *e, const double *start_row, const double 
     pl.setDt(e->dt);
     pl.setU(u);
   };
-  auto launches = [&](PlannerT &pl) { return planner_launches(pl); };
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(now() - t0).count();
+  };
+
+  if (mode == 3) {
+    // test_planner_2d_with_yaw.cpp:29-67: ACCxYAW from yaw = pi/2, yaw_max = 0.7
+    Waypoint<D> start = load(start_row, base | 0x10);
+    start.yaw = M_PI / 2;
+    Waypoint<D> goal = load(goal_row, base | 0x10);
+    PlannerT pl(false);
+    set_batch(pl, batch);
+    make(pl, U_yaw);
+    pl.setYawmax(0.7);
+    auto t0 = now();
+    const bool ok = pl.plan(start, goal);
+    fill_out<D>(pl, ok, ms_since(t0), planner_launches(pl), &out[0], &checksum[0]);
+    return 0;
+  }
+  if (mode == 4) {
+    // test_planner_2d_with_prior_traj.cpp:29-102
+    Waypoint<D> start = load(start_row, 0x01), goal = load(goal_row, 0x01);
+    PlannerT first(false);
+    set_batch(first, batch);
+    make(first, U_unit);
+    auto t0 = now();
+    bool ok = first.plan(start, goal);
+    fill_out<D>(first, ok, ms_since(t0), planner_launches(first), &out[0], &checksum[0]);
+    if (!ok) return 0;
+    const Trajectory<D> prior = first.getTraj();
+    start.use_vel = true;
+    start.use_acc = true;  // goal keeps the VEL flag (…prior_traj.cpp:45)
+    PlannerT second(false);
+    set_batch(second, batch);
+    second.setMapUtil(mu);
+    second.setEpsilon(1.0);
+    second.setVmax(e->v_max);
+    second.setAmax(e->a_max);
+    second.setDt(e->dt);
+    second.setW(10);
+    second.setU(U);
+    second.setTol(0.5);
+    second.setPriorTrajectory(prior);
+    t0 = now();
+    ok = second.plan(start, goal);
+    fill_out<D>(second, ok, ms_since(t0), planner_launches(second), &out[1], &checksum[1]);
+    return 0;
+  }
+
+  const bool with_yaw = mode == 1;
+  Waypoint<D> start = load(start_row, base);
+  const Waypoint<D> goal = load(goal_row, base);  // the goal keeps the control without yaw (…_with_yaw.cpp:47, 97)
   // stage 1
   PlannerT first(false);
   set_batch(first, batch);
   make(first, U);
-  auto t0 = std::chrono::steady_clock::now();
+  auto t0 = now();
   bool ok = first.plan(start, goal);
-  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  fill_out<D>(first, ok, ms, launches(first), &out[0], &checksum[0]);
+  fill_out<D>(first, ok, ms_since(t0), planner_launches(first), &out[0], &checksum[0]);
   if (!ok) return 0;
   const Trajectory<D> traj = first.getTraj();
   vec_Vecf<D> path;
@@ -201,22 +257,20 @@ int run_distance(const mpl_oracle_env *e, const double *start_row, const double 
   Vecf<D> rad;
   for (int i = 0; i < D; i++) rad(i) = 0.5;
   second.setSearchRadius(rad);
-  if (!with_yaw) second.setSearchRegion(path);
+  if (mode == 0) second.setSearchRegion(path);
   for (int i = 0; i < D; i++) rad(i) = 1.0;
   second.setPotentialRadius(rad);
   second.setPotentialWeight(0.5);
   second.setGradientWeight(0);
   second.updatePotentialMap(start.pos);
-  t0 = std::chrono::steady_clock::now();
+  t0 = now();
   if (with_yaw) {
     start.use_yaw = true;
     second.setYawmax(0.5);
-    ok = second.iterativePlan(start, goal, traj, 10);
-  } else {
-    ok = second.plan(start, goal);
   }
-  ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  fill_out<D>(second, ok, ms, launches(second), &out[1], &checksum[1]);
+  if (mode == 0) ok = second.plan(start, goal);
+  else ok = second.iterativePlan(start, goal, traj, 10);
+  fill_out<D>(second, ok, ms_since(t0), planner_launches(second), &out[1], &checksum[1]);
   *region_cells = (int64_t)second.getSearchRegion().size();
   int64_t ps = 0;
   for (const auto v : mu->getMap()) ps += v;  // updatePotentialMap rewrites the MapUtil's map (map_planner.cpp:387)
@@ -235,14 +289,14 @@ void set_batch(MPL::GpuMapPlanner<D> &p, int b) { p.setBatch(b > 1 ? b : 1); }
 
 }  // namespace
 
-extern "C" int mpl_ref_distance_plan(const mpl_oracle_env *env, const double *start, const double *goal, int use_gpu,
-                                     int with_yaw, mpl_ref_plan_out *out2, double *checksum2, int64_t *region_cells,
-                                     int64_t *potential_sum) {
-  if (!env || !start || !goal || !out2 || env->dim != 2) return -1;
+extern "C" int mpl_ref_scenario(const mpl_oracle_env *env, const double *start, const double *goal, int use_gpu,
+                                int mode, mpl_ref_plan_out *out2, double *checksum2, int64_t *region_cells,
+                                int64_t *potential_sum) {
+  if (!env || !start || !goal || !out2 || env->dim != 2 || mode < 0 || mode > 4) return -1;
   if (use_gpu)
-    return run_distance<2, MPL::GpuMapPlanner<2>>(env, start, goal, with_yaw, use_gpu, out2, checksum2, region_cells,
+    return run_scenario<2, MPL::GpuMapPlanner<2>>(env, start, goal, mode, use_gpu, out2, checksum2, region_cells,
                                                   potential_sum);
-  return run_distance<2, MPL::MapPlanner<2>>(env, start, goal, with_yaw, 1, out2, checksum2, region_cells, potential_sum);
+  return run_scenario<2, MPL::MapPlanner<2>>(env, start, goal, mode, 1, out2, checksum2, region_cells, potential_sum);
 }
 
 /* ---- map preprocessing through the reference's own MapPlanner (map_planner.cpp:46-95, 246-391) ---- */

@@ -120,15 +120,17 @@ def test_c1_reference_planner_itself_and_host_search_agree(engine):
     assert s["expansions"] == r["expansions"] and s["opened"] == r["opened"] and s["segments"] == r["segments"]
 
 
-@pytest.mark.parametrize("with_yaw,closed,cost,T,region", [(False, 2732, 647.0999999999999, 36.0, 17351),
-                                                          (True, 25326, 617.7304404847963, 37.0, 20911)])
-def test_reference_distance_map_scenarios_on_the_cpu(with_yaw, closed, cost, T, region):
-    """The reference's own MapPlanner through its distance-map test scenarios (oracle/_ref, where built): the
+@pytest.mark.parametrize("scenario,closed,cost,T,region", [
+    ("distance", 2732, 647.0999999999999, 36.0, 17351),
+    ("distance_yaw", 25326, 617.7304404847963, 37.0, 20911),
+    ("distance_iterative", 3419, 617.45, 37.0, 20911),
+    ("yaw", 1342, 352.4275550988982, 35.0, 0),
+    ("prior_traj", 628, 353.5, 35.0, 0)])
+def test_reference_test_scenarios_on_the_cpu(scenario, closed, cost, T, region):
+    """The reference's own MapPlanner through the scenarios of its test programs (oracle/_ref, where built): the
     numbers the GPU drop-in is compared with in tests/test_gpu_plan.py, pinned here so that a change of the
     stand-in headers or of the shim shows up."""
-    import os
     import motion_primitive_library_amd as m
-    from oracle import oracle as O
     if not os.path.exists(O.REF_PLANNER_SO):
         pytest.skip("oracle/_ref/libmpl_ref_planner.so not built")
     c = corridor()
@@ -136,7 +138,9 @@ def test_reference_distance_map_scenarios_on_the_cpu(with_yaw, closed, cost, T, 
     oenv = O.Env(2, O.ACC, U, c["cells"], c["dim"], c["origin"], c["res"], v_max=1.0, a_max=1.0, dt=1.0)
     start = m.Waypoint(2, m.ACC, pos=c["start"]).to_row()
     goal = m.Waypoint(2, m.ACC, pos=c["goal"]).to_row()
-    r = O.ref_distance_plan(oenv, start, goal, use_gpu=False, with_yaw=with_yaw)
-    assert r[0]["closed"] == 615 and r[0]["total_time"] == 35.0 and r[0]["J"][:2] == [36.75, 1.5]  # README.md:199-202
-    assert r[1]["ok"] and r[1]["closed"] == closed and r[1]["total_time"] == T and r[1]["region_cells"] == region
-    assert abs(r[1]["cost"] - cost) <= 1e-12 * cost
+    r = O.ref_scenario(oenv, start, goal, scenario)
+    last = r[0] if scenario == "yaw" else r[1]
+    if scenario.startswith("distance"):  # stage 1 is test_planner_2d itself: README.md:199-202
+        assert r[0]["closed"] == 615 and r[0]["total_time"] == 35.0 and r[0]["J"][:2] == [36.75, 1.5]
+    assert last["ok"] and last["closed"] == closed and last["total_time"] == T
+    assert r[1]["region_cells"] == region and abs(last["cost"] - cost) <= 1e-12 * cost
