@@ -630,9 +630,20 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
   }
   d.node_stride = h_out->node_stride;
   if (int rc = lists_device(c, (const double *)c->s_nodes.p, n_nodes, n_nodes, &d)) return rc;
-  if (n_nodes > 1) return mplx_detail::copy_lists_to_host(c, d, h_out, n_nodes);  // used prefixes only, pipelined
+  // large batches: only the used prefixes cross the link, pipelined (lists_copy_api.cpp); small ones (the
+  // speculative batches of a search on a small control table) are latency bound: one round of plain copies
+  const bool small = (size_t)n_slots * (size_t)(F * 8 + 24) <= ((size_t)256 << 10);
+  if (n_nodes > 1 && !small) return mplx_detail::copy_lists_to_host(c, d, h_out, n_nodes);
   HIP_TRY(c, hipMemcpyAsync(h_out->count, d.count, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, c->stream));
-  {
+  if (n_nodes > 1) {
+    if (h_out->action) HIP_TRY(c, hipMemcpyAsync(h_out->action, d.action, (size_t)n_slots * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_out->cost) HIP_TRY(c, hipMemcpyAsync(h_out->cost, d.cost, (size_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
+    if (h_out->hash) HIP_TRY(c, hipMemcpyAsync(h_out->hash, d.hash, (size_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
+    if (h_out->iters) HIP_TRY(c, hipMemcpyAsync(h_out->iters, d.iters, (size_t)n_slots * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_out->state)
+      HIP_TRY(c, hipMemcpy2DAsync(h_out->state, (size_t)h_out->state_stride * 8, d.state, (size_t)n_slots * 8,
+                                  (size_t)n_slots * 8, F, hipMemcpyDeviceToHost, c->stream));
+  } else {
     // the get_succ case: copy back only the used prefix
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const size_t m = (size_t)h_out->count[0];
