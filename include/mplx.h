@@ -314,6 +314,10 @@ int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, 
 /* Trajectory of the last successful plan: segment start states [segments][4D+2]
  * and the control index of each segment (env_base::forward_action).          */
 int mplx_planner_trajectory(mplx_planner *p, double *nodes, int32_t *actions, int32_t cap_segments);
+/* The state the last segment reaches (4D+2 doubles): with the segment start states, the way points of
+ * Trajectory::getWaypoints (trajectory.h), which MapPlanner::iterativePlan turns into the next search region
+ * (map_planner.cpp:404-410).                                                   */
+int mplx_planner_trajectory_end(mplx_planner *p, double *node);
 /* Closed-set positions of the last plan (PlannerBase::getCloseSet): fills up
  * to cap points of D doubles; *n receives the closed-set size.               */
 int mplx_planner_closed_set(mplx_planner *p, double *pos, int32_t cap, int32_t *n);

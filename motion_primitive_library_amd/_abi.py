@@ -24,7 +24,7 @@ SYMBOLS = [
     "mplx_synchronize", "mplx_timer_begin", "mplx_timer_end",
     "mplx_planner_create", "mplx_planner_destroy", "mplx_planner_attach_ctx", "mplx_planner_set_provider",
     "mplx_planner_set_map", "mplx_planner_set_controls", "mplx_planner_configure", "mplx_planner_plan",
-    "mplx_planner_trajectory", "mplx_planner_closed_set", "mplx_planner_open_set", "mplx_planner_last_error",
+    "mplx_planner_trajectory", "mplx_planner_trajectory_end", "mplx_planner_closed_set", "mplx_planner_open_set", "mplx_planner_last_error",
     "mplx_selftest_math", "mplx_set_lists_route", "mplx_last_lists_route", "mplx_device_info",
 ]
 
@@ -146,6 +146,7 @@ def lib():
         "mplx_planner_configure": (C.c_int, [vp, C.POINTER(PlannerConfig)]),
         "mplx_planner_plan": (C.c_int, [vp, vp, vp, C.POINTER(PlanSummary)]),
         "mplx_planner_trajectory": (C.c_int, [vp, vp, vp, i32]),
+        "mplx_planner_trajectory_end": (C.c_int, [vp, vp]),
         "mplx_planner_closed_set": (C.c_int, [vp, vp, i32, C.POINTER(i32)]),
         "mplx_planner_open_set": (C.c_int, [vp, vp, i32, C.POINTER(i32)]),
         "mplx_planner_last_error": (C.c_char_p, [vp]),

@@ -299,6 +299,7 @@ struct PlanResult {
   double J[4] = {0, 0, 0, 0};  // J(VEL), J(ACC), J(JRK), J(SNP) of the trajectory
   std::vector<double> traj_nodes;  // [segments][4D+2] start state of each primitive
   std::vector<int32_t> traj_actions;
+  std::vector<double> traj_end;    // [4D+2] the state the last primitive reaches (the last of Trajectory::getWaypoints)
 };
 
 class Planner {
@@ -555,6 +556,7 @@ class Planner {
   bool recover(NodePtr curr, const double *start) {
     const int f = F();
     const uint64_t start_key = lattice_hash(dim, control, start);
+    last.traj_end.assign(curr->coord, curr->coord + f);
     std::vector<std::vector<double>> from;
     std::vector<int32_t> acts;
     bool found = false;

@@ -164,6 +164,14 @@ int mplx_planner_trajectory(mplx_planner *p, double *nodes, int32_t *actions, in
   return MPLX_OK;
 }
 
+int mplx_planner_trajectory_end(mplx_planner *p, double *node) {
+  if (!p || !node) return MPLX_ERR_ARG;
+  const mplx::host::PlanResult &r = p->pl.last;
+  if (!r.ok || (int)r.traj_end.size() != p->pl.F()) return fail(p, MPLX_ERR_STATE, "mplx_planner_trajectory_end: no trajectory");
+  for (int k = 0; k < p->pl.F(); k++) node[k] = r.traj_end[(size_t)k];
+  return MPLX_OK;
+}
+
 int mplx_planner_closed_set(mplx_planner *p, double *pos, int32_t cap, int32_t *n) {
   if (!p || !n) return MPLX_ERR_ARG;
   int32_t m = 0;

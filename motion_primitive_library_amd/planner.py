@@ -36,8 +36,15 @@ class MapUtil:
 class Trajectory:
     """What the reference's tests read off Trajectory<Dim> (trajectory.h)."""
 
-    def __init__(self, total_time, J, nodes, actions, cost):
-        self._T, self._J, self.nodes, self.actions, self.cost = total_time, J, nodes, actions, cost
+    def __init__(self, total_time, J, nodes, actions, cost, end=None):
+        self._T, self._J, self.nodes, self.actions, self.cost, self.end = total_time, J, nodes, actions, cost, end
+
+    def getWaypoints(self):
+        """Rows of 4D+2: the start state of every primitive and the state the last one reaches
+        (Trajectory::getWaypoints, trajectory.h)."""
+        if self.end is None or len(self.nodes) == 0:
+            return np.asarray(self.nodes)
+        return np.vstack([self.nodes, self.end[None, :]])
 
     def getTotalTime(self):
         return self._T
@@ -65,6 +72,10 @@ class MapPlanner:
         self._cfg.tol_pos, self._cfg.tol_vel, self._cfg.tol_acc, self._cfg.tol_yaw = 0.5, -1.0, -1.0, -1.0
         self.env = None
         self._keep = provider
+        self._map_util = None
+        self._search_radius = None
+        self._potential_radius, self._potential_range, self._pow = None, None, 1.0
+        self._traj = None
         if provider is None:
             self.env = EnvMap(dim, device)
             self._check(self._L.mplx_planner_attach_ctx(self._p, self.env._ctx))
@@ -94,6 +105,7 @@ class MapPlanner:
 
     # ---- MapPlanner / PlannerBase setters (same names as the reference)
     def setMapUtil(self, map_util):
+        self._map_util = map_util
         d = (C.c_int32 * 3)(*(map_util.map_dim + [1] * (3 - len(map_util.map_dim))))
         o = (C.c_double * 3)(*(map_util.origin + [0.0] * (3 - len(map_util.origin))))
         self._check(self._L.mplx_planner_set_map(self._p, map_util.cells.ctypes.data, d, o, map_util.res))
@@ -122,6 +134,48 @@ class MapPlanner:
 
     def setTol(self, tol_pos, tol_vel=-1.0, tol_acc=-1.0):
         self._cfg.tol_pos, self._cfg.tol_vel, self._cfg.tol_acc = float(tol_pos), float(tol_vel), float(tol_acc)
+
+    # ---- MapPlanner's map preprocessing and iterative planning (map_planner.h:25-62, map_planner.cpp:46-95,
+    #      246-283, 394-430); the kernels are the engine's (EnvMap.updatePotentialMap / setSearchRegion)
+    def setSearchRadius(self, r): self._search_radius = [float(x) for x in r]
+    def setPotentialRadius(self, r): self._potential_radius = [float(x) for x in r]
+    def setPotentialMapRange(self, r): self._potential_range = [float(x) for x in r]
+    def setPotentialWeight(self, w): self._env("set_potential_weight", w)
+    def setGradientWeight(self, w): self._env("set_gradient_weight", w)
+
+    def setSearchRegion(self, path, dense=False):
+        """Cells within the search radius of `path` ([n][D] positions) become the only traversable ones."""
+        if self._search_radius is None:
+            raise ValueError("setSearchRadius first")
+        return self.env.setSearchRegion(np.asarray(path, dtype=np.float64)[:, :self.dim], self._search_radius, dense)
+
+    def updatePotentialMap(self, pos):
+        """Rewrites the MapUtil's map with the potential field around the obstacles (map_planner.cpp:246-283, 387)
+        and installs it as the env's potential map."""
+        if self._potential_radius is None:
+            raise ValueError("setPotentialRadius first")
+        new_map = self.env.updatePotentialMap(pos, self._potential_radius, self._potential_range, self._pow)
+        mu = self._map_util
+        mu.cells = new_map
+        d = (C.c_int32 * 3)(*(mu.map_dim + [1] * (3 - len(mu.map_dim))))
+        o = (C.c_double * 3)(*(mu.origin + [0.0] * (3 - len(mu.origin))))
+        self._check(self._L.mplx_planner_set_map(self._p, mu.cells.ctypes.data, d, o, mu.res))
+        return new_map
+
+    def iterativePlan(self, start, goal, raw_traj, max_num):
+        """MapPlanner::iterativePlan (map_planner.cpp:394-430): re-plan inside the tunnel around the previous
+        trajectory until the cost stops changing."""
+        traj = raw_traj
+        prev_cost = 0.0
+        for _ in range(int(max_num)):
+            self.setSearchRegion(traj.getWaypoints()[:, :self.dim], False)
+            if not self.plan(start, goal):
+                return False
+            traj = self.getTraj()
+            if prev_cost == self.getTrajCost():
+                break
+            prev_cost = self.getTrajCost()
+        return True
 
     def setBatch(self, n):
         """Nodes per device launch (1 = the reference's one-node-at-a-time loop)."""
@@ -168,7 +222,12 @@ class MapPlanner:
         nodes = np.empty((max(o.segments, 1), f), dtype=np.float64)
         acts = np.empty(max(o.segments, 1), dtype=np.int32)
         self._check(self._L.mplx_planner_trajectory(self._p, nodes.ctypes.data, acts.ctypes.data, max(o.segments, 1)))
-        return Trajectory(o.total_time, list(o.J), nodes[:o.segments], acts[:o.segments], o.cost)
+        end = np.empty(f, dtype=np.float64)
+        if o.ok and o.segments > 0:
+            self._check(self._L.mplx_planner_trajectory_end(self._p, end.ctypes.data))
+        else:
+            end = None
+        return Trajectory(o.total_time, list(o.J), nodes[:o.segments], acts[:o.segments], o.cost, end)
 
     def getTrajCost(self):
         return self._summary.cost

@@ -112,3 +112,75 @@ def test_reference_test_scenarios_with_dropin_adapter(engine, scenario):
             assert abs(gpu[stage]["cost"] - cpu[stage]["cost"]) <= tol * abs(cpu[stage]["cost"])
             assert abs(gpu[stage]["traj_checksum"] - cpu[stage]["traj_checksum"]) <= tol * abs(cpu[stage]["traj_checksum"])
         assert gpu[1]["region_cells"] == cpu[1]["region_cells"] and gpu[1]["potential_sum"] == cpu[1]["potential_sum"]
+
+
+_REF_PINS = {  # the reference's MapPlanner on the CPU (tests/test_plan_known_answer.py pins the same numbers)
+    "distance": dict(closed=2732, cost=647.0999999999999, T=36.0, J=[40.08333333333333, 7.0]),
+    "distance_iterative": dict(closed=3419, cost=617.45, T=37.0, J=[42.833333333333336, 7.75]),
+    "distance_yaw": dict(closed=25326, cost=617.7304404847963, T=37.0, J=[42.833333333333336, 7.75]),
+    "yaw": dict(closed=1342, cost=352.4275550988982, T=35.0, J=[36.666666666666664, 2.0]),
+}
+
+
+@pytest.mark.parametrize("scenario", sorted(_REF_PINS))
+@pytest.mark.parametrize("batch", [1, 64])
+def test_reference_test_scenarios_on_the_engine_planner(engine, scenario, batch):
+    """The same scenarios on the engine's own planner (motion_primitive_library_amd.MapPlanner: host A* of
+    csrc/host_planner.hpp, get_succ / updatePotentialMap / setSearchRegion on the MI355X, iterativePlan mirrored in
+    planner.py) against what the reference's MapPlanner returns on the CPU: same closed set size, cost, duration
+    and efforts, whatever the batch size."""
+    m = engine
+    c = corridor()
+    vals = [-0.5, 0.0, 0.5]
+    U = m.workloads.grid_controls(vals, 2)
+    U_yaw = m.workloads.grid_controls(vals, 2, yaw_rates=[-0.5, 0.0, 0.5])
+
+    def make(table):
+        pl = m.MapPlanner(2, device=0)
+        mu = m.MapUtil(2)
+        mu.setMap(c["origin"], c["dim"], c["cells"].copy(), c["res"])
+        pl.setMapUtil(mu)
+        pl.setVmax(1.0)
+        pl.setAmax(1.0)
+        pl.setDt(1.0)
+        pl.setU(table)
+        pl.setBatch(batch)
+        return pl
+
+    t0 = time.perf_counter()
+    if scenario == "yaw":
+        pl = make(U_yaw)
+        pl.setYawmax(0.7)
+        ok = pl.plan(m.Waypoint(2, m.ACCxYAW, pos=c["start"], yaw=np.pi / 2), m.Waypoint(2, m.ACCxYAW, pos=c["goal"]))
+    else:
+        first = make(U)
+        assert first.plan(m.Waypoint(2, m.ACC, pos=c["start"]), m.Waypoint(2, m.ACC, pos=c["goal"]))
+        assert first.summary()["closed"] == 615
+        traj = first.getTraj()
+        assert traj.getWaypoints().shape == (36, 10)
+        first.close()
+        with_yaw = scenario == "distance_yaw"
+        pl = make(U_yaw if with_yaw else U)
+        pl.setEpsilon(1.0)
+        pl.setSearchRadius([0.5, 0.5])
+        if scenario == "distance":
+            pl.setSearchRegion(traj.getWaypoints()[:, :2])
+        pl.setPotentialRadius([1.0, 1.0])
+        pl.setPotentialWeight(0.5)
+        pl.setGradientWeight(0)
+        pl.updatePotentialMap(c["start"])
+        start = m.Waypoint(2, m.ACCxYAW if with_yaw else m.ACC, pos=c["start"])
+        goal = m.Waypoint(2, m.ACC, pos=c["goal"])
+        if with_yaw:
+            pl.setYawmax(0.5)
+        ok = pl.plan(start, goal) if scenario == "distance" else pl.iterativePlan(start, goal, traj, 10)
+    dt = time.perf_counter() - t0
+    s, tr = pl.summary(), pl.getTraj()
+    pl.close()
+    want = _REF_PINS[scenario]
+    print("%s on the engine planner, batch=%d: %.1f ms, last plan %d expansions, %d launches" % (
+        scenario, batch, dt * 1e3, s["expansions"], s["device_launches"]))
+    assert ok and s["closed"] == want["closed"] and tr.getTotalTime() == want["T"]
+    rtol = 1e-9 if "yaw" in scenario else 1e-15
+    assert abs(s["cost"] - want["cost"]) <= rtol * want["cost"]
+    assert tr.J(m.VEL) == want["J"][0] and tr.J(m.ACC) == want["J"][1]
