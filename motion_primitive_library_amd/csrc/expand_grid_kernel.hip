@@ -264,6 +264,23 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
     if (lane < 2) s_misc[M_NMASK + lane] = 0;
     wave_sync();
 
+    if (YAW && K >= 2 && A.yaw_max > 0) {
+      // validate_yaw at t = 0 (primitive.h:509-523) does not depend on the control when the state carries a
+      // velocity: evaluate(0).vel = 0.0 + v and yaw(0) = wrap(yaw).  A node that fails it has no successor at all.
+      const double vx0 = 0.0 + s_node[1 * D], vy0 = 0.0 + s_node[1 * D + 1];
+      bool dead = false;
+      if (vx0 != 0 || vy0 != 0) {
+        double c0, s0;
+        sincos(wrap_angle((0.0 + 0.0) + s_node[4 * D]), &s0, &c0);
+        const double sn = sqrt(vx0 * vx0 + vy0 * vy0);
+        dead = vx0 / sn * c0 + vy0 / sn * s0 < cos_lim;
+      }
+      if (dead) {  // uniform
+        if (lane == 0 && A.l_count) A.l_count[node] = 0;
+        continue;
+      }
+    }
+
     // ---- phase T1: axis entries; the node's own lattice integers (lanes 48..)
     int flag = 0;
     if (lane < EN) {
@@ -339,8 +356,10 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         s_yawT[lane] = yT;
         s_yq[lane] = quantise(yT, 0.1, A.R01);
         if (A.yaw_max > 0) {
-          s_ycs[lane * 2 + 0] = cos(yT);
-          s_ycs[lane * 2 + 1] = sin(yT);
+          double sn_, cs_;
+          sincos(yT, &sn_, &cs_);  // same values as cos() / sin() (one argument reduction instead of two)
+          s_ycs[lane * 2 + 0] = cs_;
+          s_ycs[lane * 2 + 1] = sn_;
         }
       }
       if (lane == 63) s_misc[M_YQ] = quantise(cyaw, 0.1, A.R01);
@@ -382,7 +401,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       // values whose heading stays within yaw_max of the velocity direction
       const bool lim = A.yaw_max > 0;
       const double y0 = wrap_angle((0.0 + 0.0) + s_node[4 * D]);  // yaw polynomial at t = 0: (0.0 + u_yaw * 0.0) + yaw
-      const double c0 = lim ? cos(y0) : 0.0, s0 = lim ? sin(y0) : 0.0;
+      double c0 = 0.0, s0 = 0.0;
+      if (lim) sincos(y0, &s0, &c0);
       const float inv_n1 = 1.0f / (float)nd[1];
       for (int x = lane; x < nd[0] * nd[1]; x += 64) {
         const int j0 = (int)(((float)x + 0.5f) * inv_n1), j1 = x - j0 * nd[1];
@@ -619,8 +639,10 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               const int k = x - __umul24(jy, cn);
               const double yw = wrap_angle(s_uyaw[jy] * trow[k] + cyaw);
               double *o = s_ycsr + (__umul24(__umul24(jy, RM) + row, tts) + k) * 2;
-              o[0] = cos(yw);
-              o[1] = sin(yw);
+              double sn_, cs_;
+              sincos(yw, &sn_, &cs_);
+              o[0] = cs_;
+              o[1] = sn_;
             }
           }
         }
