@@ -474,3 +474,39 @@ def test_irregular_parameters_all_routes(engine, oracle_lib, seed):
             seed, route, env.last_lists_route()))
     env.close()
     assert "dense" in seen and (control == 0x1F or "grid" in seen or control == 0x0F and pot is not None)
+
+
+@pytest.mark.parametrize("dims", [[7, 5], [33, 3], [1, 40], [9, 6, 4], [65, 2, 3], [3, 3, 70]])
+@pytest.mark.parametrize("control", [0x01, 0x03, 0x13])
+def test_tiny_and_lopsided_maps(engine, oracle_lib, dims, control):
+    """Maps narrower than one 32-cell word of the blocked-bit rows, one cell wide, or long in one axis only: every
+    primitive leaves the map somewhere, boxes are clipped on all sides, the summed-area look-ups sit on the border."""
+    W = engine.workloads
+    dim = len(dims)
+    rng = np.random.default_rng(sum(dims) + control)
+    res = 0.1
+    cells = (rng.uniform(size=dims[::-1]) < 0.08).astype(np.int8) * 100
+    n_nodes = 80
+    nodes = np.zeros((4 * dim + 2, n_nodes))
+    for i in range(dim):
+        nodes[i] = np.round(rng.uniform(-0.15, dims[i] * res + 0.15, size=n_nodes), 2)
+    if control & 0x02:
+        nodes[dim:2 * dim] = rng.choice([-0.5, 0.0, 0.5], size=(dim, n_nodes))
+    if control & 0x10:
+        nodes[4 * dim] = np.arctan2(nodes[dim + 1], nodes[dim]) + rng.uniform(-0.3, 0.3, size=n_nodes)
+    U = W.grid_controls([-1.0, -0.5, 0.0, 0.5, 1.0] if dim == 2 else [-1.0, 0.0, 1.0], dim,
+                        yaw_rates=[-0.5, 0.0, 0.5] if control & 0x10 else None)
+    params = {"v_max": 1.5, "dt": 0.5}
+    if control & 0x10:
+        params["yaw_max"] = 0.8
+    wl = W.Workload("tiny", dim, control, cells, [0.0] * dim, res, U, nodes, params)
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=4)
+    assert np.count_nonzero(ref["status"] == 2) > 20
+    env = engine_env(engine, wl)
+    for route in ("grid", "dense") + (() if control & 0x10 else ("tile",)):
+        env.set_lists_route(route)
+        got = env.expand_lists(wl.nodes)
+        assert env.last_lists_route() == route
+        assert_lists_equal(got, ref, n_nodes, U.shape[0], cost_rtol=YAW_COST_RTOL if control & 0x10 else 0.0,
+                           what="tiny map %s ctrl0x%x route %s" % (dims, control, route))
+    env.close()
