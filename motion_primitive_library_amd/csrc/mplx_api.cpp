@@ -108,6 +108,16 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
       c->n_cus = prop.multiProcessorCount;
   }
+  {
+    auto env_int = [](const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; };
+    c->tune.grid_rmax = env_int("MPLX_GRID_RMAX");
+    c->tune.grid_boxcap = env_int("MPLX_GRID_BOXCAP");
+    c->tune.grid_blocks = env_int("MPLX_GRID_BLOCKS");
+    c->tune.dbg = env_int("MPLX_TILE_DBG");
+    c->tune.no_sat = getenv("MPLX_GRID_NOSAT") != nullptr;
+    c->tune.no_lex = getenv("MPLX_GRID_NOLEX") != nullptr;
+    c->tune.no_line_pad = getenv("MPLX_NO_LINE_PAD") != nullptr;
+  }
   *out = c;
   return MPLX_OK;
 }
@@ -408,8 +418,8 @@ GridPlan plan_grid(const mplx_ctx *c) {
   int rmax = 4, boxcap = (c->dim == 3) ? (n_max + 3) * (n_max + 3) : 4 * (n_max + 3);
   if (boxcap < 64) boxcap = 64;
   if (boxcap > 1024) boxcap = 1024;
-  if (const char *e = getenv("MPLX_GRID_RMAX")) rmax = atoi(e);      // tuning only
-  if (const char *e = getenv("MPLX_GRID_BOXCAP")) boxcap = atoi(e);  // tuning only
+  if (c->tune.grid_rmax > 0) rmax = c->tune.grid_rmax;
+  if (c->tune.grid_boxcap > 0) boxcap = c->tune.grid_boxcap;
   if (rmax < 1) rmax = 1;
   while (rmax > 1 && mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rmax, boxcap, ym, ndy) > 80 * 1024) rmax--;
   const size_t lds = mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rmax, boxcap, ym, ndy);
@@ -426,7 +436,7 @@ GridPlan plan_grid(const mplx_ctx *c) {
   g.boxcap = boxcap;
   g.order = order;
   g.grid = c->n_cus * per_cu;
-  if (const char *e = getenv("MPLX_GRID_BLOCKS")) g.grid = atoi(e) > 0 ? atoi(e) : g.grid;  // tuning only
+  if (c->tune.grid_blocks > 0) g.grid = c->tune.grid_blocks;
   return g;
 }
 
@@ -442,7 +452,7 @@ int ensure_blocked_bits(mplx_ctx *c) {
   c->sat_ok = false;
   const int d2p = c->dim == 3 ? c->mdim[2] + 1 : 2;
   const int64_t sat_n = (int64_t)(c->mdim[0] + 1) * (c->mdim[1] + 1) * d2p;
-  if (!getenv("MPLX_GRID_NOSAT") && sat_n * 4 <= (16LL << 30)) {
+  if (!c->tune.no_sat && sat_n * 4 <= (16LL << 30)) {
     if (int rc = ensure(c, c->sat, (size_t)sat_n * 4)) return rc;
     HIP_TRY(c, mplx::launch_build_sat(c->dim, (const uint32_t *)c->blk.p, c->mdim, (uint32_t *)c->sat.p, c->stream));
     c->sat_ok = true;
@@ -486,7 +496,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.pot_w = c->prm.potential_weight;
     const bool yaw = (c->prm.control & 0x10) != 0;
     // the free-box shortcut skips the sample loops, which a per-sample heading cost (wyaw > 0) still needs
-    a.sat = (c->sat_ok && gp.order <= 3 && !(yaw && c->prm.wyaw > 0) && !getenv("MPLX_GRID_NOSAT"))
+    a.sat = (c->sat_ok && gp.order <= 3 && !(yaw && c->prm.wyaw > 0) && !c->tune.no_sat)
                 ? (const uint32_t *)c->sat.p : nullptr;
     a.yaw_max = c->prm.yaw_max; a.wyaw = c->prm.wyaw; a.ndy = yaw ? c->u_nd[3] : 0;
     a.dim0 = c->mdim[0]; a.dim1 = c->mdim[1]; a.dim2 = c->mdim[2];
@@ -498,18 +508,18 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.uidx = (const uint32_t *)c->uidx.p;
     a.nd0 = c->u_nd[0]; a.nd1 = c->u_nd[1]; a.nd2 = c->u_nd[2];
     a.ndp = gp.ndp;
-    a.ulex = (c->u_lex && !getenv("MPLX_GRID_NOLEX")) ? 1 : 0;
+    a.ulex = (c->u_lex && !c->tune.no_lex) ? 1 : 0;
     a.nU = c->nU;
     a.nodes = d_nodes; a.n_nodes = n_nodes; a.node_stride = node_stride;
     a.n_max = gp.n_max; a.rmax = gp.rmax; a.boxcap = gp.boxcap; a.grid_limit = gp.grid;
-    if (const char *dbg = getenv("MPLX_TILE_DBG")) a.dbg = atoi(dbg);  // timing ablations, never set in production
+    a.dbg = c->tune.dbg;  // timing ablations, 0 in production
     a.ttab = (const double *)c->tables.p;
     a.tcnt = (const unsigned char *)c->tables.p + 64 * 64 * 8;
     a.Rres = c->recips[0]; a.R001 = c->recips[1]; a.R01 = c->recips[2];
     a.l_count = o->count; a.l_action = o->action; a.l_cost = o->cost; a.l_hash = o->hash;
     a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
     a.l_nstride = o->node_stride ? o->node_stride : c->nU;
-    a.l_pad = (a.l_nstride % 32 == 0 && !getenv("MPLX_NO_LINE_PAD")) ? 1 : 0;  // see expand_grid_kernel.hip
+    a.l_pad = (a.l_nstride % 32 == 0 && !c->tune.no_line_pad) ? 1 : 0;  // see expand_grid_kernel.hip
     HIP_TRY(c, mplx::launch_expand_grid(c->dim, c->prm.control, a, c->stream));
     c->last_route = MPLX_ROUTE_GRID;
     return MPLX_OK;
@@ -533,7 +543,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.nodes = d_nodes; a.n_nodes = n_nodes; a.node_stride = node_stride;
     a.npb = tp.npb; a.tile_pairs = tp.tile_pairs; a.wl_cap = tp.wl_cap; a.n_max = tp.n_max;
     a.lds_u_offset = tp.u_offset; a.grid_limit = tp.grid;
-    if (const char *dbg = getenv("MPLX_TILE_DBG")) a.dbg = atoi(dbg);  // timing ablations, never set in production
+    a.dbg = c->tune.dbg;  // timing ablations, 0 in production
     a.ttab = (const double *)c->tables.p;
     a.tcnt = (const unsigned char *)c->tables.p + 64 * 64 * 8;
     a.Rres = c->recips[0]; a.R001 = c->recips[1]; a.R01 = c->recips[2];

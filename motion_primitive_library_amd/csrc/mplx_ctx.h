@@ -49,6 +49,13 @@ struct mplx_ctx {
   bool u_factored = false;
   bool u_lex = false;    // the table is the full Cartesian product of its per-axis values in lexicographic order
   int32_t u_nd[4] = {0, 0, 0, 0};  // distinct control values per axis; [3] = yaw rates
+  // Diagnostic knobs, read from the environment once per context (mplx_create): ablations and forced code paths
+  // for tests and profiling scripts; all off / automatic in production.
+  struct Tuning {
+    int grid_rmax = 0, grid_boxcap = 0, grid_blocks = 0;  // MPLX_GRID_RMAX / _BOXCAP / _BLOCKS (0 = automatic)
+    int dbg = 0;                                         // MPLX_TILE_DBG ablation bits
+    bool no_sat = false, no_lex = false, no_line_pad = false;  // MPLX_GRID_NOSAT / MPLX_GRID_NOLEX / MPLX_NO_LINE_PAD
+  } tune;
   int lists_route = MPLX_ROUTE_AUTO;
   int last_route = MPLX_ROUTE_AUTO;
   int n_cus = 256;

@@ -105,7 +105,7 @@ def test_lists_irregular_control_tables(engine, oracle_lib, dim, n_controls, n_d
 
 @pytest.mark.parametrize("rmax,boxcap,dbg", [("1", None, None), (None, "8", None), ("2", "40", None), (None, None, "64")])
 def test_grid_kernel_small_lds_budgets(engine, oracle_lib, monkeypatch, rmax, boxcap, dbg):
-    """The factorised kernel with a starved LDS budget (tuning overrides read at launch): one row of
+    """The factorised kernel with a starved LDS budget (tuning overrides, read when the context is created): one row of
     cell codes per pass forces the multi-pass path, a tiny box forces sampling straight from the
     blocked-bit map.  Results must not change."""
     if rmax:
