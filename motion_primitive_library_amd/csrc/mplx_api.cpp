@@ -114,6 +114,7 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
     c->tune.grid_boxcap = env_int("MPLX_GRID_BOXCAP");
     c->tune.grid_blocks = env_int("MPLX_GRID_BLOCKS");
     c->tune.dbg = env_int("MPLX_TILE_DBG");
+    c->tune.arena_kb = env_int("MPLX_ARENA_KB");
     c->tune.no_sat = getenv("MPLX_GRID_NOSAT") != nullptr;
     c->tune.no_lex = getenv("MPLX_GRID_NOLEX") != nullptr;
     c->tune.no_line_pad = getenv("MPLX_NO_LINE_PAD") != nullptr;
@@ -131,6 +132,8 @@ void mplx_destroy(mplx_ctx *c) {
                     &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx, &c->blk, &c->sat, &c->prep_lut, &c->prep_a, &c->prep_b, &c->post_keys, &c->e_parents, &c->e_action, &c->e_free, &c->e_cost, &c->e_cells, &c->e_count})
     release(*b);
   mplx_detail::release_copy_buffers(c);
+  release(c->s_arena);
+  if (c->h_arena) (void)hipHostFree(c->h_arena);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -622,6 +625,62 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
   const int64_t n_slots = n_nodes * (h_out->node_stride ? h_out->node_stride : c->nU);
   if (h_out->state && h_out->state_stride < n_slots)
     return fail(c, MPLX_ERR_ARG, "mplx_expand_lists: state_stride < n_nodes*node_stride");
+  {
+    // Small batches (one get_succ, or the speculative batches of a search on a small control table) are latency
+    // bound: nodes and every output row live in ONE device arena mirrored by ONE pinned host buffer, so a call is
+    // one upload, the kernel, one download and one synchronisation; the used prefixes are then copied into the
+    // caller's arrays.  (Separate pageable copies per row cost 10 - 15 us each.)
+    const size_t S = (size_t)(h_out->node_stride ? h_out->node_stride : c->nU);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_count = up((size_t)F * n_nodes * 8);
+    const size_t o_action = o_count + up((size_t)n_nodes * 4);
+    const size_t o_cost = o_action + (h_out->action ? up((size_t)n_slots * 4) : 0);
+    const size_t o_hash = o_cost + (h_out->cost ? up((size_t)n_slots * 8) : 0);
+    const size_t o_iters = o_hash + (h_out->hash ? up((size_t)n_slots * 8) : 0);
+    const size_t o_state = o_iters + (h_out->iters ? up((size_t)n_slots * 4) : 0);
+    const size_t total = o_state + (h_out->state ? up((size_t)F * n_slots * 8) : 0);
+    const size_t arena_max = c->tune.arena_kb > 0 ? (size_t)c->tune.arena_kb << 10 : (size_t)4 << 20;
+    if (total <= arena_max) {
+      if (int rc = ensure(c, c->s_arena, total)) return rc;
+      if (total > c->h_arena_cap) {
+        if (c->h_arena) HIP_TRY(c, hipHostFree(c->h_arena));
+        c->h_arena = nullptr;
+        c->h_arena_cap = 0;
+        HIP_TRY(c, hipHostMalloc(&c->h_arena, arena_max, hipHostMallocDefault));
+        c->h_arena_cap = arena_max;
+      }
+      char *hb = (char *)c->h_arena, *db = (char *)c->s_arena.p;
+      for (int f = 0; f < F; f++)
+        std::memcpy(hb + (size_t)f * n_nodes * 8, h_nodes + (size_t)f * node_stride, (size_t)n_nodes * 8);
+      HIP_TRY(c, hipMemcpyAsync(db, hb, (size_t)F * n_nodes * 8, hipMemcpyHostToDevice, c->stream));
+      mplx_succ_lists d{};
+      d.count = (int32_t *)(db + o_count);
+      if (h_out->action) d.action = (int32_t *)(db + o_action);
+      if (h_out->cost) d.cost = (double *)(db + o_cost);
+      if (h_out->hash) d.hash = (uint64_t *)(db + o_hash);
+      if (h_out->iters) d.iters = (int32_t *)(db + o_iters);
+      if (h_out->state) { d.state = (double *)(db + o_state); d.state_stride = n_slots; }
+      d.node_stride = h_out->node_stride;
+      if (int rc = lists_device(c, (const double *)db, n_nodes, n_nodes, &d)) return rc;
+      HIP_TRY(c, hipMemcpyAsync(hb + o_count, db + o_count, total - o_count, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      const int32_t *cnt = (const int32_t *)(hb + o_count);
+      std::memcpy(h_out->count, cnt, (size_t)n_nodes * 4);
+      for (int64_t k = 0; k < n_nodes; k++) {
+        const size_t m = (size_t)cnt[k], at = (size_t)k * S;
+        if (!m) continue;
+        if (h_out->action) std::memcpy(h_out->action + at, hb + o_action + at * 4, m * 4);
+        if (h_out->cost) std::memcpy(h_out->cost + at, hb + o_cost + at * 8, m * 8);
+        if (h_out->hash) std::memcpy(h_out->hash + at, hb + o_hash + at * 8, m * 8);
+        if (h_out->iters) std::memcpy(h_out->iters + at, hb + o_iters + at * 4, m * 4);
+        if (h_out->state)
+          for (int f = 0; f < F; f++)
+            std::memcpy(h_out->state + (size_t)f * h_out->state_stride + at,
+                        hb + o_state + ((size_t)f * n_slots + at) * 8, m * 8);
+      }
+      return MPLX_OK;
+    }
+  }
   if (int rc = ensure(c, c->s_nodes, (size_t)F * n_nodes * sizeof(double))) return rc;
   HIP_TRY(c, hipMemcpy2DAsync(c->s_nodes.p, (size_t)n_nodes * sizeof(double), h_nodes,
                               (size_t)node_stride * sizeof(double), (size_t)n_nodes * sizeof(double), F,
@@ -640,33 +699,9 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
   }
   d.node_stride = h_out->node_stride;
   if (int rc = lists_device(c, (const double *)c->s_nodes.p, n_nodes, n_nodes, &d)) return rc;
-  // large batches: only the used prefixes cross the link, pipelined (lists_copy_api.cpp); small ones (the
-  // speculative batches of a search on a small control table) are latency bound: one round of plain copies
-  const bool small = (size_t)n_slots * (size_t)(F * 8 + 24) <= ((size_t)256 << 10);
-  if (n_nodes > 1 && !small) return mplx_detail::copy_lists_to_host(c, d, h_out, n_nodes);
-  HIP_TRY(c, hipMemcpyAsync(h_out->count, d.count, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, c->stream));
-  if (n_nodes > 1) {
-    if (h_out->action) HIP_TRY(c, hipMemcpyAsync(h_out->action, d.action, (size_t)n_slots * 4, hipMemcpyDeviceToHost, c->stream));
-    if (h_out->cost) HIP_TRY(c, hipMemcpyAsync(h_out->cost, d.cost, (size_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
-    if (h_out->hash) HIP_TRY(c, hipMemcpyAsync(h_out->hash, d.hash, (size_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
-    if (h_out->iters) HIP_TRY(c, hipMemcpyAsync(h_out->iters, d.iters, (size_t)n_slots * 4, hipMemcpyDeviceToHost, c->stream));
-    if (h_out->state)
-      HIP_TRY(c, hipMemcpy2DAsync(h_out->state, (size_t)h_out->state_stride * 8, d.state, (size_t)n_slots * 8,
-                                  (size_t)n_slots * 8, F, hipMemcpyDeviceToHost, c->stream));
-  } else {
-    // the get_succ case: copy back only the used prefix
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const size_t m = (size_t)h_out->count[0];
-    if (h_out->action && m) HIP_TRY(c, hipMemcpyAsync(h_out->action, d.action, m * 4, hipMemcpyDeviceToHost, c->stream));
-    if (h_out->cost && m) HIP_TRY(c, hipMemcpyAsync(h_out->cost, d.cost, m * 8, hipMemcpyDeviceToHost, c->stream));
-    if (h_out->hash && m) HIP_TRY(c, hipMemcpyAsync(h_out->hash, d.hash, m * 8, hipMemcpyDeviceToHost, c->stream));
-    if (h_out->iters && m) HIP_TRY(c, hipMemcpyAsync(h_out->iters, d.iters, m * 4, hipMemcpyDeviceToHost, c->stream));
-    if (h_out->state && m)
-      HIP_TRY(c, hipMemcpy2DAsync(h_out->state, (size_t)h_out->state_stride * 8, d.state, (size_t)n_slots * 8, m * 8, F,
-                                  hipMemcpyDeviceToHost, c->stream));
-  }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return MPLX_OK;
+  // everything larger: only the used prefixes cross the link, packed on the device and pipelined through pinned
+  // buffers (lists_copy_api.cpp)
+  return mplx_detail::copy_lists_to_host(c, d, h_out, n_nodes);
 }
 
 int mplx_get_succ(mplx_ctx *c, const double *node, double *succ, double *cost, int32_t *action,

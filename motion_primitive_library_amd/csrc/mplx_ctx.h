@@ -54,6 +54,7 @@ struct mplx_ctx {
   struct Tuning {
     int grid_rmax = 0, grid_boxcap = 0, grid_blocks = 0;  // MPLX_GRID_RMAX / _BOXCAP / _BLOCKS (0 = automatic)
     int dbg = 0;                                         // MPLX_TILE_DBG ablation bits
+    int arena_kb = 0;                                    // MPLX_ARENA_KB: largest batch served by the one-copy path
     bool no_sat = false, no_lex = false, no_line_pad = false;  // MPLX_GRID_NOSAT / MPLX_GRID_NOLEX / MPLX_NO_LINE_PAD
   } tune;
   int lists_route = MPLX_ROUTE_AUTO;
@@ -69,6 +70,10 @@ struct mplx_ctx {
   mplx_detail::DevBuf d_status, d_cost, d_hash, d_state, d_iters;
   // staging for the host-pointer entry points
   mplx_detail::DevBuf s_nodes, s_status, s_cost, s_hash, s_state, s_iters, s_count, s_action;
+  // small host-pointer batches: one device arena + one pinned mirror (mplx_expand_lists)
+  mplx_detail::DevBuf s_arena;
+  void *h_arena = nullptr;
+  size_t h_arena_cap = 0;
   // pipelined copy back of the lists (lists_copy_api.cpp): packed chunks on the device, pinned landing buffers
   mplx_detail::DevBuf pk_dev[2], pk_offs;
   void *pk_pin[2] = {nullptr, nullptr};
