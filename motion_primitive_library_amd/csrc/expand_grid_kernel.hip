@@ -140,6 +140,23 @@ constexpr int kBT = 64 * kWPB;
 constexpr int kTabStride = 64;  // row stride of the global time table (launch_make_tables)
 constexpr int kUB = MPLX_GRID_UB;    // samples per step of the sample loop
 
+// List stores: never re-read by this kernel, so they must not allocate in L2.  Measured on C4 (same box,
+// profiles/micro/store_policy.sh): default policy 0.723 ms, sc1 0.725, sc0 sc1 0.729, nt (what
+// __builtin_nontemporal_store emits) 0.636 - 0.641, sc1 nt 0.626, sc0 sc1 nt 0.628 -> agent-scope non-temporal.
+// -DMPLX_ST_ASM="..." selects other bits, -DMPLX_ST_BUILTIN the builtin.
+#if !defined(MPLX_ST_ASM) && !defined(MPLX_ST_BUILTIN)
+#define MPLX_ST_ASM "sc1 nt"
+#endif
+template <typename T>
+__device__ __forceinline__ void st_stream(T v, T *p) {
+#ifdef MPLX_ST_ASM
+  if constexpr (sizeof(T) == 8) asm volatile("global_store_dwordx2 %0, %1, off " MPLX_ST_ASM ::"v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dword %0, %1, off " MPLX_ST_ASM ::"v"(p), "v"(v) : "memory");
+#else
+  __builtin_nontemporal_store(v, p);
+#endif
+}
+
 // Orders this wave's LDS traffic: LDS executes a wave's instructions in order, so
 // only the compiler has to be kept from moving accesses across the point.
 __device__ __forceinline__ void wave_sync() {
@@ -737,8 +754,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
           uint64_t h = s_hp[px];
           fold_entry<K>(h, s_eq, en[D - 1]);
           if (YAW) fold(h, s_yq[jy]);
-          if (A.l_action) __builtin_nontemporal_store(mine ? ci : -1, &A.l_action[idx]);
-          if (A.l_hash && (mine || pad16)) __builtin_nontemporal_store(h, &A.l_hash[idx]);
+          if (A.l_action) st_stream(mine ? ci : -1, &A.l_action[idx]);
+          if (A.l_hash && (mine || pad16)) st_stream(h, &A.l_hash[idx]);
           if (A.l_state && (mine || pad16)) {
             double *o = A.l_state + idx;
             const int64_t ss = A.l_stride;
@@ -748,14 +765,14 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               const double u = s_uval[en[i]];
               const double uK = 0.0 + u;                                     // field of order K
               const double top = (0.0 + u * T) + s_node[(K - 1) * D + i];    // field of order K - 1
-              __builtin_nontemporal_store((double)((K >= 2) ? st[0] : top), &o[(0 * D + i) * ss]);
-              __builtin_nontemporal_store((double)((K >= 3) ? st[1] : (K == 2 ? top : uK)), &o[(1 * D + i) * ss]);
-              __builtin_nontemporal_store((double)((K >= 4) ? st[2] : (K == 3 ? top : (K == 2 ? uK : 0.0))), &o[(2 * D + i) * ss]);
-              __builtin_nontemporal_store((double)((K == 4) ? top : (K == 3 ? uK : 0.0)), &o[(3 * D + i) * ss]);
+              st_stream((double)((K >= 2) ? st[0] : top), &o[(0 * D + i) * ss]);
+              st_stream((double)((K >= 3) ? st[1] : (K == 2 ? top : uK)), &o[(1 * D + i) * ss]);
+              st_stream((double)((K >= 4) ? st[2] : (K == 3 ? top : (K == 2 ? uK : 0.0))), &o[(2 * D + i) * ss]);
+              st_stream((double)((K == 4) ? top : (K == 3 ? uK : 0.0)), &o[(3 * D + i) * ss]);
             }
             // Waypoint::yaw: 0 for a control without yaw (primitive.h:322)
-            __builtin_nontemporal_store(YAW ? s_yawT[jy] : 0.0, &o[(4 * D) * ss]);
-            __builtin_nontemporal_store(node_t + A.dt, &o[(4 * D + 1) * ss]);  // env_map.h:161
+            st_stream(YAW ? s_yawT[jy] : 0.0, &o[(4 * D) * ss]);
+            st_stream(node_t + A.dt, &o[(4 * D + 1) * ss]);  // env_map.h:161
           }
         }
         // ---- the sample loop of traverse_primitive (env_map.h:97-120)
@@ -928,8 +945,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
             J += u * u * T;
           }
           const double cost = blocked ? INFINITY : csum + (J + A.w * A.dt);
-          if (A.l_cost && (mine || pad16)) __builtin_nontemporal_store(cost, &A.l_cost[idx]);
-          if (A.l_iters) __builtin_nontemporal_store(blocked ? fb + 1 : cntl, &A.l_iters[idx]);
+          if (A.l_cost && (mine || pad16)) st_stream(cost, &A.l_cost[idx]);
+          if (A.l_iters) st_stream(blocked ? fb + 1 : cntl, &A.l_iters[idx]);
         }
       }
     }
