@@ -132,46 +132,60 @@ typedef Node *NodePtr;  // nodes live in Planner::pool (a deque: stable addresse
 
 // state_space.h:37-70 (A* fields)
 struct Node {
-  double coord[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 4D+2 used
-  uint64_t key = 0;
-  struct Pred { uint64_t key; double cost; int action; };
-  std::vector<Pred> pred;  // pred_coord / pred_action_cost / pred_action_id of state_space.h:49-53
+  // the fields every relaxation touches share the first cache line
   double g = kInf, rhs = kInf, h = kInf;
-  bool opened = false, closed = false;
+  // pred_coord / pred_action_cost / pred_action_id of state_space.h:49-53: a list threaded through the
+  // planner's one pool of records (Planner::preds), in insertion order -- no allocation per node
+  int32_t pred_head = -1, pred_tail = -1;
   int heap_pos = -1;
-  // successor cache (batched expansion)
-  bool cached = false;
+  bool opened = false, closed = false;
+  bool cached = false;  // successor cache (batched expansion)
+  uint64_t key = 0;
+  double coord[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 4D+2 used
   std::vector<double> c_succ;
   std::vector<double> c_cost;
   std::vector<int32_t> c_act;
   std::vector<uint64_t> c_key;  // lattice hashes of the cached successors (when the provider supplies them)
 };
 
-// hm_ of the reference's StateSpace (state_space.h:78): lattice hash -> node.  Open addressing with
-// linear probing, keys inline (one cache line per look-up at millions of nodes, where a node-based
-// std::unordered_map takes three).
+// hm_ of the reference's StateSpace (state_space.h:78): lattice hash -> node.  Open addressing with linear
+// probing, key and pointer side by side (one cache line per look-up at millions of nodes, where a node-based
+// std::unordered_map takes three); prefetch() lets the relaxation loop hide that one miss.
 class NodeMap {
  public:
+  // The slot of `key`, created empty (nullptr) when absent; the caller fills a new slot at once.
   NodePtr &operator[](uint64_t key) {
     if ((n_ + 1) * 10 > cap_ * 6) grow();
     size_t i = slot(key);
-    while (used_[i]) {
-      if (keys_[i] == key) return vals_[i];
+    while (slots_[i].val) {
+      if (slots_[i].key == key) return slots_[i].val;
       i = (i + 1) & (cap_ - 1);
     }
-    used_[i] = 1;
-    keys_[i] = key;
-    vals_[i] = nullptr;
+    slots_[i].key = key;
     n_++;
-    return vals_[i];
+    return slots_[i].val;
+  }
+  // The node of `key` or nullptr, without inserting.
+  NodePtr peek(uint64_t key) const {
+    if (!cap_) return nullptr;
+    size_t i = slot(key);
+    while (slots_[i].val) {
+      if (slots_[i].key == key) return slots_[i].val;
+      i = (i + 1) & (cap_ - 1);
+    }
+    return nullptr;
+  }
+  void prefetch(uint64_t key) const {
+    if (cap_) __builtin_prefetch(&slots_[slot(key)]);
   }
   size_t size() const { return n_; }
   void clear() {
-    std::fill(used_.begin(), used_.end(), 0);
+    std::fill(slots_.begin(), slots_.end(), Slot{0, nullptr});
     n_ = 0;
   }
 
  private:
+  struct Slot { uint64_t key; NodePtr val; };
   size_t slot(uint64_t k) const {
     k ^= k >> 33;
     k *= 0xff51afd7ed558ccdULL;
@@ -179,29 +193,18 @@ class NodeMap {
     return (size_t)k & (cap_ - 1);
   }
   void grow() {
-    const size_t old_cap = cap_;
-    std::vector<uint64_t> ok;
-    std::vector<NodePtr> ov;
-    std::vector<uint8_t> ou;
-    ok.swap(keys_);
-    ov.swap(vals_);
-    ou.swap(used_);
-    cap_ = old_cap ? old_cap * 2 : 1024;
-    keys_.assign(cap_, 0);
-    vals_.assign(cap_, nullptr);
-    used_.assign(cap_, 0);
-    for (size_t j = 0; j < old_cap; j++)
-      if (ou[j]) {
-        size_t i = slot(ok[j]);
-        while (used_[i]) i = (i + 1) & (cap_ - 1);
-        used_[i] = 1;
-        keys_[i] = ok[j];
-        vals_[i] = ov[j];
+    std::vector<Slot> old;
+    old.swap(slots_);
+    cap_ = cap_ ? cap_ * 2 : 1024;
+    slots_.assign(cap_, Slot{0, nullptr});
+    for (const Slot &o : old)
+      if (o.val) {
+        size_t i = slot(o.key);
+        while (slots_[i].val) i = (i + 1) & (cap_ - 1);
+        slots_[i] = o;
       }
   }
-  std::vector<uint64_t> keys_;
-  std::vector<NodePtr> vals_;
-  std::vector<uint8_t> used_;
+  std::vector<Slot> slots_;
   size_t cap_ = 0, n_ = 0;
 };
 
@@ -319,6 +322,8 @@ class Planner {
   void *user = nullptr;
 
   std::deque<Node> pool;
+  struct PredRec { uint64_t key; double cost; int32_t action; int32_t next; };
+  std::vector<PredRec> preds;
   NodeMap hm;
   OpenList pq;
   PlanResult last;
@@ -355,6 +360,7 @@ class Planner {
     t_succ = t_provider = t_fill = t_pick = 0;
     hm.clear();
     pool.clear();
+    preds.clear();
     pq = OpenList();
     if (!single && !batched) return -1;
     int pn[3];
@@ -389,7 +395,18 @@ class Planner {
       bool have_keys = false;
       if (int rc = successors(curr, succ.data(), cost.data(), act.data(), keys.data(), &have_keys, &n_succ)) return rc;
       t_succ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_s0).count();
+      // The relaxation is bound by cache misses of the node map and of the nodes (1 M look-ups on the 3D
+      // problems): with the device's hashes at hand the slots are prefetched kAhead successors ahead and the
+      // nodes half that far.
+      constexpr int kAhead = 16;
+      if (have_keys)
+        for (int s = 0; s < n_succ && s < kAhead; s++) hm.prefetch(keys[(size_t)s]);
       for (int s = 0; s < n_succ; s++) {
+        if (have_keys) {
+          if (s + kAhead < n_succ) hm.prefetch(keys[(size_t)(s + kAhead)]);
+          if (s + kAhead / 2 < n_succ && !std::isinf(cost[(size_t)(s + kAhead / 2)]))
+            if (const Node *nx = hm.peek(keys[(size_t)(s + kAhead / 2)])) __builtin_prefetch(nx);
+        }
         if (std::isinf(cost[(size_t)s])) continue;  // graph_search.h:81
         const double *sc = &succ[(size_t)s * f];
         const uint64_t key = have_keys ? keys[(size_t)s] : lattice_hash(dim, control, sc);
@@ -401,7 +418,13 @@ class Planner {
           child->key = key;
           child->h = eps == 0 ? 0 : heur_keyed(sc, key, goal, goal_key);
         }
-        child->pred.push_back({curr->key, cost[(size_t)s], act[(size_t)s]});
+        {
+          const int32_t rec = (int32_t)preds.size();
+          preds.push_back({curr->key, cost[(size_t)s], act[(size_t)s], -1});
+          if (child->pred_tail >= 0) preds[(size_t)child->pred_tail].next = rec;
+          else child->pred_head = rec;
+          child->pred_tail = rec;
+        }
         const double tentative = curr->g + cost[(size_t)s];
         if (tentative < child->g) {
           child->g = tentative;
@@ -560,20 +583,21 @@ class Planner {
     std::vector<std::vector<double>> from;
     std::vector<int32_t> acts;
     bool found = false;
-    while (!curr->pred.empty()) {
+    while (curr->pred_head >= 0) {
       int min_id = -1;
       double min_rhs = kInf, min_g = kInf;
-      for (size_t i = 0; i < curr->pred.size(); i++) {
-        const NodePtr &p = hm[curr->pred[i].key];
-        const double v = p->g + curr->pred[i].cost;
+      for (int32_t i = curr->pred_head; i >= 0; i = preds[(size_t)i].next) {
+        const PredRec &pr = preds[(size_t)i];
+        const NodePtr &p = hm[pr.key];
+        const double v = p->g + pr.cost;
         if (min_rhs > v) { min_rhs = v; min_g = p->g; min_id = (int)i; }
-        else if (!std::isinf(curr->pred[i].cost) && min_rhs == v) {
+        else if (!std::isinf(pr.cost) && min_rhs == v) {
           if (min_g < p->g) { min_g = p->g; min_id = (int)i; }
         }
       }
       if (min_id < 0) break;
-      const int a = curr->pred[(size_t)min_id].action;
-      curr = hm[curr->pred[(size_t)min_id].key];
+      const int a = preds[(size_t)min_id].action;
+      curr = hm[preds[(size_t)min_id].key];
       from.push_back(std::vector<double>(curr->coord, curr->coord + f));
       acts.push_back(a);
       if (curr->key == start_key) { found = true; break; }
