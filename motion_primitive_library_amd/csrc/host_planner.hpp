@@ -30,6 +30,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <queue>
 #include <unordered_map>
@@ -127,6 +128,29 @@ typedef int (*batch_fn)(void *user, const double *nodes, int64_t n, uint8_t *sta
 typedef int (*lists_fn)(void *user, const double *nodes, int64_t n, int32_t *count, int32_t *action, double *cost,
                         uint64_t *hash, double *state /*[4D+2][n*nU]*/);
 
+// batched form handing out the engine's own landing buffer: per-node lists packed back to back (node k owns
+// entries [offs[k], offs[k+1]) of every row), valid until the provider's next call -- no copy into caller arrays
+struct PackedView {
+  int64_t total = 0;
+  const int32_t *count = nullptr;   // [n]
+  const int64_t *offs = nullptr;    // [n + 1]
+  const double *cost = nullptr;     // [total]
+  const uint64_t *hash = nullptr;   // [total]
+  const int32_t *action = nullptr;  // [total]
+  const double *state = nullptr;    // [4D+2][total]
+};
+typedef int (*packed_fn)(void *user, const double *nodes, int64_t n, PackedView *out);
+
+// What one expansion hands to the relaxation loop: m successors, fields of successor s at state[r * fs + s * es].
+struct SuccView {
+  int32_t m = 0;
+  const double *cost = nullptr;
+  const uint64_t *keys = nullptr;  // lattice hashes when the provider supplies them
+  const int32_t *act = nullptr;
+  const double *state = nullptr;
+  int64_t fs = 1, es = 1;
+};
+
 struct Node;
 typedef Node *NodePtr;  // nodes live in Planner::pool (a deque: stable addresses, one allocation per block)
 
@@ -146,6 +170,9 @@ struct Node {
   std::vector<double> c_cost;
   std::vector<int32_t> c_act;
   std::vector<uint64_t> c_key;  // lattice hashes of the cached successors (when the provider supplies them)
+  // packed provider: one recycled buffer [cost m][hash m][state (4D+2) x m][action m] (Planner::take_blob)
+  char *c_blob = nullptr;
+  int32_t c_m = 0;
 };
 
 // hm_ of the reference's StateSpace (state_space.h:78): lattice hash -> node.  Open addressing with linear
@@ -319,6 +346,7 @@ class Planner {
   succ_fn single = nullptr;
   batch_fn batched = nullptr;
   lists_fn lists = nullptr;  // preferred over `batched` when set: compact lists + device-side hashes
+  packed_fn packed = nullptr;  // preferred over `lists`: the same lists without the copy into caller arrays
   void *user = nullptr;
 
   std::deque<Node> pool;
@@ -361,6 +389,9 @@ class Planner {
     hm.clear();
     pool.clear();
     preds.clear();
+    all_blobs.clear();
+    free_blobs.clear();
+    cur_blob = nullptr;
     pq = OpenList();
     if (!single && !batched) return -1;
     int pn[3];
@@ -379,39 +410,51 @@ class Planner {
     pq.push(curr->g + eps * curr->h, curr);
     hm[curr->key] = curr;
 
-    std::vector<double> succ((size_t)nU * f), cost((size_t)nU);
-    std::vector<int32_t> act((size_t)nU);
-    std::vector<uint64_t> keys((size_t)nU);
+    v_succ.resize((size_t)nU * f);
+    v_cost.resize((size_t)nU);
+    v_act.resize((size_t)nU);
+    v_keys.resize((size_t)nU);
     const uint64_t goal_key = lattice_hash(dim, control, goal);
     int expand_iteration = 0;
     bool reached = false;
+    double sc[14];
     for (;;) {
       expand_iteration++;
       curr = pq.top().n;
       pq.pop();
       curr->closed = true;
-      int32_t n_succ = 0;
       const auto t_s0 = std::chrono::steady_clock::now();
-      bool have_keys = false;
-      if (int rc = successors(curr, succ.data(), cost.data(), act.data(), keys.data(), &have_keys, &n_succ)) return rc;
+      SuccView sv;
+      if (int rc = successors(curr, &sv)) return rc;
       t_succ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_s0).count();
+      const int n_succ = sv.m;
+      const bool have_keys = sv.keys != nullptr;
       // The relaxation is bound by cache misses of the node map and of the nodes (1 M look-ups on the 3D
       // problems): with the device's hashes at hand the slots are prefetched kAhead successors ahead and the
       // nodes half that far.
       constexpr int kAhead = 16;
       if (have_keys)
-        for (int s = 0; s < n_succ && s < kAhead; s++) hm.prefetch(keys[(size_t)s]);
+        for (int s = 0; s < n_succ && s < kAhead; s++) hm.prefetch(sv.keys[s]);
       for (int s = 0; s < n_succ; s++) {
         if (have_keys) {
-          if (s + kAhead < n_succ) hm.prefetch(keys[(size_t)(s + kAhead)]);
-          if (s + kAhead / 2 < n_succ && !std::isinf(cost[(size_t)(s + kAhead / 2)]))
-            if (const Node *nx = hm.peek(keys[(size_t)(s + kAhead / 2)])) __builtin_prefetch(nx);
+          if (s + kAhead < n_succ) hm.prefetch(sv.keys[s + kAhead]);
+          if (s + kAhead / 2 < n_succ && !std::isinf(sv.cost[s + kAhead / 2]))
+            if (const Node *nx = hm.peek(sv.keys[s + kAhead / 2])) __builtin_prefetch(nx);
         }
-        if (std::isinf(cost[(size_t)s])) continue;  // graph_search.h:81
-        const double *sc = &succ[(size_t)s * f];
-        const uint64_t key = have_keys ? keys[(size_t)s] : lattice_hash(dim, control, sc);
+        const double c_s = sv.cost[s];
+        if (std::isinf(c_s)) continue;  // graph_search.h:81
+        uint64_t key;
+        bool have_sc = false;
+        auto gather = [&] {
+          if (!have_sc)
+            for (int r = 0; r < f; r++) sc[r] = sv.state[(int64_t)r * sv.fs + (int64_t)s * sv.es];
+          have_sc = true;
+        };
+        if (have_keys) key = sv.keys[s];
+        else { gather(); key = lattice_hash(dim, control, sc); }
         NodePtr &child = hm[key];
         if (!child) {
+          gather();
           pool.emplace_back();
           child = &pool.back();
           std::copy(sc, sc + f, child->coord);
@@ -420,12 +463,12 @@ class Planner {
         }
         {
           const int32_t rec = (int32_t)preds.size();
-          preds.push_back({curr->key, cost[(size_t)s], act[(size_t)s], -1});
+          preds.push_back({curr->key, c_s, sv.act[s], -1});
           if (child->pred_tail >= 0) preds[(size_t)child->pred_tail].next = rec;
           else child->pred_head = rec;
           child->pred_tail = rec;
         }
-        const double tentative = curr->g + cost[(size_t)s];
+        const double tentative = curr->g + c_s;
         if (tentative < child->g) {
           child->g = tentative;
           const double fval = child->g + eps * child->h;
@@ -460,15 +503,33 @@ class Planner {
   std::vector<int32_t> b_cnt, b_act;  // staging of one batched launch (lists provider)
   std::vector<double> b_cost, b_state;
   std::vector<uint64_t> b_hash;
+  std::vector<double> v_succ, v_cost;  // the current expansion's successors (providers that fill caller arrays)
+  std::vector<int32_t> v_act;
+  std::vector<uint64_t> v_keys;
+  char *cur_blob = nullptr;            // ... or the packed lists of the node being expanded
+  // Buffers of the packed lists: fixed capacity (a full list), recycled when their node has been expanded, so
+  // that steady state touches no fresh pages (a fresh 40-KB allocation per node cost more than the copy itself).
+  std::vector<std::unique_ptr<char[]>> all_blobs;
+  std::vector<char *> free_blobs;
+  char *take_blob() {
+    if (!free_blobs.empty()) { char *b = free_blobs.back(); free_blobs.pop_back(); return b; }
+    all_blobs.emplace_back(new char[(size_t)nU * (size_t)(8 + 8 + 8 * F() + 4)]);
+    return all_blobs.back().get();
+  }
   // One get_succ, possibly served from / filling the batch cache.
-  int successors(const NodePtr &curr, double *succ, double *cost, int32_t *act, uint64_t *keys, bool *have_keys,
-                 int32_t *n_succ) {
+  int successors(const NodePtr &curr, SuccView *v) {
     const int f = F();
-    if (batch <= 1 || (!batched && !lists)) {
+    if (batch <= 1 || (!batched && !lists && !packed)) {
       last.device_launches++;
       last.pairs += nU;
-      if (single) return single(user, curr->coord, succ, cost, act, n_succ);
-      return run_batch({curr}), fetch(curr, succ, cost, act, keys, have_keys, n_succ);
+      int32_t m = 0;
+      if (single) {
+        if (int rc = single(user, curr->coord, v_succ.data(), v_cost.data(), v_act.data(), &m)) return rc;
+        *v = SuccView{m, v_cost.data(), nullptr, v_act.data(), v_succ.data(), 1, f};
+        return 0;
+      }
+      if (int rc = run_batch({curr})) return rc;
+      return fetch(curr, v);
     }
     if (!curr->cached) {
       const auto t_p0 = std::chrono::steady_clock::now();
@@ -497,8 +558,7 @@ class Planner {
       t_pick += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p0).count();
       if (int rc = run_batch(group)) return rc;
     }
-    (void)f;
-    return fetch(curr, succ, cost, act, keys, have_keys, n_succ);
+    return fetch(curr, v);
   }
 
   int run_batch(const std::vector<NodePtr> &group) {
@@ -510,6 +570,27 @@ class Planner {
     const int64_t slots = n * nU;
     last.device_launches++;
     last.pairs += slots;
+    if (packed) {
+      const auto t_l0 = std::chrono::steady_clock::now();
+      PackedView pv;
+      if (int rc = packed(user, nodes.data(), n, &pv)) return rc;
+      const auto t_l1 = std::chrono::steady_clock::now();
+      t_provider += std::chrono::duration<double, std::milli>(t_l1 - t_l0).count();
+      for (int64_t k = 0; k < n; k++) {
+        Node &nd = *group[(size_t)k];
+        const size_t m = (size_t)pv.count[k], o = (size_t)pv.offs[k];
+        nd.c_m = (int32_t)m;
+        if (!nd.c_blob) nd.c_blob = take_blob();
+        char *b = nd.c_blob;
+        std::memcpy(b, pv.cost + o, m * 8);
+        std::memcpy(b + m * 8, pv.hash + o, m * 8);
+        for (int r = 0; r < f; r++) std::memcpy(b + m * 8 * (size_t)(2 + r), pv.state + (size_t)r * pv.total + o, m * 8);
+        std::memcpy(b + m * 8 * (size_t)(2 + f), pv.action + o, m * 4);
+        nd.cached = true;
+      }
+      t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_l1).count();
+      return 0;
+    }
     if (lists) {
       // compact per-node lists with the device's lattice hashes: no scan of skipped slots, no host hashing
       b_cnt.resize((size_t)n);
@@ -561,15 +642,25 @@ class Planner {
     return 0;
   }
 
-  int fetch(const NodePtr &n, double *succ, double *cost, int32_t *act, uint64_t *keys, bool *have_keys,
-            int32_t *n_succ) {
+  int fetch(const NodePtr &n, SuccView *v) {
     if (!n->cached) return -1;
-    std::copy(n->c_succ.begin(), n->c_succ.end(), succ);
-    std::copy(n->c_cost.begin(), n->c_cost.end(), cost);
-    std::copy(n->c_act.begin(), n->c_act.end(), act);
-    *n_succ = (int32_t)n->c_act.size();
-    *have_keys = n->c_key.size() == n->c_act.size() && !n->c_act.empty();
-    if (*have_keys) std::copy(n->c_key.begin(), n->c_key.end(), keys);
+    const int f = F();
+    if (packed) {
+      if (cur_blob) free_blobs.push_back(cur_blob);  // the previous expansion's lists are done with
+      cur_blob = n->c_blob;  // a closed node is never expanded again: the planner takes its lists over
+      n->c_blob = nullptr;
+      const size_t m = (size_t)n->c_m;
+      const char *b = cur_blob;
+      *v = SuccView{(int32_t)m, (const double *)b, (const uint64_t *)(b + m * 8), (const int32_t *)(b + m * 8 * (size_t)(2 + f)),
+                    (const double *)(b + m * 16), (int64_t)m, 1};
+      return 0;
+    }
+    std::copy(n->c_succ.begin(), n->c_succ.end(), v_succ.begin());
+    std::copy(n->c_cost.begin(), n->c_cost.end(), v_cost.begin());
+    std::copy(n->c_act.begin(), n->c_act.end(), v_act.begin());
+    const bool have_keys = n->c_key.size() == n->c_act.size() && !n->c_act.empty();
+    if (have_keys) std::copy(n->c_key.begin(), n->c_key.end(), v_keys.begin());
+    *v = SuccView{(int32_t)n->c_act.size(), v_cost.data(), have_keys ? v_keys.data() : nullptr, v_act.data(), v_succ.data(), 1, f};
     n->c_key.clear(); n->c_key.shrink_to_fit();
     n->c_succ.clear(); n->c_succ.shrink_to_fit();  // a closed node is never expanded again
     return 0;

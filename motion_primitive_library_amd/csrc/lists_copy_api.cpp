@@ -68,6 +68,9 @@ void release_copy_buffers(mplx_ctx *c) {
   }
   c->pk_pin_cap = 0;
   release(c->pk_offs);
+  if (c->pk_hb) (void)hipHostFree(c->pk_hb);
+  c->pk_hb = nullptr;
+  c->pk_hb_cap = 0;
 }
 
 int copy_lists_to_host(mplx_ctx *c, const mplx_succ_lists &d, const mplx_succ_lists *h, int64_t n_nodes) {
@@ -210,6 +213,87 @@ int copy_lists_to_host(mplx_ctx *c, const mplx_succ_lists &d, const mplx_succ_li
     return rc;
   }
   join_all();
+  return MPLX_OK;
+}
+
+int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t node_stride, PackedLists *out) {
+  if (!c || !out || !h_nodes || n_nodes <= 0 || node_stride < n_nodes) return fail(c, MPLX_ERR_ARG, "expand_lists_packed: bad arguments");
+  if (int rc = ctx_ready(c)) return rc;
+  if (int rc = bind_device(c)) return rc;
+  const int F = 4 * c->dim + 2;
+  const int64_t S = (c->nU + 31) & ~31;  // line-aligned node stride (see expand_grid_kernel.hip)
+  const int64_t n_slots = n_nodes * S;
+  // pinned host block: [nodes F x n][count n][offs n + 1]
+  const size_t o_cnt = ((size_t)F * n_nodes * 8 + 255) & ~(size_t)255;
+  const size_t o_off = (o_cnt + (size_t)n_nodes * 4 + 255) & ~(size_t)255;
+  const size_t hb_bytes = o_off + (size_t)(n_nodes + 1) * 8;
+  if (hb_bytes > c->pk_hb_cap) {
+    if (c->pk_hb) HIP_TRY(c, hipHostFree(c->pk_hb));
+    c->pk_hb = nullptr;
+    c->pk_hb_cap = 0;
+    HIP_TRY(c, hipHostMalloc(&c->pk_hb, hb_bytes * 2, hipHostMallocDefault));
+    c->pk_hb_cap = hb_bytes * 2;
+  }
+  char *hb = (char *)c->pk_hb;
+  for (int f = 0; f < F; f++)
+    std::memcpy(hb + (size_t)f * n_nodes * 8, h_nodes + (size_t)f * node_stride, (size_t)n_nodes * 8);
+  if (int rc = ensure(c, c->s_nodes, (size_t)F * n_nodes * 8)) return rc;
+  if (int rc = ensure(c, c->s_count, (size_t)n_nodes * 4)) return rc;
+  if (int rc = ensure(c, c->s_action, (size_t)n_slots * 4)) return rc;
+  if (int rc = ensure(c, c->s_cost, (size_t)n_slots * 8)) return rc;
+  if (int rc = ensure(c, c->s_hash, (size_t)n_slots * 8)) return rc;
+  if (int rc = ensure(c, c->s_state, (size_t)F * n_slots * 8)) return rc;
+  if (int rc = ensure(c, c->pk_offs, (size_t)n_nodes * 8)) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->s_nodes.p, hb, (size_t)F * n_nodes * 8, hipMemcpyHostToDevice, c->stream));
+  mplx_succ_lists d{};
+  d.count = (int32_t *)c->s_count.p;
+  d.action = (int32_t *)c->s_action.p;
+  d.cost = (double *)c->s_cost.p;
+  d.hash = (uint64_t *)c->s_hash.p;
+  d.state = (double *)c->s_state.p;
+  d.state_stride = n_slots;
+  d.node_stride = S;
+  if (int rc = lists_on_device(c, (const double *)c->s_nodes.p, n_nodes, n_nodes, &d)) return rc;
+  int32_t *cnt = (int32_t *)(hb + o_cnt);
+  int64_t *offs = (int64_t *)(hb + o_off);
+  HIP_TRY(c, hipMemcpyAsync(cnt, d.count, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int64_t total = 0;
+  for (int64_t k = 0; k < n_nodes; k++) { offs[k] = total; total += cnt[k]; }
+  offs[n_nodes] = total;
+  *out = PackedLists{};
+  out->total = total;
+  out->count = cnt;
+  out->offs = offs;
+  if (total == 0) return MPLX_OK;
+  const int bpe = 8 + 8 + 8 * F + 4;
+  const size_t bytes = ((size_t)total * bpe + 255) & ~(size_t)255;
+  if (int rc = ensure_pinned(c, bytes)) return rc;
+  if (int rc = ensure(c, c->pk_dev[0], bytes)) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->pk_offs.p, offs, (size_t)n_nodes * 8, hipMemcpyHostToDevice, c->stream));
+  mplx::PackArgs a{};
+  int r = 0;
+  int64_t o = 0;
+  auto row = [&](const void *src, int es) { a.src[r] = src; a.dst_off[r] = o; a.es[r] = es; o += total * es; r++; };
+  row(d.cost, 8);
+  row(d.hash, 8);
+  for (int f = 0; f < F; f++) row(d.state + (size_t)f * n_slots, 8);
+  row(d.action, 4);
+  a.n_rows = r;
+  a.node_stride = S;
+  a.count = d.count;
+  a.offs = (const int64_t *)c->pk_offs.p;
+  a.node0 = 0;
+  a.off0 = 0;
+  a.dst = (char *)c->pk_dev[0].p;
+  HIP_TRY(c, mplx::launch_pack_rows(a, n_nodes, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->pk_pin[0], c->pk_dev[0].p, (size_t)total * bpe, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const char *pin = (const char *)c->pk_pin[0];
+  out->cost = (const double *)(pin + a.dst_off[0]);
+  out->hash = (const uint64_t *)(pin + a.dst_off[1]);
+  out->state = (const double *)(pin + a.dst_off[2]);
+  out->action = (const int32_t *)(pin + a.dst_off[2 + F]);
   return MPLX_OK;
 }
 

@@ -594,6 +594,13 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
 
 }  // namespace
 
+namespace mplx_detail {
+int ctx_ready(mplx_ctx *c) { return ready(c); }
+int lists_on_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride, const mplx_succ_lists *d) {
+  return lists_device(c, d_nodes, n_nodes, node_stride, d);
+}
+}  // namespace mplx_detail
+
 extern "C" {
 
 int mplx_expand_lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride,

@@ -80,6 +80,8 @@ struct mplx_ctx {
   size_t pk_pin_cap = 0;
   hipEvent_t pk_ev[2] = {nullptr, nullptr};
   std::vector<int64_t> pk_hoffs;
+  void *pk_hb = nullptr;  // pinned block of expand_lists_packed: nodes, counts, offsets
+  size_t pk_hb_cap = 0;
   std::vector<uint8_t> h_status;
   std::vector<double> h_cost, h_state;
 };
@@ -127,6 +129,23 @@ inline void release(DevBuf &b) {
   b.p = nullptr;
   b.cap = 0;
 }
+
+// The per-node lists of a host frontier, left packed in the context's pinned landing buffer (node k owns entries
+// [offs[k], offs[k+1]) of every row): for callers inside the library that consume the lists at once (the host search,
+// planner_capi.cpp) and would only copy them again.  Valid until the next call on the context.
+struct PackedLists {
+  int64_t total = 0;
+  const int32_t *count = nullptr;   // [n_nodes]
+  const int64_t *offs = nullptr;    // [n_nodes + 1]
+  const double *cost = nullptr;     // [total]
+  const uint64_t *hash = nullptr;   // [total]
+  const int32_t *action = nullptr;  // [total]
+  const double *state = nullptr;    // [4D+2][total]
+};
+int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t node_stride, PackedLists *out);
+// mplx_api.cpp: readiness check and the route dispatch behind mplx_expand_lists*
+int ctx_ready(mplx_ctx *c);
+int lists_on_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride, const mplx_succ_lists *d);
 
 // lists_copy_api.cpp: device lists -> host lists, only the used prefixes, pipelined through pinned memory
 int copy_lists_to_host(mplx_ctx *c, const mplx_succ_lists &d, const mplx_succ_lists *h_out, int64_t n_nodes);

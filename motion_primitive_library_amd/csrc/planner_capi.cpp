@@ -2,6 +2,7 @@
 // "host search" section) on top of host_planner.hpp.
 #include "../../include/mplx.h"
 #include "host_planner.hpp"
+#include "mplx_ctx.h"
 
 #include <new>
 #include <string>
@@ -42,6 +43,20 @@ int engine_lists(void *user, const double *nodes, int64_t n, int32_t *count, int
   return mplx_expand_lists(p->ctx, nodes, n, n, &o);
 }
 
+int engine_packed(void *user, const double *nodes, int64_t n, mplx::host::PackedView *out) {
+  mplx_planner *p = (mplx_planner *)user;
+  mplx_detail::PackedLists pl;
+  if (int rc = mplx_detail::expand_lists_packed(p->ctx, nodes, n, n, &pl)) return rc;
+  out->total = pl.total;
+  out->count = pl.count;
+  out->offs = pl.offs;
+  out->cost = pl.cost;
+  out->hash = pl.hash;
+  out->action = pl.action;
+  out->state = pl.state;
+  return 0;
+}
+
 int fail(mplx_planner *p, int code, const char *msg) {
   if (p) p->err = msg;
   return code;
@@ -71,6 +86,7 @@ int mplx_planner_attach_ctx(mplx_planner *p, mplx_ctx *ctx) {
   p->pl.single = engine_single;
   p->pl.batched = engine_batch;
   p->pl.lists = engine_lists;
+  p->pl.packed = getenv("MPLX_PLAN_NO_PACKED") ? nullptr : engine_packed;  // the knob: A/B only
   p->pl.user = p;
   return MPLX_OK;
 }
@@ -81,6 +97,7 @@ int mplx_planner_set_provider(mplx_planner *p, mplx_succ_fn single, mplx_batch_f
   p->pl.single = single;
   p->pl.batched = batched;
   p->pl.lists = nullptr;
+  p->pl.packed = nullptr;
   p->pl.user = user;
   return MPLX_OK;
 }
