@@ -42,6 +42,7 @@
 #include <mpl_planner/env/env_map.h>
 #include <mpl_planner/planner/map_planner.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -63,13 +64,23 @@ class env_map_hip : public env_map<Dim> {
       ctx_ = nullptr;
     }
   }
-  ~env_map_hip() { mplx_destroy(ctx_); }
+  ~env_map_hip() {
+    if (getenv("MPLX_ADAPTER_TIMING"))
+      printf("[env_map_hip] get_succ total %.1f ms (device launches %.1f ms) over %d launches\n", t_total_ * 1e3, t_launch_ * 1e3, launches_);
+    mplx_destroy(ctx_);
+  }
   env_map_hip(const env_map_hip &) = delete;
   env_map_hip &operator=(const env_map_hip &) = delete;
 
   bool ok() const { return ctx_ != nullptr; }
   /// Nodes per device launch (1 = one launch per get_succ, the default).
   void set_batch(int n) { batch_ = n < 1 ? 1 : n; drop_cache(); }
+  /// env_map::get_succ also records every finite edge as a Primitive in expanded_edges_ (env_map.h:166, read by
+  /// PlannerBase::getExpandedEdges for drawing): a 200-byte object per relaxed edge, a fifth of the reference's
+  /// plan() time on 3D problems.  Kept by default without batching (identical side effects); with batching it is
+  /// off unless asked for.
+  void set_record_edges(bool on) { record_edges_ = on ? 1 : 0; }
+  bool record_edges() const { return record_edges_ < 0 ? batch_ <= 1 : record_edges_ != 0; }
   int launches() const { return launches_; }
   /// Re-upload the map / potential / region before the next expansion.
   void notify_map_changed() { maps_stale_ = true; }
@@ -89,6 +100,11 @@ class env_map_hip : public env_map<Dim> {
   /// The hot path: same contract as env_map<Dim>::get_succ.
   void get_succ(const Waypoint<Dim> &curr, vec_E<Waypoint<Dim>> &succ, std::vector<decimal_t> &succ_cost,
                 std::vector<int> &action_idx) const override {
+    struct Tick {
+      double &acc;
+      std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+      ~Tick() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    } tick{t_total_};
     succ.clear();
     succ_cost.clear();
     action_idx.clear();
@@ -117,16 +133,16 @@ class env_map_hip : public env_map<Dim> {
         if (std::isinf(buf_cost_[(size_t)m])) continue;
         const uint64_t ck = c.keys[(size_t)m];
         const double cg = g + buf_cost_[(size_t)m];
-        auto gi = g_est_.find(ck);
-        if (gi != g_est_.end() && gi->second <= cg) continue;
-        g_est_[ck] = cg;
-        Waypoint<Dim> tn(curr.control);
-        unpack(&buf_succ_[(size_t)m * F], tn);
+        if (m + 12 < n) g_est_.prefetch(c.keys[(size_t)m + 12]);
+        const double *gi = g_est_.find(ck);
+        if (gi && *gi <= cg) continue;
+        g_est_.put(ck, cg);
         Cand cand;
-        cand.f = cg + this->get_heur(tn);
+        cand.f = cg + rank_heur(&buf_succ_[(size_t)m * F], tn_scratch_);
         cand.g = cg;
         cand.key = ck;
-        std::memcpy(cand.row, &buf_succ_[(size_t)m * F], sizeof(double) * F);
+        cand.row = (uint32_t)(rows_.size() / F);
+        rows_.insert(rows_.end(), &buf_succ_[(size_t)m * F], &buf_succ_[(size_t)m * F] + F);
         shadow_.push(cand);
       }
       cache_.erase(it);
@@ -141,13 +157,17 @@ class env_map_hip : public env_map<Dim> {
         return;
       }
     }
+    const bool rec = record_edges();
+    succ.reserve((size_t)n);
+    succ_cost.reserve((size_t)n);
+    action_idx.reserve((size_t)n);
     for (int m = 0; m < n; m++) {
       Waypoint<Dim> tn(curr.control);
       unpack(&buf_succ_[(size_t)m * F], tn);
       succ.push_back(tn);
       succ_cost.push_back(buf_cost_[(size_t)m]);
       action_idx.push_back(buf_act_[(size_t)m]);
-      if (!std::isinf(buf_cost_[(size_t)m]))  // debug side effect of env_map.h:166
+      if (rec && !std::isinf(buf_cost_[(size_t)m]))  // debug side effect of env_map.h:166
         this->expanded_edges_.push_back(Primitive<Dim>(curr, this->U_[buf_act_[(size_t)m]], this->dt_));
     }
   }
@@ -211,6 +231,56 @@ class env_map_hip : public env_map<Dim> {
   }
 
  private:
+  // lattice hash -> best path cost seen so far (open addressing, linear probing; NaN marks an empty slot)
+  class GMap {
+   public:
+    double *find(uint64_t key) {
+      if (!cap_) return nullptr;
+      for (size_t i = slot(key);; i = (i + 1) & (cap_ - 1)) {
+        if (used_[i] == 0) return nullptr;
+        if (keys_[i] == key) return &vals_[i];
+      }
+    }
+    void put(uint64_t key, double v) {
+      if ((n_ + 1) * 10 > cap_ * 6) grow();
+      size_t i = slot(key);
+      while (used_[i] && keys_[i] != key) i = (i + 1) & (cap_ - 1);
+      if (!used_[i]) { used_[i] = 1; keys_[i] = key; n_++; }
+      vals_[i] = v;
+    }
+    void prefetch(uint64_t key) const {
+      if (cap_) { const size_t i = slot(key); __builtin_prefetch(&keys_[i]); __builtin_prefetch(&used_[i]); __builtin_prefetch(&vals_[i]); }
+    }
+    void clear() { keys_.clear(); vals_.clear(); used_.clear(); cap_ = n_ = 0; }
+
+   private:
+    size_t slot(uint64_t k) const {
+      k ^= k >> 33;
+      k *= 0xff51afd7ed558ccdULL;
+      k ^= k >> 33;
+      return (size_t)k & (cap_ - 1);
+    }
+    void grow() {
+      std::vector<uint64_t> ok;
+      std::vector<double> ov;
+      std::vector<uint8_t> ou;
+      ok.swap(keys_); ov.swap(vals_); ou.swap(used_);
+      const size_t old_cap = cap_;
+      cap_ = cap_ ? cap_ * 2 : 4096;
+      keys_.assign(cap_, 0); vals_.assign(cap_, 0.0); used_.assign(cap_, 0);
+      for (size_t j = 0; j < old_cap; j++)
+        if (ou[j]) {
+          size_t i = slot(ok[j]);
+          while (used_[i]) i = (i + 1) & (cap_ - 1);
+          used_[i] = 1; keys_[i] = ok[j]; vals_[i] = ov[j];
+        }
+    }
+    std::vector<uint64_t> keys_;
+    std::vector<double> vals_;
+    std::vector<uint8_t> used_;
+    size_t cap_ = 0, n_ = 0;
+  };
+
   struct Cached {
     std::vector<double> succ, cost;  // succ: [n][4D+2]
     std::vector<int32_t> act;
@@ -220,9 +290,23 @@ class env_map_hip : public env_map<Dim> {
   struct Cand {
     double f, g;
     uint64_t key;
-    double row[4 * Dim + 2];
+    uint32_t row;  // index into rows_ (the state, 4D+2 doubles)
     bool operator<(const Cand &o) const { return f > o.f; }  // smallest f on top
   };
+
+  // f-value used to rank speculation candidates: the search's own heuristic.  The default one
+  // (env_base.h:58-64) is evaluated in place -- get_heur would hash the state and the goal first
+  // (env_base.h:47) -- any other goes through the virtual.  Ranking only decides which nodes share a
+  // launch, never a result.
+  double rank_heur(const double *row, Waypoint<Dim> &scratch) const {
+    if (this->heur_ignore_dynamics_ && this->prior_traj_.empty()) {
+      double m = 0;
+      for (int i = 0; i < Dim; i++) m = std::max(m, std::abs(row[i] - this->goal_node_.pos(i)));
+      return this->v_max_ > 0 ? this->w_ * m / this->v_max_ : this->w_ * m;
+    }
+    unpack(row, scratch);
+    return this->get_heur(scratch);
+  }
 
   // the engine's lattice hash (waypoint.h:93-125 with the classic hash_combine), for cache keys only
   static uint64_t lattice_hash(int control, const double *w) {
@@ -242,6 +326,7 @@ class env_map_hip : public env_map<Dim> {
     cache_.clear();
     g_est_.clear();
     asked_.clear();
+    rows_.clear();
     shadow_ = std::priority_queue<Cand>();
   }
 
@@ -252,18 +337,18 @@ class env_map_hip : public env_map<Dim> {
     std::vector<uint64_t> gk{key};
     std::vector<double> rows(node, node + F), gg;
     {
-      auto gi = g_est_.find(key);
-      gg.push_back(gi == g_est_.end() ? 0.0 : gi->second);
+      const double *gi = g_est_.find(key);
+      gg.push_back(gi ? *gi : 0.0);
     }
     while ((int)gk.size() < batch_ && !shadow_.empty()) {
       const Cand c = shadow_.top();
       shadow_.pop();
-      auto gi = g_est_.find(c.key);
-      if (gi != g_est_.end() && gi->second < c.g) continue;             // superseded by a better path
+      const double *gi = g_est_.find(c.key);
+      if (gi && *gi < c.g) continue;                                    // superseded by a better path
       if (c.key == key || asked_.count(c.key) || cache_.count(c.key)) continue;  // already served / cached
       gk.push_back(c.key);
       gg.push_back(c.g);
-      rows.insert(rows.end(), c.row, c.row + F);
+      rows.insert(rows.end(), &rows_[(size_t)c.row * F], &rows_[(size_t)c.row * F] + F);
     }
     const int64_t n = (int64_t)gk.size(), slots = n * nU;
     nodes_fm_.resize((size_t)F * n);
@@ -282,7 +367,12 @@ class env_map_hip : public env_map<Dim> {
     o.state = l_state_.data();
     o.state_stride = slots;
     launches_++;
-    if (mplx_expand_lists(ctx_, nodes_fm_.data(), n, n, &o) != MPLX_OK) return complain();
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      const int rc = mplx_expand_lists(ctx_, nodes_fm_.data(), n, n, &o);
+      t_launch_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (rc != MPLX_OK) return complain();
+    }
     for (int64_t k = 0; k < n; k++) {
       Cached &c = cache_[gk[(size_t)k]];
       const int32_t m = l_count_[(size_t)k];
@@ -389,11 +479,15 @@ class env_map_hip : public env_map<Dim> {
   mutable std::vector<int32_t> buf_act_;
   // speculative batching
   int batch_ = 1;
+  int record_edges_ = -1;  // -1: automatic (on without batching)
   mutable int launches_ = 0;
+  mutable double t_total_ = 0, t_launch_ = 0;  // MPLX_ADAPTER_TIMING diagnostics
   mutable std::unordered_map<uint64_t, Cached> cache_;
-  mutable std::unordered_map<uint64_t, double> g_est_;
+  mutable GMap g_est_;
   mutable std::unordered_map<uint64_t, bool> asked_;
   mutable std::priority_queue<Cand> shadow_;
+  mutable std::vector<double> rows_;  // states of the candidates in shadow_
+  mutable Waypoint<Dim> tn_scratch_;
   mutable std::vector<double> nodes_fm_, l_cost_, l_state_;
   mutable std::vector<int32_t> l_count_, l_act_;
   mutable std::vector<uint64_t> l_hash_;
