@@ -158,9 +158,10 @@ int mplx_get_succ(mplx_ctx *ctx, const double *node, double *succ, double *cost,
  * skipped ones are not.  Only emitted successors are written, so this is the
  * bandwidth-lean output (SURVEY.md 8d counts exactly these bytes).  Any pointer
  * but `count` may be NULL.  `state` as in mplx_succ (row stride state_stride >=
- * n_nodes*S doubles).  A node_stride that is a multiple of 16 entries makes
- * every 64-successor store of the kernels start on a 128-byte line (measured
- * 11 % faster on C4 than S = 729).                                            */
+ * n_nodes*S doubles).  A node_stride that is a multiple of 32 entries makes
+ * every 64-successor store of the kernels a set of full 128-byte lines and lets
+ * the kernel complete the last line of each list (entries past count[k] up to
+ * the next multiple of 32 are then unspecified): ~20 % faster on C4 than S = 729. */
 typedef struct {
   int32_t *count;          /* [n_nodes]                                       */
   int32_t *action;         /* [n_nodes*S] control index of each successor     */
@@ -173,11 +174,17 @@ typedef struct {
 } mplx_succ_lists;
 
 /* Batched get_succ producing lists; device pointers, asynchronous on the
- * context stream.  Uses the tiled kernel (expand_tile_kernel.hip) where it
- * applies and otherwise the dense kernel followed by an on-device compaction. */
+ * context stream.  Kernel: expand_grid_kernel.hip for control tables with at
+ * most 16 distinct values per axis (incl. yaw rates; potential maps with
+ * gradient_weight == 0), else expand_tile_kernel.hip, else the dense kernel
+ * followed by an on-device compaction (mplx_set_lists_route forces one).      */
 int mplx_expand_lists_device(mplx_ctx *ctx, const double *d_nodes, int64_t n_nodes, int64_t node_stride,
                              const mplx_succ_lists *d_out);
-/* Same with host buffers (H2D, kernels, D2H of the used prefix, synchronised). */
+/* Same with host buffers, synchronised.  Only the used prefix of every list is
+ * written to the host arrays (entries past count[k] are left untouched).  Up to
+ * 4 MiB of lists: one upload, the kernel, one download through a pinned arena
+ * (a single get_succ: ~30 - 50 us end to end); larger batches are packed on the
+ * device and pipelined through pinned buffers at the PCIe link rate.            */
 int mplx_expand_lists(mplx_ctx *ctx, const double *h_nodes, int64_t n_nodes, int64_t node_stride,
                       const mplx_succ_lists *h_out);
 
