@@ -182,9 +182,10 @@ int mplx_expand_lists_device(mplx_ctx *ctx, const double *d_nodes, int64_t n_nod
                              const mplx_succ_lists *d_out);
 /* Same with host buffers, synchronised.  Only the used prefix of every list is
  * written to the host arrays (entries past count[k] are left untouched).  Up to
- * 4 MiB of lists: one upload, the kernel, one download through a pinned arena
- * (a single get_succ: ~30 - 50 us end to end); larger batches are packed on the
- * device and pipelined through pinned buffers at the PCIe link rate.            */
+ * 8 MiB of lists the kernel reads the nodes from and writes the lists to a pinned
+ * host block itself (a single get_succ: ~25 - 45 us end to end); larger batches
+ * are packed on the device and pipelined through pinned buffers at the PCIe link
+ * rate.                                                                        */
 int mplx_expand_lists(mplx_ctx *ctx, const double *h_nodes, int64_t n_nodes, int64_t node_stride,
                       const mplx_succ_lists *h_out);
 

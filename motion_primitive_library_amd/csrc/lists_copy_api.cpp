@@ -223,6 +223,50 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
   const int F = 4 * c->dim + 2;
   const int64_t S = (c->nU + 31) & ~31;  // line-aligned node stride (see expand_grid_kernel.hip)
   const int64_t n_slots = n_nodes * S;
+  if (c->tune.zero_copy && (size_t)n_slots * (size_t)(F * 8 + 24) <= ((size_t)32 << 20)) {
+    // Batches of a search: the kernel reads the nodes from and writes the lists into one pinned host block itself
+    // (only the used entries cross PCIe, while the kernel runs): the call is the kernel and one synchronisation.
+    // The view then describes the strided lists as they are: offs[k] = k * S, row stride n_nodes * S.
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_cnt = up((size_t)F * n_nodes * 8);
+    const size_t o_off = o_cnt + up((size_t)n_nodes * 4);
+    const size_t o_act = o_off + up((size_t)(n_nodes + 1) * 8);
+    const size_t o_cost = o_act + up((size_t)n_slots * 4);
+    const size_t o_hash = o_cost + up((size_t)n_slots * 8);
+    const size_t o_state = o_hash + up((size_t)n_slots * 8);
+    const size_t bytes = o_state + up((size_t)F * n_slots * 8);
+    if (bytes > c->pk_hb_cap) {
+      if (c->pk_hb) HIP_TRY(c, hipHostFree(c->pk_hb));
+      c->pk_hb = nullptr;
+      c->pk_hb_cap = 0;
+      HIP_TRY(c, hipHostMalloc(&c->pk_hb, bytes + bytes / 2, hipHostMallocDefault));
+      c->pk_hb_cap = bytes + bytes / 2;
+    }
+    char *hb = (char *)c->pk_hb;
+    for (int f = 0; f < F; f++)
+      std::memcpy(hb + (size_t)f * n_nodes * 8, h_nodes + (size_t)f * node_stride, (size_t)n_nodes * 8);
+    mplx_succ_lists d{};
+    d.count = (int32_t *)(hb + o_cnt);
+    d.action = (int32_t *)(hb + o_act);
+    d.cost = (double *)(hb + o_cost);
+    d.hash = (uint64_t *)(hb + o_hash);
+    d.state = (double *)(hb + o_state);
+    d.state_stride = n_slots;
+    d.node_stride = S;
+    if (int rc = lists_on_device(c, (const double *)hb, n_nodes, n_nodes, &d)) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int64_t *offs = (int64_t *)(hb + o_off);
+    for (int64_t k = 0; k <= n_nodes; k++) offs[k] = k * S;
+    *out = PackedLists{};
+    out->total = n_slots;
+    out->count = d.count;
+    out->offs = offs;
+    out->cost = d.cost;
+    out->hash = d.hash;
+    out->action = d.action;
+    out->state = d.state;
+    return MPLX_OK;
+  }
   // pinned host block: [nodes F x n][count n][offs n + 1]
   const size_t o_cnt = ((size_t)F * n_nodes * 8 + 255) & ~(size_t)255;
   const size_t o_off = (o_cnt + (size_t)n_nodes * 4 + 255) & ~(size_t)255;

@@ -115,6 +115,7 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
     c->tune.grid_blocks = env_int("MPLX_GRID_BLOCKS");
     c->tune.dbg = env_int("MPLX_TILE_DBG");
     c->tune.arena_kb = env_int("MPLX_ARENA_KB");
+    c->tune.zero_copy = getenv("MPLX_ZERO_COPY") ? env_int("MPLX_ZERO_COPY") : 1;
     c->tune.no_sat = getenv("MPLX_GRID_NOSAT") != nullptr;
     c->tune.no_lex = getenv("MPLX_GRID_NOLEX") != nullptr;
     c->tune.no_line_pad = getenv("MPLX_NO_LINE_PAD") != nullptr;
@@ -633,10 +634,11 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
   if (h_out->state && h_out->state_stride < n_slots)
     return fail(c, MPLX_ERR_ARG, "mplx_expand_lists: state_stride < n_nodes*node_stride");
   {
-    // Small batches (one get_succ, or the speculative batches of a search on a small control table) are latency
-    // bound: nodes and every output row live in ONE device arena mirrored by ONE pinned host buffer, so a call is
-    // one upload, the kernel, one download and one synchronisation; the used prefixes are then copied into the
-    // caller's arrays.  (Separate pageable copies per row cost 10 - 15 us each.)
+    // Small batches (one get_succ, or the speculative batches of a search) are latency bound: nodes and every
+    // output row live in ONE pinned host block that the kernel reads and writes itself over PCIe (only the used
+    // list entries cross the link, while the kernel runs), so a call is the kernel and one synchronisation; the
+    // used prefixes are then copied into the caller's arrays.  (A 2D 9-control get_succ: 25 us; with one pageable
+    // copy per row 111 us, with one upload + one download through a device arena 28 us -- MPLX_ZERO_COPY=0.)
     const size_t S = (size_t)(h_out->node_stride ? h_out->node_stride : c->nU);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_count = up((size_t)F * n_nodes * 8);
@@ -646,7 +648,7 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
     const size_t o_iters = o_hash + (h_out->hash ? up((size_t)n_slots * 8) : 0);
     const size_t o_state = o_iters + (h_out->iters ? up((size_t)n_slots * 4) : 0);
     const size_t total = o_state + (h_out->state ? up((size_t)F * n_slots * 8) : 0);
-    const size_t arena_max = c->tune.arena_kb > 0 ? (size_t)c->tune.arena_kb << 10 : (size_t)4 << 20;
+    const size_t arena_max = c->tune.arena_kb > 0 ? (size_t)c->tune.arena_kb << 10 : (size_t)8 << 20;
     if (total <= arena_max) {
       if (int rc = ensure(c, c->s_arena, total)) return rc;
       if (total > c->h_arena_cap) {
@@ -659,7 +661,9 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
       char *hb = (char *)c->h_arena, *db = (char *)c->s_arena.p;
       for (int f = 0; f < F; f++)
         std::memcpy(hb + (size_t)f * n_nodes * 8, h_nodes + (size_t)f * node_stride, (size_t)n_nodes * 8);
-      HIP_TRY(c, hipMemcpyAsync(db, hb, (size_t)F * n_nodes * 8, hipMemcpyHostToDevice, c->stream));
+      const bool zero_copy = c->tune.zero_copy != 0;
+      if (zero_copy) db = hb;  // the kernel reads the nodes from and writes the lists to the pinned host block itself
+      else HIP_TRY(c, hipMemcpyAsync(db, hb, (size_t)F * n_nodes * 8, hipMemcpyHostToDevice, c->stream));
       mplx_succ_lists d{};
       d.count = (int32_t *)(db + o_count);
       if (h_out->action) d.action = (int32_t *)(db + o_action);
@@ -669,7 +673,8 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
       if (h_out->state) { d.state = (double *)(db + o_state); d.state_stride = n_slots; }
       d.node_stride = h_out->node_stride;
       if (int rc = lists_device(c, (const double *)db, n_nodes, n_nodes, &d)) return rc;
-      HIP_TRY(c, hipMemcpyAsync(hb + o_count, db + o_count, total - o_count, hipMemcpyDeviceToHost, c->stream));
+      if (!zero_copy)
+        HIP_TRY(c, hipMemcpyAsync(hb + o_count, db + o_count, total - o_count, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       const int32_t *cnt = (const int32_t *)(hb + o_count);
       std::memcpy(h_out->count, cnt, (size_t)n_nodes * 4);

@@ -54,6 +54,7 @@ struct mplx_ctx {
   struct Tuning {
     int grid_rmax = 0, grid_boxcap = 0, grid_blocks = 0;  // MPLX_GRID_RMAX / _BOXCAP / _BLOCKS (0 = automatic)
     int dbg = 0;                                         // MPLX_TILE_DBG ablation bits
+    int zero_copy = 1;                                   // MPLX_ZERO_COPY=0: small batches through a device arena instead
     int arena_kb = 0;                                    // MPLX_ARENA_KB: largest batch served by the one-copy path
     bool no_sat = false, no_lex = false, no_line_pad = false;  // MPLX_GRID_NOSAT / MPLX_GRID_NOLEX / MPLX_NO_LINE_PAD
   } tune;
