@@ -486,9 +486,14 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
                  const mplx_succ_lists *o) {
   const int F = 4 * c->dim + 2;
   const int route = c->lists_route;
-  const GridPlan gp = (route == MPLX_ROUTE_AUTO || route == MPLX_ROUTE_GRID) ? plan_grid(c) : GridPlan();
+  GridPlan gp = (route == MPLX_ROUTE_AUTO || route == MPLX_ROUTE_GRID) ? plan_grid(c) : GridPlan();
   if (route == MPLX_ROUTE_GRID && !gp.ok)
     return fail(c, MPLX_ERR_STATE, "lists route GRID does not cover this configuration");
+  // A few hundred nodes with a large control table (the batches of a 3D search) are bound by the latency of
+  // one node, and a node is a whole workgroup in the tiled kernel but a single wave in the factorised one:
+  // 32 us against 54 us per launch for 16 - 256 nodes at |U| = 729 (profiles/micro/route_latency.py; no
+  // difference for |U| <= 125).
+  if (route == MPLX_ROUTE_AUTO && gp.ok && n_nodes <= 512 && c->nU >= 512 && plan_tile(c).ok) gp.ok = false;
   if (gp.ok) {
     if (int rc = ensure_tables(c)) return rc;
     mplx::GridArgs a{};

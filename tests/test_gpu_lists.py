@@ -98,9 +98,16 @@ def test_lists_irregular_control_tables(engine, oracle_lib, dim, n_controls, n_d
     ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
     env = engine_env(engine, wl)
     got = env.expand_lists(wl.nodes)
-    assert env.last_lists_route() == expect
-    env.close()
+    # a frontier of at most 512 nodes with 512+ controls goes to the tiled kernel (latency of one node)
+    assert env.last_lists_route() == ("tile" if n_controls >= 512 else expect)
     assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="irregular U %dx%d" % (n_controls, n_distinct))
+    if expect == "grid" and n_controls >= 512:
+        big = np.tile(wl.nodes, (1, 6))  # 540 nodes: the factorised kernel again
+        got = env.expand_lists(big)
+        assert env.last_lists_route() == "grid"
+        ref6 = {k: (np.tile(v, (1, 6)) if v.ndim == 2 else np.tile(v, 6)) for k, v in ref.items() if hasattr(v, "ndim")}
+        assert_lists_equal(got, ref6, big.shape[1], wl.U.shape[0], what="irregular U %dx%d x6" % (n_controls, n_distinct))
+    env.close()
 
 
 @pytest.mark.parametrize("rmax,boxcap,dbg", [("1", None, None), (None, "8", None), ("2", "40", None), (None, None, "64")])
@@ -188,6 +195,7 @@ def test_control_tables_larger_than_a_workgroup_tile(engine, oracle_lib):
     wl2.U[:16, 1] = vals
     ref2 = oracle_lib.expand(oracle_env(wl2), wl2.nodes, threads=8)
     env = engine_env(engine, wl2)
+    env.set_lists_route("grid")  # (40 nodes: the automatic choice would be the tiled kernel, lower latency)
     got2 = env.expand_lists(wl2.nodes)
     assert env.last_lists_route() == "grid"
     env.close()
