@@ -142,9 +142,10 @@ int copy_lists_to_host(mplx_ctx *c, const mplx_succ_lists &d, const mplx_succ_li
   if (n_thr > 15) n_thr = 15;
   if (hw > 0 && n_thr > hw - 1) n_thr = hw - 1;
   if (n_thr < 0) n_thr = 0;
-  const int parts = n_thr + 1;
+  int parts = n_thr + 1;
   std::atomic<int> ready{0};   // chunks whose data has landed
   std::atomic<int> done{0};    // (chunk, helper) pairs finished
+  std::atomic<bool> cancel{false};
   const int32_t *count = h->count;
   auto share = [&](int i, int part) {
     const Chunk &ch = chunks[(size_t)i];
@@ -153,14 +154,26 @@ int copy_lists_to_host(mplx_ctx *c, const mplx_succ_lists &d, const mplx_succ_li
     scatter(rows, n_rows, &row_off[(size_t)i * n_rows], (const char *)c->pk_pin[i & 1], count, offs.data(), ch, a, b);
   };
   std::vector<std::thread> helpers;
-  for (int t = 0; t < n_thr; t++)
-    helpers.emplace_back([&, t] {
-      for (int i = 0; i < n_chunks; i++) {
-        while (ready.load(std::memory_order_acquire) <= i) std::this_thread::yield();
-        share(i, t + 1);
-        done.fetch_add(1, std::memory_order_release);
-      }
-    });
+  try {
+    for (int t = 0; t < n_thr; t++)
+      helpers.emplace_back([&, t] {
+        for (int i = 0; i < n_chunks; i++) {
+          while (ready.load(std::memory_order_acquire) <= i) std::this_thread::yield();
+          if (cancel.load(std::memory_order_acquire)) return;
+          share(i, t + 1);
+          done.fetch_add(1, std::memory_order_release);
+        }
+      });
+  } catch (...) {
+    // no threads to be had: nothing may throw across the C ABI -- this thread scatters alone
+    cancel.store(true, std::memory_order_release);
+    ready.store(n_chunks + 1, std::memory_order_release);
+    for (auto &th : helpers) th.join();
+    helpers.clear();
+    ready.store(0, std::memory_order_release);
+    n_thr = 0;
+    parts = 1;
+  }
   auto join_all = [&] {
     ready.store(n_chunks + 1, std::memory_order_release);
     for (auto &th : helpers) th.join();
