@@ -173,6 +173,9 @@ struct Node {
   // packed provider: one recycled buffer [cost m][hash m][state (4D+2) x m][action m] (Planner::take_blob)
   char *c_blob = nullptr;
   int32_t c_m = 0;
+  // ... or, until the next launch, the node's index in the provider's own landing buffer (Planner::cur_view)
+  int32_t c_slot = -1;
+  uint32_t c_batch = 0;
 };
 
 // hm_ of the reference's StateSpace (state_space.h:78): lattice hash -> node.  Open addressing with linear
@@ -392,6 +395,8 @@ class Planner {
     all_blobs.clear();
     free_blobs.clear();
     cur_blob = nullptr;
+    cur_group.clear();
+    cur_view = PackedView();
     pq = OpenList();
     if (!single && !batched) return -1;
     int pn[3];
@@ -507,6 +512,23 @@ class Planner {
   std::vector<int32_t> v_act;
   std::vector<uint64_t> v_keys;
   char *cur_blob = nullptr;            // ... or the packed lists of the node being expanded
+  // The provider's landing buffer of the latest launch stays valid until the next one: nodes expanded before
+  // that (9 in 10) are read in place; the others are moved to buffers of their own just before the next launch.
+  PackedView cur_view;
+  uint32_t cur_batch = 0;
+  std::vector<NodePtr> cur_group;
+  void keep(Node &nd) {  // lists of `nd` out of the landing buffer into a recycled buffer
+    const int f = F();
+    const size_t m = (size_t)cur_view.count[nd.c_slot], o = (size_t)cur_view.offs[nd.c_slot];
+    nd.c_m = (int32_t)m;
+    if (!nd.c_blob) nd.c_blob = take_blob();
+    char *b = nd.c_blob;
+    std::memcpy(b, cur_view.cost + o, m * 8);
+    std::memcpy(b + m * 8, cur_view.hash + o, m * 8);
+    for (int r = 0; r < f; r++) std::memcpy(b + m * 8 * (size_t)(2 + r), cur_view.state + (size_t)r * cur_view.total + o, m * 8);
+    std::memcpy(b + m * 8 * (size_t)(2 + f), cur_view.action + o, m * 4);
+    nd.c_slot = -1;
+  }
   // Buffers of the packed lists: fixed capacity (a full list), recycled when their node has been expanded, so
   // that steady state touches no fresh pages (a fresh 40-KB allocation per node cost more than the copy itself).
   std::vector<std::unique_ptr<char[]>> all_blobs;
@@ -571,24 +593,22 @@ class Planner {
     last.device_launches++;
     last.pairs += slots;
     if (packed) {
+      const auto t_f0 = std::chrono::steady_clock::now();
+      for (NodePtr p : cur_group)  // what the previous launch delivered and the search has not consumed yet
+        if (p->cached && !p->closed && p->c_slot >= 0 && p->c_batch == cur_batch) keep(*p);
       const auto t_l0 = std::chrono::steady_clock::now();
-      PackedView pv;
-      if (int rc = packed(user, nodes.data(), n, &pv)) return rc;
-      const auto t_l1 = std::chrono::steady_clock::now();
-      t_provider += std::chrono::duration<double, std::milli>(t_l1 - t_l0).count();
+      t_fill += std::chrono::duration<double, std::milli>(t_l0 - t_f0).count();
+      cur_group.clear();
+      cur_batch++;
+      if (int rc = packed(user, nodes.data(), n, &cur_view)) return rc;
+      t_provider += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_l0).count();
       for (int64_t k = 0; k < n; k++) {
         Node &nd = *group[(size_t)k];
-        const size_t m = (size_t)pv.count[k], o = (size_t)pv.offs[k];
-        nd.c_m = (int32_t)m;
-        if (!nd.c_blob) nd.c_blob = take_blob();
-        char *b = nd.c_blob;
-        std::memcpy(b, pv.cost + o, m * 8);
-        std::memcpy(b + m * 8, pv.hash + o, m * 8);
-        for (int r = 0; r < f; r++) std::memcpy(b + m * 8 * (size_t)(2 + r), pv.state + (size_t)r * pv.total + o, m * 8);
-        std::memcpy(b + m * 8 * (size_t)(2 + f), pv.action + o, m * 4);
+        nd.c_slot = (int32_t)k;
+        nd.c_batch = cur_batch;
         nd.cached = true;
       }
-      t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_l1).count();
+      cur_group.assign(group.begin(), group.end());
       return 0;
     }
     if (lists) {
@@ -645,6 +665,14 @@ class Planner {
   int fetch(const NodePtr &n, SuccView *v) {
     if (!n->cached) return -1;
     const int f = F();
+    if (packed && n->c_slot >= 0 && n->c_batch == cur_batch) {
+      // still in the landing buffer of the latest launch: read in place
+      const size_t o = (size_t)cur_view.offs[n->c_slot];
+      *v = SuccView{cur_view.count[n->c_slot], cur_view.cost + o, cur_view.hash + o, cur_view.action + o,
+                    cur_view.state + o, cur_view.total, 1};
+      n->c_slot = -1;
+      return 0;
+    }
     if (packed) {
       if (cur_blob) free_blobs.push_back(cur_blob);  // the previous expansion's lists are done with
       cur_blob = n->c_blob;  // a closed node is never expanded again: the planner takes its lists over
