@@ -443,8 +443,15 @@ class Planner {
       for (int s = 0; s < n_succ; s++) {
         if (have_keys) {
           if (s + kAhead < n_succ) hm.prefetch(sv.keys[s + kAhead]);
-          if (s + kAhead / 2 < n_succ && !std::isinf(sv.cost[s + kAhead / 2]))
-            if (const Node *nx = hm.peek(sv.keys[s + kAhead / 2])) __builtin_prefetch(nx);
+          if (s + kAhead / 2 < n_succ && !std::isinf(sv.cost[s + kAhead / 2])) {
+            const int q = s + kAhead / 2;
+            if (const Node *nx = hm.peek(sv.keys[q])) {
+              __builtin_prefetch(nx);
+            } else if (sv.fs > 64) {
+              // a state not seen before: its fields will be gathered from rows far apart (lists read in place)
+              for (int r = 0; r < f; r++) __builtin_prefetch(&sv.state[(int64_t)r * sv.fs + (int64_t)q * sv.es]);
+            }
+          }
         }
         const double c_s = sv.cost[s];
         if (std::isinf(c_s)) continue;  // graph_search.h:81
