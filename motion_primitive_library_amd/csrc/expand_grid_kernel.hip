@@ -157,6 +157,21 @@ __device__ __forceinline__ void st_stream(T v, T *p) {
 #endif
 }
 
+// Wave priority by progress through a node: 0 while the tables are built (T1, A), 1 for rows and box staging, 3
+// for a phase-D step (list stores + sample loop), back to 1 after it.  A wave that is about to retire its stores
+// and move on wins issue slots over waves that are still setting up, which keeps the store path busier: -5.5 % on
+// C4 (0.632 -> 0.597 ms on one box; flat priority 3 around the stores alone -2 %, around a whole phase-D step -4 %;
+// profiles/micro/variants_run.sh).  -DMPLX_NO_PRIO compiles it out.
+__device__ __forceinline__ void wave_prio(int p) {
+#ifndef MPLX_NO_PRIO
+  if (p == 0) __builtin_amdgcn_s_setprio(0);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(3);
+#else
+  (void)p;
+#endif
+}
+
 // Orders this wave's LDS traffic: LDS executes a wave's instructions in order, so
 // only the compiler has to be kept from moving accesses across the point.
 __device__ __forceinline__ void wave_sync() {
@@ -274,6 +289,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
 
   for (int64_t node = wave_id; node < A.n_nodes; node += wave_stride) {
     // ---- phase 0: node state into LDS, prefetch of the next node
+    wave_prio(0);
     wave_sync();
     if (lane < F) s_node[lane] = nxt;
     if (node + wave_stride < A.n_nodes && lane < F)
@@ -576,6 +592,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       safe = sat_inside && !ycost && __builtin_amdgcn_readfirstlane((int)term) == 0;
     }
 
+    wave_prio(1);
     // ---- rounds of up to RM sample counts
     for (int pass = 0; pass == 0 || nm != 0ull; pass++) {
       // this round's sample counts and their rows
@@ -750,6 +767,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         // the kernel was still compute bound).
         const bool pad16 = A.l_pad && !act && pass == 0 && e < ((E + 15) & ~15);  // 8-byte entries
         const bool pad32 = A.l_pad && !act && pass == 0 && e < ((E + 31) & ~31);  // 4-byte entries
+        wave_prio(3);
         if ((mine || pad32) && !(A.dbg & 2)) {
           uint64_t h = s_hp[px];
           fold_entry<K>(h, s_eq, en[D - 1]);
@@ -948,6 +966,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
           if (A.l_cost && (mine || pad16)) st_stream(cost, &A.l_cost[idx]);
           if (A.l_iters) st_stream(blocked ? fb + 1 : cntl, &A.l_iters[idx]);
         }
+        wave_prio(1);
       }
     }
   }
