@@ -301,7 +301,9 @@ typedef struct {
   double cost;             /* traj_cost_ (goal g-value)                       */
   double total_time;       /* Trajectory::getTotalTime                        */
   double J[4];             /* Trajectory::J(VEL, ACC, JRK, SNP)               */
-  int32_t segments, reserved;
+  int32_t segments;
+  int32_t reserved;        /* diagnostic: with MPLX_PLAN_CHECK_STATES=1, successors whose host-evaluated
+                              state differed from the device's (must be 0)       */
 } mplx_plan_summary;
 
 int mplx_planner_create(int dim, mplx_planner **out);

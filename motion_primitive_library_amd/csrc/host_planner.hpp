@@ -176,6 +176,7 @@ struct Node {
   // ... or, until the next launch, the node's index in the provider's own landing buffer (Planner::cur_view)
   int32_t c_slot = -1;
   uint32_t c_batch = 0;
+  bool c_has_state = true;
 };
 
 // hm_ of the reference's StateSpace (state_space.h:78): lattice hash -> node.  Open addressing with linear
@@ -321,6 +322,49 @@ inline double effort_1d(const double c[6], double t, int order) {
   return 0;
 }
 
+// End state of the forward primitive (node, u, T): Primitive<Dim>::evaluate(T) of primitive.h:321-331 with the 1-D
+// polynomials of :128-145 for the coefficient vectors of :34-50, written out per control order exactly as the
+// kernels evaluate them (csrc/mplx_device_common.h, Ax<K>::pos/vel/acc/jrk<true>) -- IEEE doubles, no contraction
+// (the library is built with -ffp-contract=off), so the host value equals the device's bit for bit.  Lets the search
+// ask the device for (action, cost, hash) only and build the 112-byte state of the few successors that are new.
+inline double wrap_pi(double a) {  // mpl_basis/math.h:15-19
+  while (a > M_PI) a -= 2.0 * M_PI;
+  while (a < -M_PI) a += 2.0 * M_PI;
+  return a;
+}
+inline void forward_state(int dim, int control, const double *nd, const double *u, double T, double *out) {
+  const int K = (control & 8) ? 4 : (control & 4) ? 3 : (control & 2) ? 2 : 1;
+  const double t3 = (T * T) * T;
+  for (int i = 0; i < dim; i++) {
+    const double p = nd[i], v = nd[dim + i], a = nd[2 * dim + i], j = nd[3 * dim + i], ui = u[i];
+    double np, nv = 0.0, na = 0.0, nj = 0.0;
+    if (K == 1) {
+      np = (0.0 + ui * T) + p;
+      nv = 0.0 + ui;
+    } else if (K == 2) {
+      np = ((0.0 + ((ui / 2) * T) * T) + v * T) + p;
+      nv = (0.0 + ui * T) + v;
+      na = 0.0 + ui;
+    } else if (K == 3) {
+      np = (((0.0 + (ui / 6) * t3) + ((a / 2) * T) * T) + v * T) + p;
+      nv = ((0.0 + ((ui / 2) * T) * T) + a * T) + v;
+      na = (0.0 + ui * T) + a;
+      nj = 0.0 + ui;
+    } else {
+      np = ((((0.0 + (ui / 24) * (t3 * T)) + (j / 6) * t3) + ((a / 2) * T) * T) + v * T) + p;
+      nv = (((0.0 + (ui / 6) * t3) + ((j / 2) * T) * T) + a * T) + v;
+      na = ((0.0 + ((ui / 2) * T) * T) + j * T) + a;
+      nj = (0.0 + ui * T) + j;
+    }
+    out[i] = np;
+    out[dim + i] = nv;
+    out[2 * dim + i] = na;
+    out[3 * dim + i] = nj;
+  }
+  out[4 * dim] = (control & 16) ? wrap_pi((0.0 + u[dim] * T) + nd[4 * dim]) : 0.0;
+  out[4 * dim + 1] = nd[4 * dim + 1] + T;  // env_map.h:161
+}
+
 struct PlanResult {
   bool ok = false;
   double cost = kInf;
@@ -328,6 +372,7 @@ struct PlanResult {
   int closed = 0, opened = 0, nodes = 0;
   int device_launches = 0;  // provider calls actually made
   int64_t pairs = 0;        // node x control pairs evaluated by the provider
+  int64_t state_mismatches = 0;  // check_states: successors whose host-evaluated state differs from the device's
   double total_time = 0;
   double J[4] = {0, 0, 0, 0};  // J(VEL), J(ACC), J(JRK), J(SNP) of the trajectory
   std::vector<double> traj_nodes;  // [segments][4D+2] start state of each primitive
@@ -350,6 +395,8 @@ class Planner {
   batch_fn batched = nullptr;
   lists_fn lists = nullptr;  // preferred over `batched` when set: compact lists + device-side hashes
   packed_fn packed = nullptr;  // preferred over `lists`: the same lists without the copy into caller arrays
+  bool edges_only = false;     // packed provider delivers no states: new nodes are built with forward_state()
+  bool check_states = false;   // test hook (needs states): count host / device state mismatches
   void *user = nullptr;
 
   std::deque<Node> pool;
@@ -447,7 +494,7 @@ class Planner {
             const int q = s + kAhead / 2;
             if (const Node *nx = hm.peek(sv.keys[q])) {
               __builtin_prefetch(nx);
-            } else if (sv.fs > 64) {
+            } else if (sv.state && sv.fs > 64) {
               // a state not seen before: its fields will be gathered from rows far apart (lists read in place)
               for (int r = 0; r < f; r++) __builtin_prefetch(&sv.state[(int64_t)r * sv.fs + (int64_t)q * sv.es]);
             }
@@ -458,8 +505,18 @@ class Planner {
         uint64_t key;
         bool have_sc = false;
         auto gather = [&] {
-          if (!have_sc)
-            for (int r = 0; r < f; r++) sc[r] = sv.state[(int64_t)r * sv.fs + (int64_t)s * sv.es];
+          if (!have_sc) {
+            if (sv.state) {
+              for (int r = 0; r < f; r++) sc[r] = sv.state[(int64_t)r * sv.fs + (int64_t)s * sv.es];
+              if (check_states) {  // test hook: the host evaluation against the device's states
+                double hs[14];
+                forward_state(dim, control, curr->coord, &U[(size_t)sv.act[s] * udim], dt, hs);
+                if (std::memcmp(hs, sc, sizeof(double) * (size_t)f) != 0) last.state_mismatches++;
+              }
+            } else {
+              forward_state(dim, control, curr->coord, &U[(size_t)sv.act[s] * udim], dt, sc);
+            }
+          }
           have_sc = true;
         };
         if (have_keys) key = sv.keys[s];
@@ -532,8 +589,10 @@ class Planner {
     char *b = nd.c_blob;
     std::memcpy(b, cur_view.cost + o, m * 8);
     std::memcpy(b + m * 8, cur_view.hash + o, m * 8);
-    for (int r = 0; r < f; r++) std::memcpy(b + m * 8 * (size_t)(2 + r), cur_view.state + (size_t)r * cur_view.total + o, m * 8);
+    if (cur_view.state)
+      for (int r = 0; r < f; r++) std::memcpy(b + m * 8 * (size_t)(2 + r), cur_view.state + (size_t)r * cur_view.total + o, m * 8);
     std::memcpy(b + m * 8 * (size_t)(2 + f), cur_view.action + o, m * 4);
+    nd.c_has_state = cur_view.state != nullptr;
     nd.c_slot = -1;
   }
   // Buffers of the packed lists: fixed capacity (a full list), recycled when their node has been expanded, so
@@ -676,7 +735,7 @@ class Planner {
       // still in the landing buffer of the latest launch: read in place
       const size_t o = (size_t)cur_view.offs[n->c_slot];
       *v = SuccView{cur_view.count[n->c_slot], cur_view.cost + o, cur_view.hash + o, cur_view.action + o,
-                    cur_view.state + o, cur_view.total, 1};
+                    cur_view.state ? cur_view.state + o : nullptr, cur_view.total, 1};
       n->c_slot = -1;
       return 0;
     }
@@ -687,7 +746,7 @@ class Planner {
       const size_t m = (size_t)n->c_m;
       const char *b = cur_blob;
       *v = SuccView{(int32_t)m, (const double *)b, (const uint64_t *)(b + m * 8), (const int32_t *)(b + m * 8 * (size_t)(2 + f)),
-                    (const double *)(b + m * 16), (int64_t)m, 1};
+                    n->c_has_state ? (const double *)(b + m * 16) : nullptr, (int64_t)m, 1};
       return 0;
     }
     std::copy(n->c_succ.begin(), n->c_succ.end(), v_succ.begin());

@@ -229,14 +229,15 @@ int copy_lists_to_host(mplx_ctx *c, const mplx_succ_lists &d, const mplx_succ_li
   return MPLX_OK;
 }
 
-int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t node_stride, PackedLists *out) {
+int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t node_stride, bool want_state,
+                        PackedLists *out) {
   if (!c || !out || !h_nodes || n_nodes <= 0 || node_stride < n_nodes) return fail(c, MPLX_ERR_ARG, "expand_lists_packed: bad arguments");
   if (int rc = ctx_ready(c)) return rc;
   if (int rc = bind_device(c)) return rc;
   const int F = 4 * c->dim + 2;
   const int64_t S = (c->nU + 31) & ~31;  // line-aligned node stride (see expand_grid_kernel.hip)
   const int64_t n_slots = n_nodes * S;
-  if (c->tune.zero_copy && (size_t)n_slots * (size_t)(F * 8 + 24) <= ((size_t)32 << 20)) {
+  if (c->tune.zero_copy && (size_t)n_slots * (size_t)((want_state ? F * 8 : 0) + 24) <= ((size_t)32 << 20)) {
     // Batches of a search: the kernel reads the nodes from and writes the lists into one pinned host block itself
     // (only the used entries cross PCIe, while the kernel runs): the call is the kernel and one synchronisation.
     // The view then describes the strided lists as they are: offs[k] = k * S, row stride n_nodes * S.
@@ -247,7 +248,7 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
     const size_t o_cost = o_act + up((size_t)n_slots * 4);
     const size_t o_hash = o_cost + up((size_t)n_slots * 8);
     const size_t o_state = o_hash + up((size_t)n_slots * 8);
-    const size_t bytes = o_state + up((size_t)F * n_slots * 8);
+    const size_t bytes = o_state + (want_state ? up((size_t)F * n_slots * 8) : 0);
     if (bytes > c->pk_hb_cap) {
       if (c->pk_hb) HIP_TRY(c, hipHostFree(c->pk_hb));
       c->pk_hb = nullptr;
@@ -263,8 +264,7 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
     d.action = (int32_t *)(hb + o_act);
     d.cost = (double *)(hb + o_cost);
     d.hash = (uint64_t *)(hb + o_hash);
-    d.state = (double *)(hb + o_state);
-    d.state_stride = n_slots;
+    if (want_state) { d.state = (double *)(hb + o_state); d.state_stride = n_slots; }
     d.node_stride = S;
     if (int rc = lists_on_device(c, (const double *)hb, n_nodes, n_nodes, &d)) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -299,7 +299,8 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
   if (int rc = ensure(c, c->s_action, (size_t)n_slots * 4)) return rc;
   if (int rc = ensure(c, c->s_cost, (size_t)n_slots * 8)) return rc;
   if (int rc = ensure(c, c->s_hash, (size_t)n_slots * 8)) return rc;
-  if (int rc = ensure(c, c->s_state, (size_t)F * n_slots * 8)) return rc;
+  if (want_state)
+    if (int rc = ensure(c, c->s_state, (size_t)F * n_slots * 8)) return rc;
   if (int rc = ensure(c, c->pk_offs, (size_t)n_nodes * 8)) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->s_nodes.p, hb, (size_t)F * n_nodes * 8, hipMemcpyHostToDevice, c->stream));
   mplx_succ_lists d{};
@@ -307,8 +308,7 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
   d.action = (int32_t *)c->s_action.p;
   d.cost = (double *)c->s_cost.p;
   d.hash = (uint64_t *)c->s_hash.p;
-  d.state = (double *)c->s_state.p;
-  d.state_stride = n_slots;
+  if (want_state) { d.state = (double *)c->s_state.p; d.state_stride = n_slots; }
   d.node_stride = S;
   if (int rc = lists_on_device(c, (const double *)c->s_nodes.p, n_nodes, n_nodes, &d)) return rc;
   int32_t *cnt = (int32_t *)(hb + o_cnt);
@@ -323,7 +323,7 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
   out->count = cnt;
   out->offs = offs;
   if (total == 0) return MPLX_OK;
-  const int bpe = 8 + 8 + 8 * F + 4;
+  const int bpe = 8 + 8 + (want_state ? 8 * F : 0) + 4;
   const size_t bytes = ((size_t)total * bpe + 255) & ~(size_t)255;
   if (int rc = ensure_pinned(c, bytes)) return rc;
   if (int rc = ensure(c, c->pk_dev[0], bytes)) return rc;
@@ -334,7 +334,8 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
   auto row = [&](const void *src, int es) { a.src[r] = src; a.dst_off[r] = o; a.es[r] = es; o += total * es; r++; };
   row(d.cost, 8);
   row(d.hash, 8);
-  for (int f = 0; f < F; f++) row(d.state + (size_t)f * n_slots, 8);
+  if (want_state)
+    for (int f = 0; f < F; f++) row(d.state + (size_t)f * n_slots, 8);
   row(d.action, 4);
   a.n_rows = r;
   a.node_stride = S;
@@ -349,8 +350,8 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
   const char *pin = (const char *)c->pk_pin[0];
   out->cost = (const double *)(pin + a.dst_off[0]);
   out->hash = (const uint64_t *)(pin + a.dst_off[1]);
-  out->state = (const double *)(pin + a.dst_off[2]);
-  out->action = (const int32_t *)(pin + a.dst_off[2 + F]);
+  out->state = want_state ? (const double *)(pin + a.dst_off[2]) : nullptr;
+  out->action = (const int32_t *)(pin + a.dst_off[want_state ? 2 + F : 2]);
   return MPLX_OK;
 }
 

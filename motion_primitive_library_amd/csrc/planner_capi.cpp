@@ -46,7 +46,7 @@ int engine_lists(void *user, const double *nodes, int64_t n, int32_t *count, int
 int engine_packed(void *user, const double *nodes, int64_t n, mplx::host::PackedView *out) {
   mplx_planner *p = (mplx_planner *)user;
   mplx_detail::PackedLists pl;
-  if (int rc = mplx_detail::expand_lists_packed(p->ctx, nodes, n, n, &pl)) return rc;
+  if (int rc = mplx_detail::expand_lists_packed(p->ctx, nodes, n, n, !p->pl.edges_only || p->pl.check_states, &pl)) return rc;
   out->total = pl.total;
   out->count = pl.count;
   out->offs = pl.offs;
@@ -87,6 +87,11 @@ int mplx_planner_attach_ctx(mplx_planner *p, mplx_ctx *ctx) {
   p->pl.batched = engine_batch;
   p->pl.lists = engine_lists;
   p->pl.packed = getenv("MPLX_PLAN_NO_PACKED") ? nullptr : engine_packed;  // the knob: A/B only
+  // edges only: the device delivers (action, cost, hash); the states of new nodes are evaluated on the host
+  // (host_planner.hpp::forward_state).  MPLX_PLAN_FULL_STATES=1 moves the states as well; MPLX_PLAN_CHECK_STATES=1
+  // moves them and counts disagreements with the host evaluation (tests).
+  p->pl.edges_only = getenv("MPLX_PLAN_FULL_STATES") == nullptr;
+  p->pl.check_states = getenv("MPLX_PLAN_CHECK_STATES") != nullptr;
   p->pl.user = p;
   return MPLX_OK;
 }
@@ -160,6 +165,7 @@ int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, 
   out->nodes = r.nodes;
   out->device_launches = r.device_launches;
   out->pairs = r.pairs;
+  out->reserved = (int32_t)(r.state_mismatches > 0x7fffffff ? 0x7fffffff : r.state_mismatches);
   out->cost = r.cost;
   out->total_time = r.total_time;
   for (int i = 0; i < 4; i++) out->J[i] = r.J[i];

@@ -198,7 +198,8 @@ class MapPlanner:
     def summary(self):
         o = self._summary
         return {k: getattr(o, k) for k in ("ok", "expansions", "closed", "opened", "nodes", "device_launches",
-                                           "pairs", "cost", "total_time", "segments")} | {"J": list(o.J)}
+                                           "pairs", "cost", "total_time", "segments")} | {
+            "J": list(o.J), "state_mismatches": o.reserved}
 
     def getCloseSet(self):
         n = C.c_int32()

@@ -184,3 +184,39 @@ def test_reference_test_scenarios_on_the_engine_planner(engine, scenario, batch)
     rtol = 1e-9 if "yaw" in scenario else 1e-15
     assert abs(s["cost"] - want["cost"]) <= rtol * want["cost"]
     assert tr.J(m.VEL) == want["J"][0] and tr.J(m.ACC) == want["J"][1]
+
+
+@pytest.mark.parametrize("control,dim", [(0x01, 2), (0x03, 2), (0x07, 2), (0x0F, 2), (0x13, 2), (0x03, 3), (0x07, 3)])
+def test_host_evaluated_states_equal_the_devices(engine, monkeypatch, control, dim):
+    """The engine's search asks the device for (action, cost, hash) only and evaluates the state of a successor it
+    has not seen before on the host (host_planner.hpp::forward_state).  MPLX_PLAN_CHECK_STATES=1 moves the device's
+    states as well and counts every disagreement, bit for bit: there must be none, for every control order."""
+    monkeypatch.setenv("MPLX_PLAN_CHECK_STATES", "1")
+    m = engine
+    rng = np.random.default_rng(control * 10 + dim)
+    edge = 60 if dim == 2 else 28
+    grid = m.workloads.box_map([edge] * dim, 0.1, 0.06, 31 + control, side_m=(0.3, 0.8))
+    flat = grid.ravel().copy()
+    pl = m.MapPlanner(dim, device=0)
+    mu = m.MapUtil(dim)
+    mu.setMap([0.0] * dim, [edge] * dim, flat, 0.1)
+    pl.setMapUtil(mu)
+    pl.setVmax(1.5)
+    pl.setAmax(1.5)
+    pl.setJmax(3.0)
+    pl.setYawmax(0.9)
+    pl.setDt(0.5)
+    vals = [-1.0, 0.0, 1.0]
+    pl.setU(m.workloads.grid_controls(vals, dim, yaw_rates=[-0.4, 0.0, 0.4] if control & 0x10 else None))
+    pl.setBatch(32)
+    pl.setEpsilon(0.0)  # uniform-cost search: many expansions whatever the start and the goal
+    pl.setMaxNum(1500)
+    free = np.argwhere(grid.reshape([edge] * dim) == 0)
+    a, b = free[0][::-1], free[-1][::-1]  # opposite corners of the map
+    start = m.Waypoint(dim, control, pos=(a + 0.5) * 0.1)
+    goal = m.Waypoint(dim, control, pos=(b + 0.5) * 0.1)
+    pl.plan(start, goal)
+    s = pl.summary()
+    pl.close()
+    assert s["expansions"] > 50 and s["nodes"] > 150, s
+    assert s["state_mismatches"] == 0, s
