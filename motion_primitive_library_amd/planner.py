@@ -67,7 +67,8 @@ class MapPlanner:
             raise _abi.MplxError(rc, "mplx_planner_create failed")
         self._p = p
         self._cfg = _abi.PlannerConfig()
-        self._cfg.control, self._cfg.max_expand, self._cfg.batch = 0x03, -1, 1
+        # nodes per device launch: the result does not depend on it (get_succ is a pure function), the speed does
+        self._cfg.control, self._cfg.max_expand, self._cfg.batch = 0x03, -1, (64 if provider is None else 1)
         self._cfg.dt, self._cfg.w, self._cfg.v_max, self._cfg.epsilon = 1.0, 10.0, -1.0, 1.0
         self._cfg.tol_pos, self._cfg.tol_vel, self._cfg.tol_acc, self._cfg.tol_yaw = 0.5, -1.0, -1.0, -1.0
         self.env = None
@@ -178,7 +179,7 @@ class MapPlanner:
         return True
 
     def setBatch(self, n):
-        """Nodes per device launch (1 = the reference's one-node-at-a-time loop)."""
+        """Nodes per device launch (1 = the reference's one-node-at-a-time loop; default 64 on the engine)."""
         self._cfg.batch = int(n)
 
     # ---- PlannerBase::plan
