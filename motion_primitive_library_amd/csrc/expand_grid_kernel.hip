@@ -29,7 +29,12 @@
 // it computes) with ~60 instructions per map sample, most of them address
 // arithmetic of the global look-up, so here the occupancy bits of the node's
 // reachable box are staged into LDS once per node and a sample is 3 byte
-// look-ups + 1 word look-up.
+// look-ups + 1 word look-up; (3) with that done the kernel is bound by its list
+// stores (2.7 GB per launch on C4), so they are full 128-byte lines, carry the
+// `sc1 nt` policy (st_stream), and the waves' priority follows their progress
+// through a node (wave_prio) so that store bursts are issued ahead of set-up work;
+// nodes whose whole reach box is free (summed-area table) skip R and the sample
+// loops altogether.
 //
 // Per node (one wave):
 //   T1  axis entries (axis, value): limits, n_axis, end state, lattice integers,
