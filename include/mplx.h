@@ -337,6 +337,11 @@ int mplx_planner_open_set(mplx_planner *p, double *states, int32_t cap, int32_t 
 const char *mplx_planner_last_error(const mplx_planner *p);
 
 /* ---- diagnostics -------------------------------------------------------- */
+/* The host search's evaluation of a successor state (Primitive<Dim>(node, u, dt).evaluate(dt),
+ * primitive.h:220-256, 321-331): node and out 4D+2 doubles, u one row of the control table.  Pure host
+ * arithmetic (no device needed); the tests compare it with the oracle and with the device's states.   */
+int mplx_selftest_forward_state(int32_t dim, int32_t control, const double *node, const double *u, double dt,
+                                double *out);
 /* Element-wise device evaluation of the libm-class operations the path uses,
  * for checking them against the host libm: op 0 a/b, 1 sqrt(a), 2 cos(a),
  * 3 sin(a), 4 round(a), 5 ceil(a).  Host pointers, n elements.               */

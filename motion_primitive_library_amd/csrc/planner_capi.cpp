@@ -195,6 +195,13 @@ int mplx_planner_trajectory_end(mplx_planner *p, double *node) {
   return MPLX_OK;
 }
 
+int mplx_selftest_forward_state(int32_t dim, int32_t control, const double *node, const double *u, double dt,
+                                double *out) {
+  if ((dim != 2 && dim != 3) || !node || !u || !out) return MPLX_ERR_ARG;
+  mplx::host::forward_state(dim, control, node, u, dt, out);
+  return MPLX_OK;
+}
+
 int mplx_planner_closed_set(mplx_planner *p, double *pos, int32_t cap, int32_t *n) {
   if (!p || !n) return MPLX_ERR_ARG;
   int32_t m = 0;
