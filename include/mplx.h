@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MPLX_ABI_VERSION 2
+#define MPLX_ABI_VERSION 3
 
 typedef struct mplx_ctx mplx_ctx;
 
@@ -39,7 +39,8 @@ typedef enum {
   MPLX_ERR_ARG = -1,     /* bad argument / call order                         */
   MPLX_ERR_HIP = -2,     /* HIP runtime error (text in mplx_last_error)       */
   MPLX_ERR_NO_DEVICE = -3,
-  MPLX_ERR_STATE = -4    /* map / controls / params not set before expand     */
+  MPLX_ERR_STATE = -4,   /* map / controls / params not set before expand     */
+  MPLX_ERR_NOMEM = -5    /* host allocation failed inside the library         */
 } mplx_status;
 
 /* Control::Control bit flags (reference include/mpl_basis/control.h:10-20). */
@@ -194,8 +195,10 @@ int mplx_expand_lists(mplx_ctx *ctx, const double *h_nodes, int64_t n_nodes, int
  *      (graph_search.h:84-88, :146), for a whole batch of lists in HBM ------ */
 typedef struct {
   const double *goal;      /* host pointer: goal waypoint, 4D+2 doubles         */
-  int32_t control;         /* Waypoint::control of goal and successors          */
-  int32_t reserved;
+  int32_t control;         /* Waypoint::control of the successors               */
+  int32_t goal_control;    /* Waypoint::control of the goal: the `goal_node_ == state` test of
+                              env_base.h:47 hashes each side with ITS OWN flags (waypoint.h:93-125);
+                              0 = same as `control`                               */
   double w, v_max;         /* env_base.h:370, :382 (cal_heur, :58-64)           */
   double tol_pos, tol_vel, tol_acc, tol_yaw; /* env_base.h:374-380; vel / acc /
                               yaw tests are skipped when < 0 (env_map.h:29-36)  */
@@ -286,7 +289,9 @@ typedef struct {
   int32_t control;      /* control flag of start / goal (Waypoint::control)   */
   int32_t max_expand;   /* PlannerBase::setMaxNum, planner_base.h:251; <=0 off */
   int32_t batch;        /* nodes per launch; 1 = one-at-a-time like Astar     */
-  int32_t reserved;
+  int32_t goal_control; /* control flag of the goal waypoint when it differs from the start's (the
+                           reference's test_distance_map_planner_2d_with_yaw: ACCxYAW start, ACC goal);
+                           0 = same as `control`                                */
   double dt, w, v_max;  /* used by the heuristic (env_base.h:58-64)           */
   double epsilon;       /* PlannerBase::setEpsilon, planner_base.h:238        */
   double tol_pos, tol_vel, tol_acc, tol_yaw; /* setTol, planner_base.h:262    */
@@ -302,7 +307,7 @@ typedef struct {
   double total_time;       /* Trajectory::getTotalTime                        */
   double J[4];             /* Trajectory::J(VEL, ACC, JRK, SNP)               */
   int32_t segments;
-  int32_t reserved;        /* diagnostic: with MPLX_PLAN_CHECK_STATES=1, successors whose host-evaluated
+  int32_t state_mismatches; /* diagnostic: with MPLX_PLAN_CHECK_STATES=1, successors whose host-evaluated
                               state differed from the device's (must be 0)       */
 } mplx_plan_summary;
 

@@ -55,7 +55,7 @@ class SuccLists(C.Structure):
 
 
 class GoalSpec(C.Structure):
-    _fields_ = [("goal", C.c_void_p), ("control", C.c_int32), ("reserved", C.c_int32), ("w", C.c_double),
+    _fields_ = [("goal", C.c_void_p), ("control", C.c_int32), ("goal_control", C.c_int32), ("w", C.c_double),
                 ("v_max", C.c_double), ("tol_pos", C.c_double), ("tol_vel", C.c_double), ("tol_acc", C.c_double),
                 ("tol_yaw", C.c_double)]
 
@@ -71,7 +71,7 @@ class Post(C.Structure):
 
 class PlannerConfig(C.Structure):
     _fields_ = [
-        ("control", C.c_int32), ("max_expand", C.c_int32), ("batch", C.c_int32), ("reserved", C.c_int32),
+        ("control", C.c_int32), ("max_expand", C.c_int32), ("batch", C.c_int32), ("goal_control", C.c_int32),
         ("dt", C.c_double), ("w", C.c_double), ("v_max", C.c_double), ("epsilon", C.c_double),
         ("tol_pos", C.c_double), ("tol_vel", C.c_double), ("tol_acc", C.c_double), ("tol_yaw", C.c_double),
     ]
@@ -82,7 +82,7 @@ class PlanSummary(C.Structure):
         ("ok", C.c_int32), ("expansions", C.c_int32), ("closed", C.c_int32), ("opened", C.c_int32),
         ("nodes", C.c_int32), ("device_launches", C.c_int32), ("pairs", C.c_int64),
         ("cost", C.c_double), ("total_time", C.c_double), ("J", C.c_double * 4),
-        ("segments", C.c_int32), ("reserved", C.c_int32),
+        ("segments", C.c_int32), ("state_mismatches", C.c_int32),
     ]
 
 

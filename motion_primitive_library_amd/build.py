@@ -26,6 +26,12 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def _obj_dir():
+    d = os.path.join(CSRC, "build")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True
@@ -34,17 +40,46 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile libmplx.so if missing or older than its sources; returns its path."""
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"]
+
+
+def build(force=False, verbose=False, jobs=None):
+    """Compile libmplx.so if missing or older than its sources; returns its path.  One object per source
+    (csrc/build/, git-ignored), compiled in parallel, only the stale ones; then one link."""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off",
-           "-fPIC", "-shared", "-Wall", "-o", LIB] + SOURCES
+    from concurrent.futures import ThreadPoolExecutor
+
+    hipcc = hipcc_path()
+    odir = _obj_dir()
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    todo, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(odir, src + ".o")
+        objs.append(obj)
+        st = max(os.path.getmtime(os.path.join(CSRC, src)), hdr_t)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < st:
+            todo.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        return src, subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+        for src, proc in ex.map(cc, todo):
+            if proc.returncode != 0:
+                raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, proc.stdout, proc.stderr))
+            if verbose and proc.stderr.strip():
+                print(proc.stderr, file=sys.stderr)
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     proc = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError("hipcc failed:\n%s\n%s" % (proc.stdout, proc.stderr))
+        raise RuntimeError("hipcc link failed:\n%s\n%s" % (proc.stdout, proc.stderr))
     return LIB
 
 

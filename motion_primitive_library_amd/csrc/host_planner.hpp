@@ -176,6 +176,7 @@ struct Node {
   // ... or, until the next launch, the node's index in the provider's own landing buffer (Planner::cur_view)
   int32_t c_slot = -1;
   uint32_t c_batch = 0;
+  uint32_t pick_stamp = 0;  // launch for which the node was last picked (a re-opened node sits in the heap twice)
   bool c_has_state = true;
 };
 
@@ -384,6 +385,8 @@ class Planner {
  public:
   int dim = 2;
   int control = 0x03;
+  int goal_control = 0;  // control flag of the goal waypoint (0 = the search's): env_base.h:47 compares the goal with a
+                         // state by hash, and each side is hashed with its own flags (waypoint.h:93-125)
   double dt = 1.0, w = 10.0, v_max = -1.0, eps = 1.0;
   double tol_pos = 0.5, tol_vel = -1, tol_acc = -1, tol_yaw = -1;
   int max_expand = -1;
@@ -397,6 +400,8 @@ class Planner {
   packed_fn packed = nullptr;  // preferred over `lists`: the same lists without the copy into caller arrays
   bool edges_only = false;     // packed provider delivers no states: new nodes are built with forward_state()
   bool check_states = false;   // test hook (needs states): count host / device state mismatches
+  int check_perturb = -1;      // test hook of the test hook: the n-th checked state gets one bit flipped, so the
+                               // counter must come out as exactly 1
   void *user = nullptr;
 
   std::deque<Node> pool;
@@ -409,7 +414,7 @@ class Planner {
   int F() const { return 4 * dim + 2; }
 
   double heur(const double *s, const double *goal) const {  // env_base.h:46-64
-    return heur_keyed(s, lattice_hash(dim, control, s), goal, lattice_hash(dim, control, goal));
+    return heur_keyed(s, lattice_hash(dim, control, s), goal, lattice_hash(dim, goal_control ? goal_control : control, goal));
   }
   double heur_keyed(const double *s, uint64_t s_key, const double *goal, uint64_t goal_key) const {
     if (s_key == goal_key) return 0;
@@ -436,6 +441,7 @@ class Planner {
   int plan(const double *start, const double *goal) {
     last = PlanResult();
     t_succ = t_provider = t_fill = t_pick = 0;
+    checked_states = 0;
     hm.clear();
     pool.clear();
     preds.clear();
@@ -466,7 +472,7 @@ class Planner {
     v_cost.resize((size_t)nU);
     v_act.resize((size_t)nU);
     v_keys.resize((size_t)nU);
-    const uint64_t goal_key = lattice_hash(dim, control, goal);
+    const uint64_t goal_key = lattice_hash(dim, goal_control ? goal_control : control, goal);
     int expand_iteration = 0;
     bool reached = false;
     double sc[14];
@@ -511,6 +517,12 @@ class Planner {
               if (check_states) {  // test hook: the host evaluation against the device's states
                 double hs[14];
                 forward_state(dim, control, curr->coord, &U[(size_t)sv.act[s] * udim], dt, hs);
+                if (check_perturb >= 0 && checked_states++ == check_perturb) {
+                  uint64_t b;
+                  std::memcpy(&b, &hs[0], 8);
+                  b ^= 1ull;
+                  std::memcpy(&hs[0], &b, 8);
+                }
                 if (std::memcmp(hs, sc, sizeof(double) * (size_t)f) != 0) last.state_mismatches++;
               }
             } else {
@@ -558,10 +570,10 @@ class Planner {
               t_succ, t_provider, t_fill, t_pick);
     last.expansions = expand_iteration;
     last.nodes = (int)hm.size();
-    for (const Node &nd : pool) {
+    for (const Node &nd : pool)
       if (nd.closed) last.closed++;
-      else if (nd.opened) last.opened++;
-    }
+    // PlannerBase::getOpenSet walks the heap (planner_base.h:77-81): a closed node that was pushed again counts
+    last.opened = (int)pq.size();
     if (!reached) return 0;
     if (recover(curr, start)) { last.ok = true; last.cost = curr->g; }
     return 0;
@@ -569,6 +581,7 @@ class Planner {
 
  private:
   double t_succ = 0, t_provider = 0, t_fill = 0, t_pick = 0;  // MPLX_PLAN_TIMING diagnostics
+  int64_t checked_states = 0;
   std::vector<int32_t> b_cnt, b_act;  // staging of one batched launch (lists provider)
   std::vector<double> b_cost, b_state;
   std::vector<uint64_t> b_hash;
@@ -579,7 +592,7 @@ class Planner {
   // The provider's landing buffer of the latest launch stays valid until the next one: nodes expanded before
   // that (9 in 10) are read in place; the others are moved to buffers of their own just before the next launch.
   PackedView cur_view;
-  uint32_t cur_batch = 0;
+  uint32_t cur_batch = 0, pick_counter = 0;
   std::vector<NodePtr> cur_group;
   void keep(Node &nd) {  // lists of `nd` out of the landing buffer into a recycled buffer
     const int f = F();
@@ -625,6 +638,7 @@ class Planner {
       // array (k smallest of a binary heap with an auxiliary heap of positions), O(k log k) whatever
       // the size of the open list
       std::vector<NodePtr> group{curr};
+      curr->pick_stamp = ++pick_counter;
       const size_t want = (size_t)batch - 1;
       const std::vector<OpenList::Item> &h = pq.items();
       auto worse = [&](int a, int b) {  // max-heap on "better", so top() is the best position
@@ -639,7 +653,11 @@ class Planner {
         const int i = aux.top();
         aux.pop();
         visited++;
-        if (!h[(size_t)i].n->cached) group.push_back(h[(size_t)i].n);
+        Node *cand = h[(size_t)i].n;
+        if (!cand->cached && cand->pick_stamp != pick_counter) {
+          cand->pick_stamp = pick_counter;
+          group.push_back(cand);
+        }
         if (2 * i + 1 < (int)h.size()) aux.push(2 * i + 1);
         if (2 * i + 2 < (int)h.size()) aux.push(2 * i + 2);
       }
@@ -661,7 +679,7 @@ class Planner {
     if (packed) {
       const auto t_f0 = std::chrono::steady_clock::now();
       for (NodePtr p : cur_group)  // what the previous launch delivered and the search has not consumed yet
-        if (p->cached && !p->closed && p->c_slot >= 0 && p->c_batch == cur_batch) keep(*p);
+        if (p->cached && p->c_slot >= 0 && p->c_batch == cur_batch) keep(*p);  // (a re-opened node is closed AND waiting)
       const auto t_l0 = std::chrono::steady_clock::now();
       t_fill += std::chrono::duration<double, std::milli>(t_l0 - t_f0).count();
       cur_group.clear();
@@ -728,9 +746,14 @@ class Planner {
     return 0;
   }
 
+  // Hands the cached lists of `n` to the relaxation loop and forgets them: the reference expands a node again
+  // when a cheaper path re-opens it after it was closed (graph_search.h:108-141 pushes it a second time; that
+  // happens with an inconsistent heuristic, i.e. eps > 1 or the default v_max <= 0), so the cache entry must not
+  // outlive its one use -- a re-popped node goes through run_batch again (get_succ is pure: same lists).
   int fetch(const NodePtr &n, SuccView *v) {
     if (!n->cached) return -1;
     const int f = F();
+    n->cached = false;
     if (packed && n->c_slot >= 0 && n->c_batch == cur_batch) {
       // still in the landing buffer of the latest launch: read in place
       const size_t o = (size_t)cur_view.offs[n->c_slot];
@@ -741,9 +764,11 @@ class Planner {
     }
     if (packed) {
       if (cur_blob) free_blobs.push_back(cur_blob);  // the previous expansion's lists are done with
-      cur_blob = n->c_blob;  // a closed node is never expanded again: the planner takes its lists over
+      cur_blob = n->c_blob;  // the planner takes the node's lists over for the duration of this expansion
       n->c_blob = nullptr;
+      n->c_slot = -1;
       const size_t m = (size_t)n->c_m;
+      n->c_m = 0;
       const char *b = cur_blob;
       *v = SuccView{(int32_t)m, (const double *)b, (const uint64_t *)(b + m * 8), (const int32_t *)(b + m * 8 * (size_t)(2 + f)),
                     n->c_has_state ? (const double *)(b + m * 16) : nullptr, (int64_t)m, 1};
@@ -756,7 +781,8 @@ class Planner {
     if (have_keys) std::copy(n->c_key.begin(), n->c_key.end(), v_keys.begin());
     *v = SuccView{(int32_t)n->c_act.size(), v_cost.data(), have_keys ? v_keys.data() : nullptr, v_act.data(), v_succ.data(), 1, f};
     n->c_key.clear(); n->c_key.shrink_to_fit();
-    n->c_succ.clear(); n->c_succ.shrink_to_fit();  // a closed node is never expanded again
+    n->c_succ.clear(); n->c_succ.shrink_to_fit();
+    n->c_cost.clear(); n->c_act.clear();
     return 0;
   }
 

@@ -154,9 +154,13 @@ int mplx_set_map(mplx_ctx *c, const int8_t *cells, const int32_t *dim, const dou
     return fail(c, MPLX_ERR_ARG, "mplx_set_map: %lld cells exceed the reference's int cell index",
                 (long long)n);
   if (int rc = bind_device(c)) return rc;
-  if (n != c->n_cells) {  // a different grid invalidates potential and region
-    c->has_pot = false;
-    c->has_region = false;
+  {  // a different grid (size, shape, origin or resolution) invalidates potential and region
+    bool same = n == c->n_cells && res == c->res;
+    for (int i = 0; i < c->dim; i++) same = same && dim[i] == c->mdim[i] && origin[i] == c->origin[i];
+    if (!same) {
+      c->has_pot = false;
+      c->has_region = false;
+    }
   }
   if (int rc = ensure(c, c->map, (size_t)n)) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->map.p, cells, (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -216,6 +220,7 @@ int mplx_set_controls(mplx_ctx *c, const double *U, int32_t nU, int32_t udim) {
   if (!c) return MPLX_ERR_ARG;
   if (!U || nU <= 0 || udim < c->dim || udim > c->dim + 1)
     return fail(c, MPLX_ERR_ARG, "mplx_set_controls: need U != NULL, nU > 0, udim in {%d,%d}", c->dim, c->dim + 1);
+  MPLX_GUARD_BEGIN
   if (int rc = bind_device(c)) return rc;
   const size_t bytes = (size_t)nU * udim * sizeof(double);
   if (int rc = ensure(c, c->U, bytes)) return rc;
@@ -276,6 +281,7 @@ int mplx_set_controls(mplx_ctx *c, const double *U, int32_t nU, int32_t udim) {
   }
   c->has_U = true;
   return MPLX_OK;
+  MPLX_GUARD_END(c)
 }
 
 int mplx_expand_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride,
@@ -718,7 +724,9 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
   if (int rc = lists_device(c, (const double *)c->s_nodes.p, n_nodes, n_nodes, &d)) return rc;
   // everything larger: only the used prefixes cross the link, packed on the device and pipelined through pinned
   // buffers (lists_copy_api.cpp)
+  MPLX_GUARD_BEGIN
   return mplx_detail::copy_lists_to_host(c, d, h_out, n_nodes);
+  MPLX_GUARD_END(c)
 }
 
 int mplx_get_succ(mplx_ctx *c, const double *node, double *succ, double *cost, int32_t *action,
@@ -726,6 +734,7 @@ int mplx_get_succ(mplx_ctx *c, const double *node, double *succ, double *cost, i
   if (!c) return MPLX_ERR_ARG;
   if (!node || !succ || !cost || !action || !n_succ) return fail(c, MPLX_ERR_ARG, "mplx_get_succ: NULL argument");
   if (int rc = ready(c)) return rc;
+  MPLX_GUARD_BEGIN
   const int F = 4 * c->dim + 2;
   const int nU = c->nU;
   c->h_state.resize((size_t)F * nU);
@@ -741,6 +750,7 @@ int mplx_get_succ(mplx_ctx *c, const double *node, double *succ, double *cost, i
     for (int f = 0; f < F; f++) succ[(size_t)m * F + f] = c->h_state[(size_t)f * nU + m];
   *n_succ = count;
   return MPLX_OK;
+  MPLX_GUARD_END(c)
 }
 
 int mplx_device_alloc(mplx_ctx *c, size_t bytes, void **dptr) {

@@ -8,6 +8,8 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -106,6 +108,15 @@ inline int fail(mplx_ctx *c, int code, const char *fmt, ...) {
       return mplx_detail::fail((c), MPLX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
                   __FILE__, __LINE__);                                                     \
   } while (0)
+
+// No exception may cross the C ABI (include/mplx.h: "never throws"): entry points that touch std containers wrap
+// their bodies in these.
+#define MPLX_GUARD_BEGIN try {
+#define MPLX_GUARD_END(c)                                                                            \
+  }                                                                                                  \
+  catch (const std::bad_alloc &) { return mplx_detail::fail((c), MPLX_ERR_NOMEM, "out of host memory"); } \
+  catch (const std::exception &e) { return mplx_detail::fail((c), MPLX_ERR_NOMEM, "unexpected exception: %s", e.what()); } \
+  catch (...) { return mplx_detail::fail((c), MPLX_ERR_NOMEM, "unexpected exception"); }
 
 inline int bind_device(mplx_ctx *c) {
   HIP_TRY(c, hipSetDevice(c->device));

@@ -92,6 +92,7 @@ int mplx_planner_attach_ctx(mplx_planner *p, mplx_ctx *ctx) {
   // moves them and counts disagreements with the host evaluation (tests).
   p->pl.edges_only = getenv("MPLX_PLAN_FULL_STATES") == nullptr;
   p->pl.check_states = getenv("MPLX_PLAN_CHECK_STATES") != nullptr;
+  p->pl.check_perturb = getenv("MPLX_PLAN_CHECK_PERTURB") ? atoi(getenv("MPLX_PLAN_CHECK_PERTURB")) : -1;
   p->pl.user = p;
   return MPLX_OK;
 }
@@ -118,13 +119,13 @@ int mplx_planner_set_map(mplx_planner *p, const int8_t *cells, const int32_t *di
     n *= (size_t)dim[i];
   }
   p->pl.grid.res = res;
-  p->pl.grid.cells.assign(cells, cells + n);
+  try { p->pl.grid.cells.assign(cells, cells + n); } catch (...) { return fail(p, MPLX_ERR_NOMEM, "mplx_planner_set_map: out of host memory"); }
   return MPLX_OK;
 }
 
 int mplx_planner_set_controls(mplx_planner *p, const double *U, int32_t nU, int32_t udim) {
   if (!p || !U || nU <= 0 || udim < p->pl.dim) return fail(p, MPLX_ERR_ARG, "mplx_planner_set_controls: bad arguments");
-  p->pl.U.assign(U, U + (size_t)nU * udim);
+  try { p->pl.U.assign(U, U + (size_t)nU * udim); } catch (...) { return fail(p, MPLX_ERR_NOMEM, "mplx_planner_set_controls: out of host memory"); }
   p->pl.nU = nU;
   p->pl.udim = udim;
   return MPLX_OK;
@@ -133,6 +134,7 @@ int mplx_planner_set_controls(mplx_planner *p, const double *U, int32_t nU, int3
 int mplx_planner_configure(mplx_planner *p, const mplx_planner_config *c) {
   if (!p || !c) return MPLX_ERR_ARG;
   p->pl.control = c->control;
+  p->pl.goal_control = c->goal_control ? c->goal_control : c->control;
   p->pl.max_expand = c->max_expand;
   p->pl.batch = c->batch < 1 ? 1 : c->batch;
   p->pl.dt = c->dt;
@@ -151,7 +153,16 @@ int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, 
   if (p->pl.grid.cells.empty()) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: map not set");
   if (p->pl.nU <= 0) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: controls not set");
   if (!p->pl.single && !p->pl.batched) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: no successor provider attached");
-  const int rc = p->pl.plan(start, goal);
+  int rc;
+  try {
+    rc = p->pl.plan(start, goal);
+  } catch (const std::exception &e) {  // no exception crosses the C ABI
+    p->err = std::string("mplx_planner_plan: ") + e.what();
+    return MPLX_ERR_NOMEM;
+  } catch (...) {
+    p->err = "mplx_planner_plan: unexpected exception";
+    return MPLX_ERR_NOMEM;
+  }
   if (rc != 0) {
     p->err = "successor provider failed";
     if (p->ctx) p->err += std::string(": ") + mplx_last_error(p->ctx);
@@ -165,12 +176,11 @@ int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, 
   out->nodes = r.nodes;
   out->device_launches = r.device_launches;
   out->pairs = r.pairs;
-  out->reserved = (int32_t)(r.state_mismatches > 0x7fffffff ? 0x7fffffff : r.state_mismatches);
+  out->state_mismatches = (int32_t)(r.state_mismatches > 0x7fffffff ? 0x7fffffff : r.state_mismatches);
   out->cost = r.cost;
   out->total_time = r.total_time;
   for (int i = 0; i < 4; i++) out->J[i] = r.J[i];
   out->segments = (int32_t)r.traj_actions.size();
-  out->reserved = 0;
   return MPLX_OK;
 }
 
@@ -219,10 +229,9 @@ int mplx_planner_open_set(mplx_planner *p, double *states, int32_t cap, int32_t 
   if (!p || !n) return MPLX_ERR_ARG;
   const int f = p->pl.F();
   int32_t m = 0;
-  for (const mplx::host::Node &nd : p->pl.pool) {
-    if (!nd.opened || nd.closed) continue;
+  for (const mplx::host::OpenList::Item &it : p->pl.pq.items()) {  // the heap, as planner_base.h:77-81 walks it
     if (states && m < cap)
-      for (int i = 0; i < f; i++) states[(size_t)m * f + i] = nd.coord[(size_t)i];
+      for (int i = 0; i < f; i++) states[(size_t)m * f + i] = it.n->coord[(size_t)i];
     m++;
   }
   *n = m;

@@ -30,7 +30,7 @@ extern "C" int mplx_post_lists_device(mplx_ctx *c, const mplx_succ_lists *d_list
   a.nstride = S;
   a.sstride = d_lists->state_stride;
   std::memcpy(a.goal, goal->goal, sizeof(double) * F);
-  a.goal_hash = mplx::host::lattice_hash(D, goal->control, goal->goal);
+  a.goal_hash = mplx::host::lattice_hash(D, goal->goal_control ? goal->goal_control : goal->control, goal->goal);
   a.w = goal->w;
   a.v_max = goal->v_max;
   a.tol_pos = goal->tol_pos;

@@ -185,6 +185,7 @@ class MapPlanner:
     # ---- PlannerBase::plan
     def plan(self, start, goal):
         self._cfg.control = int(start.control)
+        self._cfg.goal_control = int(goal.control) if goal.control else 0  # env_base.h:47 hashes the goal with its own flags
         if self.env is not None:
             self.env.set_control(start.control)
             self.env._flush()
@@ -200,7 +201,7 @@ class MapPlanner:
         o = self._summary
         return {k: getattr(o, k) for k in ("ok", "expansions", "closed", "opened", "nodes", "device_launches",
                                            "pairs", "cost", "total_time", "segments")} | {
-            "J": list(o.J), "state_mismatches": o.reserved}
+            "J": list(o.J), "state_mismatches": o.state_mismatches}
 
     def getCloseSet(self):
         n = C.c_int32()

@@ -220,3 +220,30 @@ def test_host_evaluated_states_equal_the_devices(engine, monkeypatch, control, d
     pl.close()
     assert s["expansions"] > 50 and s["nodes"] > 150, s
     assert s["state_mismatches"] == 0, s
+
+
+def test_state_mismatch_counter_counts(engine, monkeypatch):
+    """Negative self-check of the check above: with one host-evaluated state corrupted on purpose
+    (MPLX_PLAN_CHECK_PERTURB = index of the checked state that gets one bit flipped) the counter must report
+    exactly one mismatch -- so a zero from the test above means the comparison really ran."""
+    monkeypatch.setenv("MPLX_PLAN_CHECK_STATES", "1")
+    monkeypatch.setenv("MPLX_PLAN_CHECK_PERTURB", "7")
+    m = engine
+    edge = 60
+    grid = m.workloads.box_map([edge] * 2, 0.1, 0.06, 34, side_m=(0.3, 0.8))
+    pl = m.MapPlanner(2, device=0)
+    mu = m.MapUtil(2)
+    mu.setMap([0.0] * 2, [edge] * 2, grid.ravel().copy(), 0.1)
+    pl.setMapUtil(mu)
+    pl.setVmax(1.5)
+    pl.setDt(0.5)
+    pl.setU(m.workloads.grid_controls([-1.0, 0.0, 1.0], 2))
+    pl.setBatch(32)
+    pl.setEpsilon(0.0)
+    pl.setMaxNum(300)
+    free = np.argwhere(grid.reshape([edge] * 2) == 0)
+    a, b = free[0][::-1], free[-1][::-1]
+    pl.plan(m.Waypoint(2, m.ACC, pos=(a + 0.5) * 0.1), m.Waypoint(2, m.ACC, pos=(b + 0.5) * 0.1))
+    s = pl.summary()
+    pl.close()
+    assert s["state_mismatches"] == 1, s
