@@ -3,20 +3,34 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C4]
 
-A "step" is one pass of the hot path (one mplx_expand_device launch) over one
-synthetic frontier batch that is already resident in HBM.  The default workload
-is BASELINE.json configs[3], the one the metric is quoted on:
+A "step" is one pass of the hot path (one mplx_expand_lists_device launch) over
+one synthetic frontier batch that is already resident in HBM.  The default
+workload is BASELINE.json configs[3], the one the metric is quoted on:
     C4 = 3D VoxelMapUtil 512^3, Control::ACC, |U| = 729, 64k-node frontier.
-N > 1 (launched by torch.distributed.run, one rank per GPU): the frontier is
-sharded by node, every rank expands its own 64k-node shard against its own
-replica of the map -- no data-path collective -- so scaling is
-"weak" and value = all ranks' pairs / max-over-ranks time.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): THE frontier of the
+workload is block-partitioned by node over the ranks (shard.partition; rank r
+expands nodes [r*N/G, (r+1)*N/G) against its own replica of the map) -- no
+data-path collective, so `value` = the workload's pairs / the
+slowest rank's time per step and scaling is "strong" (BASELINE configs[3]:
+"64k-node frontier, 1 -> 8 x MI355X shard").  The same run also reports
+  weak       every rank a full-size frontier of its own (per-GPU work fixed)
+  allgather  the optional exchange for a consumer that needs the whole successor
+             set on every GPU: lists packed on the device, all-gathered by RCCL
+             over the engine's own buffers (shard.all_gather_packed)
+MPLX_BENCH_FORCE_DIST=1 runs that code path with a world of one.
 
 Rank 0 prints ONE JSON line (see the task contract) including
   roofline     : algorithmic bytes per launch / HIP-event kernel time vs 8 TB/s
   cpu_baseline : the reference's own headers compiled into oracle/_ref ("reference";
                  the CPU oracle, "port", when that build is absent) timed on this
-                 box's host cores on a bounded sample of the same workload.
+                 box's host cores on a bounded sample of the same workload
+and, at N = 1, the rest of BASELINE's metric (--no-extras skips them):
+  e2e            the same batch through host pointers (H2D + kernel + D2H)
+  wavefront      the frontier with realistic locality (open list of a search)
+  other_configs  C2, C3, C5 (C5's potential map made on the device)
+  plan           plan() wall time, reference CPU planner vs the drop-in adapter
+                 vs the engine's host search, on C1 and on a 3D |U| = 729 problem
 """
 import argparse
 import json
@@ -38,25 +52,73 @@ WORKLOAD_DESC = {
     "C4": "C4: 3D VoxelMapUtil 512^3, Control::ACC |U|=729 (9^3), 64k-node synthetic frontier",
     "C5": "C5: 3D 256^3 potential map, Control::ACCxYAW |U|=81, 32k-node synthetic frontier",
 }
+FRONTIER_SEED = {"C2": 2002, "C3": 2003, "C4": 2004, "C5": 2005}
+FRONTIER_KW = {"C2": (2.0, 0.5), "C3": (3.0, 0.5, 2.0, 1.0), "C4": (2.0, 0.5), "C5": (2.0, 0.5)}
+KERNEL_NAME = {"grid": "expand_grid_kernel", "tile": "expand_tile_kernel", "dense": "expand_kernel", "none": "expand_kernel"}
 
 
-def algorithmic_bytes(wl, n_emit, n_samples):
+def algorithmic_bytes(wl, n_nodes, n_emit, n_samples):
     """B_alg = N*S_wp + |U|*udim*8 + samples*(1 + r/8) + N_emit*(S_wp + 8 + 4)."""
     s_wp = (4 * wl.dim + 2) * 8
     r = 1 if wl.region is not None else 0
-    return (wl.n_nodes * s_wp + wl.U.size * 8 + n_samples * (1 + r / 8.0) + n_emit * (s_wp + 8 + 4))
+    return n_nodes * s_wp + wl.U.size * 8 + n_samples * (1 + r / 8.0) + n_emit * (s_wp + 8 + 4)
 
 
 def measured_traffic(workload, kernel):
     """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, each its own
     run; profiles/README.md): bench.py cannot collect counters itself, so it reports the figure measured for
     this workload + kernel, or None when no such profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % workload.lower())
-    try:
-        rec = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    return rec["traffic_bytes"] if rec.get("kernel", "").split("<")[0] in kernel else None
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (rnd, workload.lower()))
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("kernel", "").split("<")[0] in kernel:
+            return rec["traffic_bytes"]
+    return None
+
+
+def count_work(env, frontier, n_nodes):
+    """One untimed launch of the dense kernel with diagnostic outputs: emitted / finite successors and map samples
+    of this frontier (the terms of the algorithmic bytes)."""
+    vs = env.alloc_slots(n_nodes, want_state=False, want_iters=True)
+    env.expand_resident(frontier, vs)
+    env.synchronize()
+    v = vs.download()
+    vs.free()
+    st = v["status"]
+    return (int(np.count_nonzero((st == 1) | (st == 2))), int(np.count_nonzero(st == 1)),
+            int(v["iters"].sum(dtype=np.int64)))
+
+
+def time_lists(env, frontier, lists, steps, warmup):
+    """Kernel time per launch (ms), HIP events on the engine's own stream."""
+    for _ in range(warmup):
+        env.expand_lists_resident(frontier, lists)
+    env.synchronize()
+    env.timer_begin()
+    for _ in range(steps):
+        env.expand_lists_resident(frontier, lists)
+    return env.timer_end() / steps
+
+
+def run_config(m, wl, steps, warmup, device=0):
+    """Resident-lists kernel rate of one workload (used for the configurations next to the headline)."""
+    env = m.EnvMap(wl.dim, device)
+    wl.apply(env)
+    fr = env.upload_frontier(wl.nodes)
+    lists = env.alloc_lists(wl.n_nodes, want_state=True, want_iters=False)
+    n_emit, n_fin, n_samples = count_work(env, fr, wl.n_nodes)
+    ms = time_lists(env, fr, lists, steps, warmup)
+    route = env.last_lists_route()
+    lists.free()
+    fr.free()
+    env.close()
+    b_alg = algorithmic_bytes(wl, wl.n_nodes, n_emit, n_samples)
+    return {"kernel_ms": ms, "pairs_per_s": wl.n_pairs / (ms * 1e-3), "algorithmic_bytes_per_launch": b_alg,
+            "achieved_GBps": b_alg / (ms * 1e-3) / 1e9, "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "pairs": wl.n_pairs, "emitted": n_emit, "finite": n_fin, "map_samples": n_samples, "kernel": KERNEL_NAME[route]}
 
 
 def cpu_baseline(wl, target_seconds=12.0):
@@ -99,6 +161,155 @@ def cpu_baseline(wl, target_seconds=12.0):
     }, oenv, n
 
 
+# ------------------------------------------------------------------ extras (N = 1)
+def extra_e2e(m, wl, reps=3):
+    """The same batch through host pointers (mplx_expand_lists): H2D of the frontier, kernel, D2H of the used list
+    prefixes into the caller's pageable arrays -- SURVEY 8(d) "end-to-end incl. H2D + D2H"."""
+    env = m.EnvMap(wl.dim, 0)
+    wl.apply(env)
+    out = env.expand_lists(wl.nodes, want_iters=False)  # warm-up: code object, device scratch, page faults
+    emitted = int(out["count"].sum(dtype=np.int64))
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = env.expand_lists(wl.nodes, want_iters=False, out=out)  # buffers reused, as a C caller would
+        times.append(time.perf_counter() - t0)
+    env.close()
+    F = 4 * wl.dim + 2
+    bytes_out = wl.n_nodes * 4 + emitted * (4 + 8 + 8 + F * 8)
+    best = min(times)
+    return {"e2e_ms_per_step": best * 1e3, "e2e_pairs_per_s": wl.n_pairs / best, "bytes_copied_back": bytes_out,
+            "copy_back_GBps": bytes_out / best / 1e9, "calls_ms": [round(t * 1e3, 2) for t in times],
+            "what": "mplx_expand_lists on host pointers: frontier H2D, kernel, only the used list prefixes D2H into pageable arrays"}
+
+
+def corridor_fixture():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "corridor_map.npz"))
+    n = int(z["n_cells"])
+    occ = np.unpackbits(z["occupied_bits"])[:n].astype(bool)
+    return dict(cells=np.where(occ, 100, 0).astype(np.int8), dim=[int(x) for x in z["dim"]],
+                origin=[float(x) for x in z["origin"]], res=float(z["resolution"]), start=z["start"], goal=z["goal"])
+
+
+def engine_plan(m, dim, origin, md, cells, res, U, start, goal, v_max, a_max, batch, reps=3):
+    pl = m.MapPlanner(dim, device=0)
+    mu = m.MapUtil(dim)
+    mu.setMap(origin, md, cells, res)
+    pl.setMapUtil(mu)
+    pl.setVmax(v_max)
+    pl.setAmax(a_max)
+    pl.setDt(1.0)
+    pl.setU(U)
+    pl.setBatch(batch)
+    pl.plan(start, goal)  # warm-up
+    best = 1e30
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        ok = pl.plan(start, goal)
+        best = min(best, (time.perf_counter() - t0) * 1e3)
+    s = pl.summary()
+    pl.close()
+    return {"wall_ms": best, "ok": bool(ok), "cost": s["cost"], "expansions": s["expansions"], "launches": s["device_launches"]}
+
+
+def extra_plan(m):
+    """plan() wall time (BASELINE metric, second half): the reference's own MapPlanner on the host CPU
+    (oracle/_ref/libmpl_ref_planner.so, 1 thread -- the reference's search is sequential), the same planner with
+    only get_succ swapped for the MI355X (include/mplx_env_map.hpp, speculative batches), and the engine's host A*
+    with batched expansion.  All three must agree on the trajectory cost."""
+    from oracle import oracle as O
+    out = {}
+    W = m.workloads
+    have_ref = os.path.exists(O.REF_PLANNER_SO)
+    # ---- C1: test_planner_2d on corridor.yaml
+    c = corridor_fixture()
+    U = W.grid_controls([-0.5, 0.0, 0.5], 2)
+    start, goal = m.Waypoint(2, m.ACC, pos=c["start"]), m.Waypoint(2, m.ACC, pos=c["goal"])
+    c1 = {"problem": "C1: test_planner_2d on data/corridor.yaml, ACC, |U| = 9"}
+    c1["engine_host_search"] = engine_plan(m, 2, c["origin"], c["dim"], c["cells"], c["res"], U, start, goal, 1.0, 1.0, 64)
+    if have_ref:
+        oenv = O.Env(2, O.ACC, U, c["cells"], c["dim"], c["origin"], c["res"], v_max=1.0, a_max=1.0, dt=1.0)
+        cpu = min((O.ref_plan(oenv, start.to_row(), goal.to_row(), use_gpu=False) for _ in range(3)), key=lambda r: r["wall_ms"])
+        ad = min((O.ref_plan(oenv, start.to_row(), goal.to_row(), use_gpu=64) for _ in range(3)), key=lambda r: r["wall_ms"])
+        c1["reference_cpu"] = {k: cpu[k] for k in ("wall_ms", "ok", "cost", "expansions")}
+        c1["reference_planner_gpu_adapter"] = {"wall_ms": ad["wall_ms"], "ok": ad["ok"], "cost": ad["cost"],
+                                               "expansions": ad["expansions"], "launches": ad["device_launches"]}
+        c1["agree"] = bool(cpu["cost"] == ad["cost"] == c1["engine_host_search"]["cost"] and cpu["closed"] == 615)
+    out["C1"] = c1
+    # ---- 3D, |U| = 729: large enough for batching to matter
+    edge, res = 120, 0.1
+    grid = W.box_map([edge] * 3, res, 0.08, 4242, side_m=(0.5, 2.5))
+    flat = grid.ravel()
+    U3 = W.grid_controls(np.linspace(-2.0, 2.0, 9), 3)
+
+    def free_near(p):
+        cc = np.array([int(x / res) for x in p])
+        for r in range(0, 30):
+            for d in np.ndindex(2 * r + 1, 2 * r + 1, 2 * r + 1):
+                q = cc + np.array(d) - r
+                if np.all(q >= 0) and np.all(q < edge) and flat[q[0] + edge * (q[1] + edge * q[2])] == 0:
+                    return [(q[i] + 0.5) * res for i in range(3)]
+        raise RuntimeError("no free cell")
+
+    s3 = m.Waypoint(3, m.ACC, pos=free_near([1.0, 1.0, 1.0]))
+    g3 = m.Waypoint(3, m.ACC, pos=free_near([edge * res - 1.0, edge * res - 1.2, edge * res - 1.5]))
+    p3 = {"problem": "3D %d^3 voxels, ACC, |U| = 729, v_max 2" % edge}
+    p3["engine_host_search"] = engine_plan(m, 3, [0.0] * 3, [edge] * 3, flat, res, U3, s3, g3, 2.0, 2.0, 64, reps=2)
+    if have_ref:
+        oenv = O.Env(3, O.ACC, U3, flat, [edge] * 3, [0.0] * 3, res, v_max=2.0, a_max=2.0, dt=1.0)
+        cpu = O.ref_plan(oenv, s3.to_row(), g3.to_row(), use_gpu=False)
+        ad = O.ref_plan(oenv, s3.to_row(), g3.to_row(), use_gpu=64)
+        p3["reference_cpu"] = {k: cpu[k] for k in ("wall_ms", "ok", "cost", "expansions")}
+        p3["reference_planner_gpu_adapter"] = {"wall_ms": ad["wall_ms"], "ok": ad["ok"], "cost": ad["cost"],
+                                               "expansions": ad["expansions"], "launches": ad["device_launches"]}
+        p3["agree"] = bool(cpu["cost"] == ad["cost"] == p3["engine_host_search"]["cost"])
+        p3["speedup_engine_vs_reference_cpu"] = cpu["wall_ms"] / p3["engine_host_search"]["wall_ms"]
+        p3["speedup_adapter_vs_reference_cpu"] = cpu["wall_ms"] / ad["wall_ms"]
+    out["3D"] = p3
+    out["cpu_threads_used"] = 1
+    return out
+
+
+def extras(m, args, wl, out):
+    """Everything BASELINE's metric names beyond the headline kernel rate; each leg is independent and a failure is
+    recorded instead of losing the line."""
+    def leg(name, fn):
+        t0 = time.time()
+        try:
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if isinstance(out[name], dict):
+            out[name]["leg_seconds"] = round(time.time() - t0, 2)
+
+    leg("e2e", lambda: extra_e2e(m, wl))
+
+    def wavefront():
+        import copy
+        w2 = copy.copy(wl)
+        w2.nodes = m.workloads.wavefront_frontier(wl, wl.n_nodes, 0)
+        r = run_config(m, w2, args.steps, args.warmup)
+        r["value"] = r.pop("pairs_per_s")
+        r["what"] = "same workload, frontier = the first %d open-list nodes of an eps = 0 search from the map centre" % wl.n_nodes
+        return r
+    leg("wavefront", wavefront)
+
+    def others():
+        res = {}
+        for name in ("C2", "C3", "C5"):
+            if name == args.workload:
+                continue
+            stats = {}
+            w = m.workloads.make(name, potential_fn=m.workloads.device_potential_fn(0, stats) if name == "C5" else None)
+            r = run_config(m, w, args.steps, args.warmup)
+            r.update(stats)
+            r["workload"] = WORKLOAD_DESC[name]
+            res[name] = r
+        return res
+    leg("other_configs", others)
+    leg("plan", lambda: extra_plan(m))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,12 +319,10 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="map edge scale (debug only; invalidates the metric)")
     ap.add_argument("--nodes", type=int, default=None, help="frontier size override (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip e2e / wavefront / other_configs / plan (N = 1 only)")
     ap.add_argument("--frontier", default="random", choices=["random", "wavefront"],
                     help="random: SURVEY 8(d)'s uniformly scattered frontier (the headline); wavefront: the open list of "
-                         "an eps = 0 search from the map centre (realistic locality; reported in profiles/README.md)")
-    ap.add_argument("--output", default="lists", choices=["lists", "dense", "dense-compact"],
-                    help="lists: per-node successor lists, the reference's output shape (count, action, cost, hash, "
-                         "full Waypoint) -- default; dense: one 129-B slot per pair; dense-compact: status+cost+hash only")
+                         "an eps = 0 search from the map centre (realistic locality; also reported as an extra)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,133 +338,205 @@ def main():
     import torch.distributed as dist
 
     import motion_primitive_library_amd as m
+    from motion_primitive_library_amd import shard
 
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    # MPLX_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL init, barrier, all-reduce of the timing) with whatever
-    # world size the launcher gave, including 1 -- the only way to exercise it on a one-GPU box
-    force_dist = os.environ.get("MPLX_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
-    if world > 1 or force_dist:
+    # MPLX_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL init, barrier, all-reduce of the timing, the list
+    # gather) with whatever world size the launcher gave, including 1 -- the only way to exercise it on a one-GPU box
+    force_dist = os.environ.get("MPLX_BENCH_FORCE_DIST") == "1"
+    distributed = world > 1 or force_dist
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    # ---- build the workload; rank r gets shard r of the global frontier
-    t_gen = time.time()
-    wl = m.workloads.make(args.workload, scale=args.scale, n_nodes=args.nodes)
-    if rank > 0:
-        seed = {"C2": 2002, "C3": 2003, "C4": 2004, "C5": 2005}[args.workload] + 100 * rank
-        kw = {"C2": (2.0, 0.5), "C3": (3.0, 0.5, 2.0, 1.0), "C4": (2.0, 0.5), "C5": (2.0, 0.5)}[args.workload]
-        wl.nodes = m.workloads.random_frontier(wl.grid, wl.origin, wl.res, wl.n_nodes, seed, wl.control, *kw)
+    # ---- the workload; rank r owns block r of ITS frontier
+    stats = {}
+    pot_fn = m.workloads.device_potential_fn(local_rank, stats) if args.workload == "C5" else None
+    wl = m.workloads.make(args.workload, scale=args.scale, n_nodes=args.nodes, potential_fn=pot_fn)
     if args.frontier == "wavefront":
         wl.nodes = m.workloads.wavefront_frontier(wl, wl.n_nodes, local_rank)
-    t_gen = time.time() - t_gen
+    N, nU = wl.n_nodes, wl.U.shape[0]
+    lo, hi = shard.partition(N, world, rank)
+    n_loc = hi - lo
+    my_nodes = np.ascontiguousarray(wl.nodes[:, lo:hi])
 
     env = m.EnvMap(wl.dim, local_rank)
     wl.apply(env)
-    frontier = env.upload_frontier(wl.nodes)
-    if args.output == "lists":
-        slots = env.alloc_lists(wl.n_nodes, want_state=True, want_iters=False)
-        launch = lambda: env.expand_lists_resident(frontier, slots)
-    else:
-        slots = env.alloc_slots(wl.n_nodes, want_state=(args.output == "dense"), want_iters=False)
-        launch = lambda: env.expand_resident(frontier, slots)
+    alloc = shard.torch_alloc("cuda:%d" % local_rank) if distributed else None  # RCCL moves these very buffers
+    frontier = env.upload_frontier(my_nodes)
+    slots = env.alloc_lists(n_loc, want_state=True, want_iters=False, alloc=alloc)
+    launch = lambda: env.expand_lists_resident(frontier, slots)
     dev_name, cus = env.device_info()
 
-    # ---- one untimed verification launch: counts for the algorithmic bytes
-    vs = env.alloc_slots(wl.n_nodes, want_state=False, want_iters=True)
-    env.expand_resident(frontier, vs)
-    env.synchronize()
-    v = vs.download()
-    vs.free()
-    n_emit = int(np.count_nonzero((v["status"] == 1) | (v["status"] == 2)))
-    n_finite = int(np.count_nonzero(v["status"] == 1))
-    n_samples = int(v["iters"].sum(dtype=np.int64))
-    b_alg = algorithmic_bytes(wl, n_emit, n_samples)
+    # ---- one untimed verification launch: counts for the algorithmic bytes of THIS rank's launch
+    n_emit, n_finite, n_samples = count_work(env, frontier, n_loc)
+    b_alg = algorithmic_bytes(wl, n_loc, n_emit, n_samples)
 
     def barrier():
-        if world > 1 or force_dist:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, steps):
+        """W warm-ups were done by the caller; K steps bracketed by barrier + synchronize on both sides."""
+        barrier()
+        t0 = time.perf_counter()
+        env.timer_begin()
+        for _ in range(steps):
+            fn()
+        kernel_ms_total = env.timer_end()  # HIP events on the engine's own stream (synchronises it)
+        barrier()
+        el = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, kernel_ms_total / steps
+
     for _ in range(args.warmup):
         launch()
-    barrier()
-    t0 = time.perf_counter()
-    env.timer_begin()
-    for _ in range(args.steps):
-        launch()
-    kernel_ms_total = env.timer_end()  # HIP events on the engine's own stream
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, kernel_ms = timed(launch, args.steps)
+    route = env.last_lists_route()
 
-    if world > 1 or force_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cnt = torch.tensor([wl.n_pairs], dtype=torch.float64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_pairs = float(cnt.item())
+    # ---- parity of the TIMED output: the lists the timed launches wrote, against the oracle
+    timed_head = slots.download_nodes(0, min(n_loc, 512)) if rank == 0 else None
+
+    weak = gather = None
+    if distributed:
+        # ---- weak scaling: every rank a full-size frontier of its own
+        nodes_w = wl.nodes if rank == 0 else m.workloads.random_frontier(
+            wl.grid, wl.origin, wl.res, N, FRONTIER_SEED[args.workload] + 100 * rank, wl.control, *FRONTIER_KW[args.workload])
+        fw = env.upload_frontier(nodes_w)
+        sw = env.alloc_lists(N, want_state=True, want_iters=False)
+        launch_w = lambda: env.expand_lists_resident(fw, sw)
+        for _ in range(args.warmup):
+            launch_w()
+        el_w, k_w = timed(launch_w, args.steps)
+        weak = {"value": float(N) * nU * world * args.steps / el_w, "unit": "pairs/s", "ms_per_step": el_w / args.steps * 1e3,
+                "kernel_ms_rank0": k_w, "frontier_nodes_per_gpu": N, "scaling": "weak"}
+        sw.free()
+        fw.free()
+        # ---- the optional all-gather of the successor lists (packed on the device, moved by RCCL)
+        try:
+            packed = env.alloc_packed(n_loc, capacity=(n_loc + 1) * nU, want_state=True, alloc=alloc)
+
+            def pack_and_gather(want_state):
+                env.pack_lists(slots, packed)
+                env.synchronize()  # engine stream -> torch's
+                cnt, offs, rows = shard.packed_views(packed, n_loc)
+                if not want_state:
+                    rows = {k: v for k, v in rows.items() if k != "state"}
+                res = shard.all_gather_packed(cnt, offs, rows, n_loc)
+                torch.cuda.synchronize()
+                return res
+
+            gather = {}
+            for label, ws in (("edges", False), ("full", True)):
+                pack_and_gather(ws)  # warm-up
+                barrier()
+                t0 = time.perf_counter()
+                reps = 3
+                for _ in range(reps):
+                    res = pack_and_gather(ws)
+                barrier()
+                dt_ = (time.perf_counter() - t0) / reps
+                entries = int(res[4][-1])
+                bpe = 20 + (8 * (4 * wl.dim + 2) if ws else 0)
+                gather[label] = {"ms": dt_ * 1e3, "entries": entries, "bytes_per_entry": bpe,
+                                 "received_GBps_per_rank": entries * bpe * (world - 1) / max(world, 1) / dt_ / 1e9}
+            gather["what"] = ("pack on the device + torch.distributed all_gather_into_tensor (RCCL) of the packed rows of every "
+                              "rank, padded to the largest rank, compacted on the device; edges = action + cost + hash, "
+                              "full = + the 4D+2 state rows")
+            packed.free()
+        except Exception as e:  # noqa: BLE001 -- never lose the headline to the optional exchange
+            gather = {"error": "%s: %s" % (type(e).__name__, e)}
+        # global work of the strong-scaling step, for the record
+        tot = torch.tensor([n_emit, n_samples], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        n_emit_all, n_samples_all = int(tot[0].item()), int(tot[1].item())
     else:
-        total_pairs = float(wl.n_pairs)
+        n_emit_all, n_samples_all = n_emit, n_samples
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        out_kernel = {"grid": "expand_grid_kernel", "tile": "expand_tile_kernel", "dense": "expand_kernel",
-                      "none": "expand_kernel"}[env.last_lists_route()]
-        kernel_ms = kernel_ms_total / args.steps
+        out_kernel = KERNEL_NAME[route]
         achieved = b_alg / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "node-expansions/s (frontier x |U| pair evaluations per second)",
-            "value": total_pairs * args.steps / elapsed,
+            "value": float(N) * nU * args.steps / elapsed,
             "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": WORKLOAD_DESC[args.workload] + ("" if args.scale == 1.0 and args.nodes is None else
                                                            " [DEBUG scale=%g nodes=%s]" % (args.scale, args.nodes)),
-                "frontier": args.frontier, "frontier_nodes_per_gpu": wl.n_nodes, "controls": int(wl.U.shape[0]), "dim": wl.dim,
-                "pairs_per_step_per_gpu": wl.n_pairs, "map_cells": int(wl.grid.size),
-                "output": {"lists": "per-node successor lists: count + action + cost + hash + full Waypoint (4D+2 doubles), emitted successors only",
-                           "dense": "dense slots: status + cost + hash + full Waypoint for every pair",
-                           "dense-compact": "dense slots: status + cost + hash"}[args.output],
-                "sharding": "frontier nodes block-partitioned over ranks, map replicated, no collective",
+                "frontier": args.frontier, "frontier_nodes": N, "frontier_nodes_per_gpu": n_loc,
+                "controls": int(nU), "dim": wl.dim, "pairs_per_step": N * nU, "map_cells": int(wl.grid.size),
+                "output": "per-node successor lists: count + action + cost + hash + full Waypoint (4D+2 doubles), emitted successors only",
+                "sharding": "the frontier block-partitioned by node over the ranks (strong scaling), map replicated per "
+                            "rank, no data-path collective; the optional list all-gather is timed separately",
                 "device": dev_name, "compute_units": cus,
-                "kernel": {"grid": "expand_grid_kernel (per-axis factorised tables in LDS)",
-                           "tile": "expand_tile_kernel", "dense": "expand_kernel + compact_lists_kernel",
-                           "none": "expand_kernel"}[env.last_lists_route()],
+                "kernel": {"grid": "expand_grid_kernel (per-axis factorised tables in LDS)", "tile": "expand_tile_kernel",
+                           "dense": "expand_kernel + compact_lists_kernel", "none": "expand_kernel"}[route],
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.workload, out_kernel) if args.output == "lists" else None,
+                "traffic": measured_traffic(args.workload, out_kernel) if world == 1 and args.frontier == "random" else None,
+                "traffic_source": "committed rocprofv3 --pmc passes of this workload + kernel (profiles/), not collected in this run",
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_alg,
+                "launch": "rank 0's launch: %d nodes" % n_loc,
                 "emitted": n_emit, "finite": n_finite, "map_samples": n_samples,
+                "emitted_all_ranks": n_emit_all, "map_samples_all_ranks": n_samples_all,
             },
         }
-        if not args.no_cpu_baseline and world >= 1:
+        out.update({k: v for k, v in stats.items()})
+        if weak is not None:
+            out["weak"] = weak
+        if gather is not None:
+            out["allgather"] = gather
+        if not args.no_cpu_baseline and world == 1:
             cb, oenv, n_chk = cpu_baseline(wl)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_all_cores"] = out["value"] / cb["value"]
-            # cheap consistency check of the measured run against the oracle on a slice
+        # the lists the TIMED launches wrote (first <= 512 nodes of rank 0) against the oracle: same successors, same
+        # order, bit-identical hash and state, cost exact (1e-6 for yaw controls: trig in the per-sample cost)
+        try:
+            from oracle import compare as OC
             from oracle import oracle as O
-            n_chk = min(n_chk, 512)
-            ref = O.expand(oenv, wl.nodes[:, :n_chk], threads=os.cpu_count() or 1, want_state=False)
-            k = n_chk * wl.U.shape[0]
-            out["parity_sample_ok"] = bool(np.array_equal(v["status"][:k], ref["status"]) and
-                                           np.array_equal(v["hash"][:k], ref["hash"]) and
-                                           np.array_equal(v["iters"][:k], ref["iters"]))
+            oenv = O.Env(wl.dim, wl.control, wl.U, wl.grid, wl.map_dim, wl.origin, wl.res,
+                         potential=wl.potential, region=wl.region, **wl.params)
+            n_chk = min(n_loc, 512)
+            use_ref = os.path.exists(O.REF_SO)
+            ref = O.expand(oenv, my_nodes[:, :n_chk], threads=os.cpu_count() or 1, ref=use_ref)
+            problems = OC.lists_mismatches(timed_head, ref, n_chk, nU, cost_rtol=1e-6 if wl.control & 0x10 else 0.0)
+            out["parity_sample_ok"] = not problems
+            out["parity_sample"] = {"what": "lists written by the timed %s launches, first %d nodes, vs %s" % (
+                out_kernel, n_chk, "oracle/_ref (reference headers)" if use_ref else "the oracle"), "problems": problems}
+        except Exception as e:  # noqa: BLE001
+            out["parity_sample_ok"] = False
+            out["parity_sample"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not distributed and not args.no_extras and args.scale == 1.0 and args.nodes is None:
+            slots.free()
+            frontier.free()
+            env.close()
+            env = None
+            extras(m, args, wl, out)
         print(json.dumps(out), flush=True)
 
-    slots.free()
-    frontier.free()
-    env.close()
-    if world > 1 or force_dist:
+    if env is not None:
+        slots.free()
+        frontier.free()
+        env.close()
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -225,6 +225,60 @@ typedef struct {
 int mplx_post_lists_device(mplx_ctx *ctx, const mplx_succ_lists *d_lists, int64_t n_nodes,
                            const mplx_goal_spec *goal, const mplx_post *d_out);
 
+/* ---- packed lists and the multi-GPU exchange ----------------
+ * The frontier is block-partitioned by node over the GPUs (rank r expands nodes
+ * [r*N/G, (r+1)*N/G) against its own replica of the map: every (node, control)
+ * pair is independent, env_map.h:147-172 reads nothing but its arguments), so the
+ * expansion itself needs NO collective.  When a consumer wants the complete
+ * successor set on every GPU (an on-device dedup / open-list merge; north_star:
+ * "an RCCL all-gather of successor lists over xGMI only when the open set exceeds
+ * a single GPU's launch"), the used prefixes of the lists are first PACKED on the
+ * device -- node k owns entries [offs[k], offs[k+1]) of every row, no padding --
+ * and the packed rows are all-gathered with exact sizes.                       */
+typedef struct {
+  int32_t *count;          /* [n_nodes]      copy of the lists' counts           */
+  int64_t *offs;           /* [n_nodes + 1]  exclusive prefix sums; offs[n_nodes] = total entries */
+  int32_t *action;         /* [capacity]     any row pointer may be NULL         */
+  double *cost;
+  uint64_t *hash;
+  double *state;           /* [4D+2][state_stride]                               */
+  int64_t state_stride;    /* >= capacity                                        */
+  int64_t capacity;        /* entries every non-NULL row can hold                */
+} mplx_packed_lists;
+
+/* d_lists (as filled by mplx_expand_lists_device) -> d_out, all device pointers,
+ * asynchronous on the context stream.  A capacity >= n_nodes * nU always
+ * suffices; a smaller one is checked against the actual total (one
+ * synchronisation) and the call fails with MPLX_ERR_ARG when it is too small.
+ * h_total_or_null, when given, receives offs[n_nodes] (synchronises).           */
+int mplx_pack_lists_device(mplx_ctx *ctx, const mplx_succ_lists *d_lists, int64_t n_nodes,
+                           const mplx_packed_lists *d_out, int64_t *h_total_or_null);
+
+/* RCCL communicator of the context (one context = one GPU = one rank; one process
+ * per GPU or several contexts in one process).  The 128-byte id is RCCL's
+ * ncclUniqueId: rank 0 makes it, the application hands it to the other ranks by
+ * whatever means it has (MPI, a socket, torch.distributed ...).  librccl.so.1 is
+ * loaded on first use; libmplx.so does not link it.                             */
+#define MPLX_COMM_ID_BYTES 128
+int mplx_comm_unique_id(uint8_t *id_out /* [MPLX_COMM_ID_BYTES] */);
+int mplx_comm_init(mplx_ctx *ctx, const uint8_t *id, int32_t rank, int32_t world);
+int mplx_comm_destroy(mplx_ctx *ctx);
+/* Replicates the map (and the potential map / search region, when set) of rank
+ * `root` on every rank with ncclBroadcast over xGMI instead of one H2D copy per
+ * rank; every rank must have called mplx_set_map with the same geometry.        */
+int mplx_comm_broadcast_map(mplx_ctx *ctx, int32_t root);
+/* All-gather of packed lists: rank r contributes d_local (n_local nodes, packed by
+ * mplx_pack_lists_device); every rank receives the concatenation in rank order
+ * (= ascending global node index for the block partition) in d_all, whose rows
+ * must hold the global totals (n_nodes_total nodes; capacity >= sum of totals).
+ * Exact-size exchange: one small ncclAllGather of (n_local, total) pairs, then an
+ * all-pairs ncclSend / ncclRecv of the rows inside ONE group call -- direct
+ * peer-to-peer copies, all xGMI links busy at once, no padding and no ring.  d_all->offs is
+ * rebuilt from the gathered counts.  h_node_offs / h_entry_offs ([world + 1], may
+ * be NULL) receive the per-rank node and entry offsets.  Synchronises.          */
+int mplx_comm_allgather_lists(mplx_ctx *ctx, const mplx_packed_lists *d_local, int64_t n_local,
+                              const mplx_packed_lists *d_all, int64_t *h_node_offs, int64_t *h_entry_offs);
+
 /* ---- batched re-validation of stored edges for incremental re-planning
  *       --------------------------------------------------- */
 /* For every edge (parent waypoint, action id): env_base::forward_action

@@ -8,9 +8,10 @@ fallback of any kind.
 """
 from . import _abi, workloads
 from .env import (ACC, ACCxYAW, JRK, JRKxYAW, SNP, SNPxYAW, VEL, VELxYAW, SLOT_BLOCKED, SLOT_FINITE,
-                  SLOT_SKIP_DYN, SLOT_SKIP_SAME, DeviceArray, EnvMap, Lists, Slots, Waypoint, lists_from_dense)
+                  SLOT_SKIP_DYN, SLOT_SKIP_SAME, DeviceArray, EnvMap, Lists, PackedLists, Slots, Waypoint, lists_from_dense,
+                  pack_host_lists)
 
 from .planner import MapPlanner, MapUtil, Trajectory
 
-__all__ = ["MapPlanner", "MapUtil", "Trajectory", "EnvMap", "Waypoint", "Slots", "Lists", "lists_from_dense", "DeviceArray", "workloads", "VEL", "ACC", "JRK", "SNP", "VELxYAW",
+__all__ = ["MapPlanner", "MapUtil", "Trajectory", "EnvMap", "Waypoint", "Slots", "Lists", "lists_from_dense", "PackedLists", "pack_host_lists", "DeviceArray", "workloads", "VEL", "ACC", "JRK", "SNP", "VELxYAW",
            "ACCxYAW", "JRKxYAW", "SNPxYAW", "SLOT_SKIP_SAME", "SLOT_FINITE", "SLOT_BLOCKED", "SLOT_SKIP_DYN"]

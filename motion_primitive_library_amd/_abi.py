@@ -19,7 +19,10 @@ SYMBOLS = [
     "mplx_set_map", "mplx_set_potential", "mplx_set_region", "mplx_set_params", "mplx_set_controls",
     "mplx_update_potential_map", "mplx_set_search_region_path",
     "mplx_expand_device", "mplx_expand", "mplx_expand_lists_device", "mplx_expand_lists", "mplx_get_succ",
-    "mplx_post_lists_device", "mplx_check_edges",
+    "mplx_post_lists_device",
+    "mplx_pack_lists_device", "mplx_comm_unique_id", "mplx_comm_init", "mplx_comm_destroy", "mplx_comm_broadcast_map",
+    "mplx_comm_allgather_lists",
+    "mplx_check_edges",
     "mplx_device_alloc", "mplx_device_free", "mplx_memcpy_h2d", "mplx_memcpy_d2h", "mplx_memset",
     "mplx_synchronize", "mplx_timer_begin", "mplx_timer_end",
     "mplx_planner_create", "mplx_planner_destroy", "mplx_planner_attach_ctx", "mplx_planner_set_provider",
@@ -52,6 +55,16 @@ class SuccLists(C.Structure):
         ("count", C.c_void_p), ("action", C.c_void_p), ("cost", C.c_void_p), ("hash", C.c_void_p),
         ("state", C.c_void_p), ("state_stride", C.c_int64), ("iters", C.c_void_p), ("node_stride", C.c_int64),
     ]
+
+
+class PackedLists(C.Structure):
+    _fields_ = [
+        ("count", C.c_void_p), ("offs", C.c_void_p), ("action", C.c_void_p), ("cost", C.c_void_p), ("hash", C.c_void_p),
+        ("state", C.c_void_p), ("state_stride", C.c_int64), ("capacity", C.c_int64),
+    ]
+
+
+COMM_ID_BYTES = 128
 
 
 class GoalSpec(C.Structure):
@@ -129,6 +142,12 @@ def lib():
         "mplx_get_succ": (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(i32)]),
         "mplx_post_lists_device": (C.c_int, [vp, C.POINTER(SuccLists), i64, C.POINTER(GoalSpec), C.POINTER(Post)]),
         "mplx_check_edges": (C.c_int, [vp, vp, vp, i64, i64, C.POINTER(EdgesOut)]),
+        "mplx_pack_lists_device": (C.c_int, [vp, C.POINTER(SuccLists), i64, C.POINTER(PackedLists), C.POINTER(i64)]),
+        "mplx_comm_unique_id": (C.c_int, [vp]),
+        "mplx_comm_init": (C.c_int, [vp, vp, i32, i32]),
+        "mplx_comm_destroy": (C.c_int, [vp]),
+        "mplx_comm_broadcast_map": (C.c_int, [vp, i32]),
+        "mplx_comm_allgather_lists": (C.c_int, [vp, C.POINTER(PackedLists), i64, C.POINTER(PackedLists), vp, vp]),
         "mplx_device_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
         "mplx_device_free": (C.c_int, [vp, vp]),
         "mplx_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),

@@ -132,6 +132,8 @@ void mplx_destroy(mplx_ctx *c) {
                     &c->s_cost, &c->s_hash, &c->s_state, &c->s_iters, &c->s_count, &c->s_action, &c->tables,
                     &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx, &c->blk, &c->sat, &c->prep_lut, &c->prep_a, &c->prep_b, &c->post_keys, &c->e_parents, &c->e_action, &c->e_free, &c->e_cost, &c->e_cells, &c->e_count})
     release(*b);
+  (void)mplx_comm_destroy(c);
+  release(c->comm_meta);
   mplx_detail::release_copy_buffers(c);
   release(c->s_arena);
   if (c->h_arena) (void)hipHostFree(c->h_arena);

@@ -85,6 +85,10 @@ struct mplx_ctx {
   std::vector<int64_t> pk_hoffs;
   void *pk_hb = nullptr;  // pinned block of expand_lists_packed: nodes, counts, offsets
   size_t pk_hb_cap = 0;
+  // RCCL communicator of this context (comm_api.cpp); the library is loaded on first use
+  void *comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  mplx_detail::DevBuf comm_meta;  // [world][2] int64: (n_local nodes, total entries) of every rank
   std::vector<uint8_t> h_status;
   std::vector<double> h_cost, h_state;
 };

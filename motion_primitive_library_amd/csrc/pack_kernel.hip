@@ -26,7 +26,38 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const PackArgs A) {
   }
 }
 
+// Exclusive prefix sums of the per-node counts: offs[k] = count[0] + ... + count[k-1], offs[n] = total.  One
+// workgroup: each thread sums a contiguous slice, the slice sums are scanned through LDS, then each thread
+// writes its slice (n is a frontier size: at most a few million, i.e. microseconds).
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t *count, int64_t n, int64_t *offs) {
+  __shared__ int64_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t a = (int64_t)t * per, b = (a + per < n) ? a + per : n;
+  int64_t s = 0;
+  for (int64_t k = a; k < b; k++) s += count[k];
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int64_t v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int64_t run = part[t] - s;  // exclusive
+  for (int64_t k = a; k < b; k++) {
+    offs[k] = run;
+    run += count[k];
+  }
+  if (t == 1023) offs[n] = part[1023];
+}
+
 }  // namespace
+
+hipError_t launch_scan_counts(const int32_t *count, int64_t n, int64_t *offs, hipStream_t stream) {
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, count, n, offs);
+  return hipGetLastError();
+}
 
 hipError_t launch_pack_rows(const PackArgs &a, int64_t n_nodes, hipStream_t stream) {
   if (n_nodes <= 0) return hipSuccess;

@@ -78,10 +78,12 @@ class DeviceArray:
         assert host.nbytes <= self.nbytes
         _abi.check(self._env._ctx, _abi.lib().mplx_memcpy_h2d(self._env._ctx, self.ptr, host.ctypes.data, host.nbytes))
 
-    def download(self, dtype, shape):
+    def download(self, dtype, shape, offset=0):
+        """Copy `shape` elements of `dtype` starting `offset` BYTES into the allocation back to the host."""
         out = np.empty(shape, dtype=dtype)
-        assert out.nbytes <= self.nbytes
-        _abi.check(self._env._ctx, _abi.lib().mplx_memcpy_d2h(self._env._ctx, out.ctypes.data, self.ptr, out.nbytes))
+        assert int(offset) + out.nbytes <= self.nbytes
+        _abi.check(self._env._ctx, _abi.lib().mplx_memcpy_d2h(self._env._ctx, out.ctypes.data, self.ptr + int(offset),
+                                                               out.nbytes))
         return out
 
     def free(self):
@@ -94,6 +96,12 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+
+def _alloc(env, nbytes, alloc=None):
+    """An HBM allocation for the engine: through the C ABI by default, or from `alloc(nbytes)` -- any object with
+    .ptr / .nbytes / .download / .free, e.g. shard.TorchArray, so that torch.distributed can move the same memory."""
+    return DeviceArray(env, nbytes) if alloc is None else alloc(int(nbytes))
 
 
 class Slots:
@@ -139,7 +147,7 @@ class Slots:
 class Lists:
     """HBM-resident per-node successor lists (mplx_succ_lists)."""
 
-    def __init__(self, env, n_nodes, nU, want_state=True, want_iters=False, want_hash=True, stride=None):
+    def __init__(self, env, n_nodes, nU, want_state=True, want_iters=False, want_hash=True, stride=None, alloc=None):
         self.n_nodes, self.nU = int(n_nodes), int(nU)
         # entries reserved per node: a multiple of 32 keeps every node's rows on 128-byte lines (and lets the
         # kernel complete the last line of each list instead of leaving a partial-line store)
@@ -147,12 +155,12 @@ class Lists:
         self.n_slots = self.n_nodes * self.stride
         self.n_fields = env.n_fields
         n = max(self.n_slots, 1)
-        self.count = DeviceArray(env, max(self.n_nodes, 1) * 4)
-        self.action = DeviceArray(env, n * 4)
-        self.cost = DeviceArray(env, n * 8)
-        self.hash = DeviceArray(env, n * 8) if want_hash else None
-        self.state = DeviceArray(env, n * 8 * self.n_fields) if want_state else None
-        self.iters = DeviceArray(env, n * 4) if want_iters else None
+        self.count = _alloc(env, max(self.n_nodes, 1) * 4, alloc)
+        self.action = _alloc(env, n * 4, alloc)
+        self.cost = _alloc(env, n * 8, alloc)
+        self.hash = _alloc(env, n * 8, alloc) if want_hash else None
+        self.state = _alloc(env, n * 8 * self.n_fields, alloc) if want_state else None
+        self.iters = _alloc(env, n * 4, alloc) if want_iters else None
 
     def c_struct(self):
         s = _abi.SuccLists()
@@ -179,10 +187,89 @@ class Lists:
             out["iters"] = self.iters.download(np.int32, (self.n_slots,))
         return out
 
+    def download_nodes(self, lo, hi):
+        """The lists of nodes [lo, hi) only, as download() would return them for a frontier of hi - lo nodes
+        (lets a host with less memory than the device walk a full-size result chunk by chunk)."""
+        lo, hi = int(lo), int(hi)
+        n, S = hi - lo, self.stride
+        out = {
+            "stride": S,
+            "count": self.count.download(np.int32, (n,), lo * 4),
+            "action": self.action.download(np.int32, (n * S,), lo * S * 4),
+            "cost": self.cost.download(np.float64, (n * S,), lo * S * 8),
+        }
+        if self.hash:
+            out["hash"] = self.hash.download(np.uint64, (n * S,), lo * S * 8)
+        if self.state:
+            st = np.empty((self.n_fields, n * S), np.float64)
+            for r in range(self.n_fields):
+                st[r] = self.state.download(np.float64, (n * S,), (r * self.n_slots + lo * S) * 8)
+            out["state"] = st
+        if self.iters:
+            out["iters"] = self.iters.download(np.int32, (n * S,), lo * S * 4)
+        return out
+
     def free(self):
         for b in (self.count, self.action, self.cost, self.hash, self.state, self.iters):
             if b is not None:
                 b.free()
+
+
+class PackedLists:
+    """HBM-resident packed successor lists (mplx_packed_lists): node k owns entries [offs[k], offs[k+1]) of every
+    row, no padding -- the form the multi-GPU all-gather moves and an on-device consumer reads."""
+
+    def __init__(self, env, n_nodes, capacity, want_state=True, want_hash=True, alloc=None):
+        self.n_nodes, self.capacity = int(n_nodes), max(int(capacity), 1)
+        self.n_fields = env.n_fields
+        c = self.capacity
+        self.count = _alloc(env, max(self.n_nodes, 1) * 4, alloc)
+        self.offs = _alloc(env, (self.n_nodes + 1) * 8, alloc)
+        self.action = _alloc(env, c * 4, alloc)
+        self.cost = _alloc(env, c * 8, alloc)
+        self.hash = _alloc(env, c * 8, alloc) if want_hash else None
+        self.state = _alloc(env, c * 8 * self.n_fields, alloc) if want_state else None
+
+    def c_struct(self):
+        s = _abi.PackedLists()
+        s.count, s.offs, s.action, s.cost = self.count.ptr, self.offs.ptr, self.action.ptr, self.cost.ptr
+        s.hash = self.hash.ptr if self.hash else None
+        s.state = self.state.ptr if self.state else None
+        s.state_stride = self.capacity
+        s.capacity = self.capacity
+        return s
+
+    def download(self, n_nodes=None):
+        n = self.n_nodes if n_nodes is None else int(n_nodes)
+        offs = self.offs.download(np.int64, (n + 1,))
+        total = int(offs[n])
+        out = {"offs": offs, "total": total, "count": self.count.download(np.int32, (n,)),
+               "action": self.action.download(np.int32, (total,)), "cost": self.cost.download(np.float64, (total,))}
+        if self.hash:
+            out["hash"] = self.hash.download(np.uint64, (total,))
+        if self.state:
+            out["state"] = self.state.download(np.float64, (self.n_fields, self.capacity))[:, :total]
+        return out
+
+    def free(self):
+        for b in (self.count, self.offs, self.action, self.cost, self.hash, self.state):
+            if b is not None:
+                b.free()
+
+
+def pack_host_lists(lists, n_nodes):
+    """Host-side restatement of mplx_pack_lists_device on downloaded lists (tests, CPU stand-ins)."""
+    S = int(lists["stride"])
+    cnt = np.asarray(lists["count"][:n_nodes], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    src = (np.repeat(np.arange(n_nodes, dtype=np.int64) * S - offs[:-1], cnt) + np.arange(offs[-1], dtype=np.int64))
+    out = {"offs": offs, "total": int(offs[-1]), "count": cnt.astype(np.int32)}
+    for k in ("action", "cost", "hash"):
+        if lists.get(k) is not None:
+            out[k] = lists[k][src]
+    if lists.get("state") is not None:
+        out["state"] = lists["state"][:, src]
+    return out
 
 
 def lists_from_dense(dense, n_nodes, nU):
@@ -418,8 +505,50 @@ class EnvMap:
         _abi.check(self._ctx, _abi.lib().mplx_expand_lists(self._ctx, nodes.ctypes.data, n, n, C.byref(s)))
         return out
 
-    def alloc_lists(self, n_nodes, want_state=True, want_iters=False, want_hash=True, stride=None):
-        return Lists(self, n_nodes, self.nU, want_state, want_iters, want_hash, stride)
+    def alloc_lists(self, n_nodes, want_state=True, want_iters=False, want_hash=True, stride=None, alloc=None):
+        return Lists(self, n_nodes, self.nU, want_state, want_iters, want_hash, stride, alloc)
+
+    def alloc_packed(self, n_nodes, capacity=None, want_state=True, want_hash=True, alloc=None):
+        """Packed lists for n_nodes nodes; the default capacity n_nodes * nU always suffices."""
+        return PackedLists(self, n_nodes, n_nodes * self.nU if capacity is None else capacity, want_state, want_hash, alloc)
+
+    def pack_lists(self, lists, packed, n_nodes=None, want_total=False):
+        """mplx_pack_lists_device: asynchronous unless want_total (then returns the number of packed entries)."""
+        n = lists.n_nodes if n_nodes is None else int(n_nodes)
+        s, p = lists.c_struct(), packed.c_struct()
+        total = C.c_int64(-1)
+        _abi.check(self._ctx, _abi.lib().mplx_pack_lists_device(self._ctx, C.byref(s), n, C.byref(p),
+                                                                 C.byref(total) if want_total else None))
+        return total.value if want_total else None
+
+    # ---- RCCL communicator of the context (mplx_comm_*)
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * _abi.COMM_ID_BYTES)()
+        rc = _abi.lib().mplx_comm_unique_id(buf)
+        if rc != _abi.OK:
+            msg = _abi.lib().mplx_last_error(None)
+            raise _abi.MplxError(rc, msg.decode() if msg else "?")
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * _abi.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _abi.check(self._ctx, _abi.lib().mplx_comm_init(self._ctx, buf, int(rank), int(world)))
+
+    def comm_destroy(self):
+        _abi.check(self._ctx, _abi.lib().mplx_comm_destroy(self._ctx))
+
+    def comm_broadcast_map(self, root=0):
+        _abi.check(self._ctx, _abi.lib().mplx_comm_broadcast_map(self._ctx, int(root)))
+
+    def comm_allgather_lists(self, local, n_local, gathered):
+        """mplx_comm_allgather_lists; returns (node_offs, entry_offs) per rank, each [world + 1]."""
+        a, b = local.c_struct(), gathered.c_struct()
+        no = np.zeros(1025, np.int64)
+        eo = np.zeros(1025, np.int64)
+        _abi.check(self._ctx, _abi.lib().mplx_comm_allgather_lists(self._ctx, C.byref(a), int(n_local), C.byref(b),
+                                                                    no.ctypes.data, eo.ctypes.data))
+        return no, eo
 
     def expand_lists_resident(self, frontier, lists, n_nodes=None):
         """Asynchronous launch on HBM-resident buffers (mplx_expand_lists_device)."""

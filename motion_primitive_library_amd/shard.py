@@ -1,15 +1,22 @@
 """Frontier sharding across GPUs.
 
-Every (node, control) pair is independent, so the frontier is block-partitioned
-by node, the map / U / parameters are replicated per rank, and the data path
-needs NO collective.  The optional all-gather below is for consumers that want
-the complete successor set on every rank (e.g. an on-device dedup / open-list
-merge stage): it exchanges compact records only -- (global slot, cost, hash) =
-24 B per *emitted* successor instead of the 129 B dense slot -- with one
-count exchange followed by one padded all_gather, which RCCL runs as direct
-peer-to-peer copies over xGMI (all links busy at once; a ring would be
-per-link bound).  Works with any torch.distributed backend (nccl on GPUs,
-gloo on CPU for the tests).
+Every (node, control) pair is independent (env_map<Dim>::get_succ, reference
+include/mpl_planner/env/env_map.h:147-172, reads nothing but its arguments), so
+the frontier is block-partitioned by node, the map / U / parameters are
+replicated per rank, and the expansion itself needs NO collective.
+
+The all-gather below is for consumers that want the complete successor set on
+every rank (an on-device dedup / open-list merge stage; north_star: "only when
+the open set exceeds a single GPU's launch").  It moves the successor LISTS in
+their packed form (mplx_pack_lists_device: node k owns entries
+[offs[k], offs[k+1]) of every row -- only emitted successors, no padding between
+nodes), device to device: one exchange of the (nodes, entries) pair of every
+rank, then one all_gather_into_tensor per row, padded to the largest rank and
+compacted on the device.  The tensors are the engine's own buffers (TorchArray
+hands torch-owned HBM to the C ABI through data_ptr), so nothing crosses the
+host.  Works with any torch.distributed backend: nccl (= RCCL over xGMI) on
+GPUs, gloo on CPU for the tests.  A C host uses mplx_comm_allgather_lists
+(include/mplx.h), which does the same with exact-size all-pairs ncclSend/Recv.
 """
 import numpy as np
 
@@ -24,39 +31,97 @@ def partition(n_nodes, world, rank):
     return lo, hi
 
 
-def compact_records(status, cost, hash_, node_offset, nU):
-    """Dense slots of one shard -> compact records of the emitted successors
-    (status FINITE or BLOCKED, as the reference returns them), with GLOBAL slot
-    ids (global node index * nU + control)."""
-    status = np.asarray(status)
-    keep = np.nonzero((status == 1) | (status == 2))[0]
-    gslot = keep.astype(np.int64) + np.int64(node_offset) * np.int64(nU)
-    return gslot, np.asarray(cost)[keep], np.asarray(hash_)[keep].astype(np.int64)
+class TorchArray:
+    """Memory owned by a torch tensor (HBM on a GPU rank, host memory under gloo) with the interface the engine
+    expects of a DeviceArray (.ptr, .nbytes, .download, .free): lets torch.distributed move the very buffers the
+    kernels wrote."""
+
+    def __init__(self, nbytes, device):
+        import torch
+
+        self.nbytes = int(nbytes)
+        self.t = torch.zeros((self.nbytes + 7) // 8 + 1, dtype=torch.int64, device=device)
+        self.ptr = self.t.data_ptr()
+
+    def view(self, dtype, n=None, offset=0):
+        """The first n elements of `dtype` starting `offset` bytes in, as a tensor sharing the memory."""
+        import torch
+
+        raw = self.t.view(torch.uint8)[int(offset):self.nbytes]
+        v = raw[: (raw.numel() // dtype.itemsize) * dtype.itemsize].view(dtype)
+        return v if n is None else v[: int(n)]
+
+    def download(self, dtype, shape, offset=0):
+        import torch
+
+        td = {np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.float64): torch.float64,
+              np.dtype(np.uint64): torch.int64, np.dtype(np.uint8): torch.uint8}[np.dtype(dtype)]
+        n = int(np.prod(shape))
+        out = self.view(td, n, offset).cpu().numpy()
+        return out.view(dtype).reshape(shape).copy()
+
+    def free(self):
+        self.t = None
+        self.ptr = None
 
 
-def all_gather_records(gslot, cost, hash_, device=None):
-    """All-gather variable-length compact records from every rank.  Returns the
-    concatenation ordered by rank (= ascending global slot for a block
-    partition).  Needs an initialised torch.distributed process group."""
+def torch_alloc(device):
+    """`alloc` argument of EnvMap.alloc_lists / alloc_packed: buffers owned by torch on `device`."""
+    return lambda nbytes: TorchArray(nbytes, device)
+
+
+def all_gather_packed(count, offs, rows, n_local, group=None):
+    """All-gather of packed successor lists, device to device.
+
+    count : int32 tensor [>= n_local]   per-node counts of this rank's shard
+    offs  : int64 tensor [>= n_local+1] their exclusive prefix sums (offs[n_local] = entries of this rank)
+    rows  : dict name -> tensor; 1-D rows are [capacity], a 2-D row (the state) is [F, capacity]
+    Returns (count_all, offs_all, rows_all, node_offs, entry_offs): the concatenation in rank order (= ascending
+    global node index for the block partition); node_offs / entry_offs are the per-rank offsets, [world + 1].
+    Needs an initialised torch.distributed process group; every tensor lives on the backend's device.
+    """
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size()
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    n = torch.tensor([gslot.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
-    cap = max(max(counts), 1)
-    # one [cap, 3] int64 payload per rank: slot, cost bits, hash bits
-    pay = torch.zeros((cap, 3), dtype=torch.int64, device=dev)
-    if gslot.shape[0]:
-        pay[: gslot.shape[0], 0] = torch.as_tensor(np.ascontiguousarray(gslot), device=dev)
-        pay[: gslot.shape[0], 1] = torch.as_tensor(np.ascontiguousarray(cost).view(np.int64), device=dev)
-        pay[: gslot.shape[0], 2] = torch.as_tensor(np.ascontiguousarray(hash_).view(np.int64), device=dev)
-    out = torch.empty((world * cap, 3), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(out, pay)
-    out = out.cpu().numpy().reshape(world, cap, 3)
-    parts = [out[r, : counts[r]] for r in range(world)]
-    allp = np.concatenate(parts, axis=0) if parts else np.zeros((0, 3), np.int64)
-    return allp[:, 0].copy(), allp[:, 1].copy().view(np.float64), allp[:, 2].copy().view(np.uint64)
+    world = dist.get_world_size(group)
+    dev = count.device
+    total = offs[n_local:n_local + 1]  # stays on the device
+    meta = torch.cat([torch.tensor([n_local], dtype=torch.int64, device=dev), total.to(torch.int64)])
+    metas = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(metas, meta, group=group)
+    m = metas.cpu().numpy().reshape(world, 2)  # the one host round trip: sizes
+    node_offs = np.concatenate([[0], np.cumsum(m[:, 0])]).astype(np.int64)
+    entry_offs = np.concatenate([[0], np.cumsum(m[:, 1])]).astype(np.int64)
+    cap_n, cap_e = max(int(m[:, 0].max()), 1), max(int(m[:, 1].max()), 1)
+
+    def gather(x, cap, sizes):
+        """x: [..., >= own size] -> concatenation over ranks of x[..., :size_r]."""
+        lead = x.shape[:-1]
+        if x.dim() == 1 and x.shape[0] >= cap:
+            own = x[:cap]  # a contiguous prefix of the engine's own buffer: no staging copy
+        else:
+            own = torch.zeros(lead + (cap,), dtype=x.dtype, device=dev)
+            k = min(cap, x.shape[-1])
+            own[..., :k] = x[..., :k]
+        out = torch.empty((world,) + lead + (cap,), dtype=x.dtype, device=dev)
+        dist.all_gather_into_tensor(out.view(-1), own.view(-1), group=group)
+        return torch.cat([out[r][..., : int(sizes[r])] for r in range(world)], dim=-1)
+
+    count_all = gather(count, cap_n, m[:, 0])
+    rows_all = {k: gather(v, cap_e, m[:, 1]) for k, v in rows.items() if v is not None}
+    offs_all = torch.zeros(int(node_offs[-1]) + 1, dtype=torch.int64, device=dev)
+    offs_all[1:] = torch.cumsum(count_all.to(torch.int64), dim=0)
+    return count_all, offs_all, rows_all, node_offs, entry_offs
+
+
+def packed_views(packed, n_local, total=None):
+    """Tensor views of an env.PackedLists whose buffers are TorchArrays (for all_gather_packed)."""
+    import torch
+
+    cap = packed.capacity if total is None else int(total)
+    rows = {"action": packed.action.view(torch.int32, cap), "cost": packed.cost.view(torch.float64, cap)}
+    if packed.hash is not None:
+        rows["hash"] = packed.hash.view(torch.int64, cap)
+    if packed.state is not None:
+        rows["state"] = packed.state.view(torch.float64, packed.n_fields * packed.capacity).view(packed.n_fields, packed.capacity)[:, :cap]
+    return packed.count.view(torch.int32, max(n_local, 1))[:n_local], packed.offs.view(torch.int64, n_local + 1), rows

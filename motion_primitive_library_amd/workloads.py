@@ -207,9 +207,32 @@ class Workload:
         env.set_search_region(self.region)
 
 
-def make(name, scale=1.0, n_nodes=None):
+def device_potential_fn(device=0, stats=None):
+    """potential_fn for make("C5"): the potential map is produced by the engine's own reference-semantics
+    MapPlanner::updatePotentialMap on the MI355X (mplx_update_potential_map, SURVEY.md 8f-3 -> 8d's C5: "256^3 as C3
+    then reference-semantics updatePotentialMap").  stats (a dict) receives the wall time of the call."""
+    import time
+
+    def fn(grid, origin, res, radius):
+        from .env import EnvMap
+        dim = grid.ndim
+        env = EnvMap(dim, device)
+        env.setMap(origin, list(reversed(grid.shape)), grid, res)
+        t0 = time.perf_counter()
+        out = env.updatePotentialMap([0.0] * dim, radius, None, 1.0)
+        if stats is not None:
+            stats["potential_map_ms"] = (time.perf_counter() - t0) * 1e3
+        env.close()
+        return out.reshape(grid.shape)
+
+    return fn
+
+
+def make(name, scale=1.0, n_nodes=None, potential_fn=None):
     """Build configuration `name` in {"C2","C3","C4","C5"}.  `scale` < 1
-    shrinks the map edge (tests); n_nodes overrides the frontier size."""
+    shrinks the map edge (tests); n_nodes overrides the frontier size.
+    potential_fn(grid, origin, res, radius) -> int8 map builds C5's potential map (device_potential_fn: on the
+    GPU); the default is the numpy restatement potential_field (33 s at 256^3: the checker of the device path)."""
     if name == "C2":
         edge = max(32, int(1024 * scale))
         grid = box_map([edge, edge], 0.1, 0.20, 1002)
@@ -231,7 +254,8 @@ def make(name, scale=1.0, n_nodes=None):
     if name == "C5":
         edge = max(16, int(256 * scale))
         grid = box_map([edge] * 3, 0.1, 0.15, 1005)
-        pot = potential_field(grid, 0.1, 1.0, 1.0)
+        pot = (potential_field(grid, 0.1, 1.0, 1.0) if potential_fn is None
+               else np.ascontiguousarray(potential_fn(grid, [0, 0, 0], 0.1, [1.0, 1.0, 1.0]), dtype=np.int8))
         U = grid_controls([-1, 0, 1], 3, yaw_rates=[-0.5, 0, 0.5])
         nodes = random_frontier(pot, [0, 0, 0], 0.1, n_nodes or 32768, 2005, ACCxYAW, 2.0, 0.5)
         return Workload("C5", 3, ACCxYAW, pot, [0, 0, 0], 0.1, U, nodes,

@@ -1,5 +1,6 @@
 """CPU, world_size = 2 over gloo: the multi-GPU sharding logic (partition +
-optional all-gather of compact successor records).  The per-rank expansion is
+optional all-gather of the packed successor LISTS -- count, action, cost, hash
+and the full Waypoint of every emitted successor).  The per-rank expansion is
 done by the CPU oracle here (test stand-in for the engine: no GPU in this
 container); what is under test is that sharding + gather reproduces the
 single-process result exactly."""
@@ -29,24 +30,41 @@ def test_partition_covers_frontier_exactly():
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
     import torch.distributed as dist
     from helpers import oracle_env
     from oracle import oracle as O
     import motion_primitive_library_amd.workloads as W
-    from motion_primitive_library_amd.shard import all_gather_records, compact_records, partition
+    from motion_primitive_library_amd.env import lists_from_dense, pack_host_lists
+    from motion_primitive_library_amd.shard import all_gather_packed, partition
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     wl = W.make("C4", scale=0.125, n_nodes=37)  # deliberately not divisible by the world size
+    nU = wl.U.shape[0]
     lo, hi = partition(wl.n_nodes, world, rank)
     shard = np.ascontiguousarray(wl.nodes[:, lo:hi])
-    r = O.expand(oracle_env(wl), shard, want_state=False)
-    gs, c, h = compact_records(r["status"], r["cost"], r["hash"], lo, wl.U.shape[0])
-    gs, c, h = all_gather_records(gs, c, h)
+    # the per-rank expansion: the CPU oracle stands in for the engine (no GPU here); its dense slots are put in
+    # the engine's list layout and packed the way mplx_pack_lists_device packs them
+    r = O.expand(oracle_env(wl), shard, want_state=True)
+    lists = lists_from_dense(r, hi - lo, nU)
+    lists["stride"] = nU
+    p = pack_host_lists(lists, hi - lo)
+    cap = (hi - lo + 1) * nU  # the capacity a rank allocates without knowing the others' totals
+
+    def padded(a):
+        out = np.zeros(a.shape[:-1] + (cap,), a.dtype)
+        out[..., : a.shape[-1]] = a
+        return torch.from_numpy(out)
+
+    rows = {"action": padded(p["action"]), "cost": padded(p["cost"]), "hash": padded(p["hash"].view(np.int64)),
+            "state": padded(p["state"])}
+    cnt, offs, rows_all, noff, eoff = all_gather_packed(torch.from_numpy(p["count"]), torch.from_numpy(p["offs"]), rows,
+                                                        hi - lo)
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, gs, c, h))
+    q.put((rank, cnt.numpy(), offs.numpy(), {k: v.numpy() for k, v in rows_all.items()}, noff, eoff))
 
 
 def test_two_rank_shard_and_gather_matches_single_process():
@@ -54,7 +72,8 @@ def test_two_rank_shard_and_gather_matches_single_process():
     from helpers import oracle_env
     from oracle import oracle as O
     import motion_primitive_library_amd.workloads as W
-    from motion_primitive_library_amd.shard import compact_records
+    from motion_primitive_library_amd.env import lists_from_dense, pack_host_lists
+    from motion_primitive_library_amd.shard import partition
 
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -70,9 +89,28 @@ def test_two_rank_shard_and_gather_matches_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     wl = W.make("C4", scale=0.125, n_nodes=37)
-    full = O.expand(oracle_env(wl), wl.nodes, want_state=False)
-    gs, c, h = compact_records(full["status"], full["cost"], full["hash"], 0, wl.U.shape[0])
-    assert gs.size > 1000
-    for rank, g2, c2, h2 in got:  # every rank holds the complete, identically ordered set
-        assert np.array_equal(g2, gs) and np.array_equal(h2, h.view(np.uint64))
-        assert np.array_equal(c2.view(np.int64), c.view(np.int64))
+    nU = wl.U.shape[0]
+    full = O.expand(oracle_env(wl), wl.nodes, want_state=True)
+    lists = lists_from_dense(full, wl.n_nodes, nU)
+    lists["stride"] = nU
+    want = pack_host_lists(lists, wl.n_nodes)
+    assert want["total"] > 1000
+    for rank, cnt, offs, rows, noff, eoff in got:  # every rank holds the complete, identically ordered lists
+        assert np.array_equal(cnt, want["count"]) and np.array_equal(offs, want["offs"])
+        assert noff.tolist() == [0] + [partition(wl.n_nodes, 2, r)[1] for r in range(2)]
+        assert eoff[-1] == want["total"] and eoff[1] == want["offs"][noff[1]]
+        assert np.array_equal(rows["action"], want["action"])
+        assert np.array_equal(rows["hash"].view(np.uint64), want["hash"])
+        assert np.array_equal(rows["cost"].view(np.int64), want["cost"].view(np.int64))
+        assert np.array_equal(rows["state"].view(np.int64), want["state"].view(np.int64))
+
+
+def test_pack_host_lists_is_the_used_prefixes_in_order():
+    from motion_primitive_library_amd.env import pack_host_lists
+    lists = {"stride": 4, "count": np.array([2, 0, 3], np.int32), "action": np.arange(12, dtype=np.int32),
+             "cost": np.arange(12, dtype=np.float64), "hash": np.arange(12, dtype=np.uint64),
+             "state": np.arange(24, dtype=np.float64).reshape(2, 12)}
+    p = pack_host_lists(lists, 3)
+    assert p["offs"].tolist() == [0, 2, 2, 5] and p["total"] == 5
+    assert p["action"].tolist() == [0, 1, 8, 9, 10]
+    assert p["state"].tolist() == [[0, 1, 8, 9, 10], [12, 13, 20, 21, 22]]
