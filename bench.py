@@ -325,6 +325,13 @@ def main():
                          "an eps = 0 search from the map centre (realistic locality; also reported as an extra)")
     args = ap.parse_args()
 
+    verbose = os.environ.get("MPLX_BENCH_VERBOSE") == "1"
+
+    def note(msg):
+        if verbose:
+            print("[bench %.1fs] %s" % (time.time() - t_start, msg), file=sys.stderr, flush=True)
+
+    t_start = time.time()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -396,9 +403,11 @@ def main():
             el = float(t.item())
         return el, kernel_ms_total / steps
 
+    note("workload ready, %d of %d nodes on this rank" % (n_loc, N))
     for _ in range(args.warmup):
         launch()
     elapsed, kernel_ms = timed(launch, args.steps)
+    note("timed region done: %.3f ms per step" % (elapsed / args.steps * 1e3))
     route = env.last_lists_route()
 
     # ---- parity of the TIMED output: the lists the timed launches wrote, against the oracle
@@ -419,6 +428,7 @@ def main():
                 "kernel_ms_rank0": k_w, "frontier_nodes_per_gpu": N, "scaling": "weak"}
         sw.free()
         fw.free()
+        note("weak leg done")
         # ---- the optional all-gather of the successor lists (packed on the device, moved by RCCL)
         try:
             packed = env.alloc_packed(n_loc, capacity=(n_loc + 1) * nU, want_state=True, alloc=alloc)
@@ -453,6 +463,7 @@ def main():
             packed.free()
         except Exception as e:  # noqa: BLE001 -- never lose the headline to the optional exchange
             gather = {"error": "%s: %s" % (type(e).__name__, e)}
+        note("gather leg done: %s" % (gather,))
         # global work of the strong-scaling step, for the record
         tot = torch.tensor([n_emit, n_samples], dtype=torch.float64, device="cuda")
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)

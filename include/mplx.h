@@ -406,6 +406,14 @@ int mplx_selftest_forward_state(int32_t dim, int32_t control, const double *node
  * 3 sin(a), 4 round(a), 5 ceil(a).  Host pointers, n elements.               */
 int mplx_selftest_math(mplx_ctx *ctx, int op, const double *a, const double *b, double *out,
                        int64_t n);
+/* Yaw controls: validate_yaw (primitive.h:504-525) compares with cos(yaw_max) and the reference's cos / sin are the
+ * host libm's, the device's differ from them in the last place on a few per cent of arguments.  The engine therefore
+ * flags every node with a heading-limit decision within rounding noise (2^-46) of its threshold and re-expands exactly
+ * those nodes with trig values the HOST computes with its libm, at the next synchronising call (mplx_synchronize,
+ * mplx_timer_end, mplx_memcpy_d2h, any host-pointer entry point): the successor SET is the reference's for every input,
+ * not only for the tested ones.  The results of an asynchronous *_device launch are final after such a call.
+ * Statistics since mplx_create: nodes flagged, fix passes launched (both 0 on the BASELINE configurations).        */
+int mplx_yaw_pin_stats(const mplx_ctx *ctx, int64_t *flagged_nodes, int64_t *fix_passes);
 /* Which kernel serves mplx_expand_lists*: AUTO picks the fastest one that
  * covers the configuration (GRID: controls with <= 16 distinct values per axis,
  * no yaw, no potential, bounded velocity; TILE: any control table, otherwise the

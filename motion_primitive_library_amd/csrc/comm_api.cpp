@@ -49,10 +49,17 @@ Rccl &rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // A process that already has an RCCL (PyTorch-ROCm ships its own librccl.so) must keep using that one: two
+    // RCCL builds in one process corrupt each other's state.  So first look for a loaded copy, then load ROCm's.
+    for (const char *name : {"librccl.so", "librccl.so.1"}) {
+      r.h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
       if (r.h) break;
     }
+    if (!r.h)
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.h) break;
+      }
     if (!r.h) { r.err = std::string("cannot load librccl.so.1: ") + dlerror(); return; }
     auto sym = [&](const char *n) {
       void *p = dlsym(r.h, n);
@@ -169,6 +176,7 @@ int mplx_comm_allgather_lists(mplx_ctx *c, const mplx_packed_lists *loc, int64_t
     return fail(c, MPLX_ERR_ARG, "mplx_comm_allgather_lists: a gathered row is requested that the local side lacks");
   MPLX_GUARD_BEGIN
   if (int rc = bind_device(c)) return rc;
+  if (int rc = resolve_pending(c)) return rc;
   ncclComm_t comm = (ncclComm_t)c->comm;
   const int G = c->comm_world, me = c->comm_rank, F = 4 * c->dim + 2;
   // ---- (n_local, total) of every rank

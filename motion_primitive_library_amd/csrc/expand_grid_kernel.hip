@@ -285,20 +285,27 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   }
   __syncthreads();  // the only workgroup barrier
 
-  const double cos_lim = (YAW && A.yaw_max > 0) ? cos(A.yaw_max) : 0.0;  // primitive.h:521
+  // primitive.h:521; in the override pass the host libm's value (see YawPin in mplx_internal.h)
+  const bool pinned = YAW && A.yaw.tab != nullptr;
+  const double cos_lim = (YAW && A.yaw_max > 0) ? (pinned ? A.yaw.cos_lim : cos(A.yaw_max)) : 0.0;
   const int64_t wave_id = (int64_t)blockIdx.x * kWPB + wv;
   const int64_t wave_stride = (int64_t)gridDim.x * kWPB;
+  // the override pass of the yaw pinning walks a list of nodes; everything else the whole frontier in order
+  auto node_of = [&](int64_t it) -> int64_t { return (YAW && A.yaw.node_list) ? (int64_t)A.yaw.node_list[it] : it; };
   double nxt = 0.0;  // lanes < F: one field of the next node (prefetched)
-  if (wave_id < A.n_nodes && lane < F) nxt = A.nodes[(int64_t)lane * A.node_stride + wave_id];
+  if (wave_id < A.n_nodes && lane < F) nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(wave_id)];
   asm volatile("" ::"v"(nxt));  // arrived before the loop: no wait for it at the loop head (see the pin after phase A)
 
-  for (int64_t node = wave_id; node < A.n_nodes; node += wave_stride) {
+  for (int64_t it = wave_id; it < A.n_nodes; it += wave_stride) {
+    const int64_t node = node_of(it);
+    const double *ytab = pinned ? A.yaw.tab + it * A.yaw.tab_stride : nullptr;  // [c0, s0, cT[16], sT[16]]
+    bool yaw_amb = false;  // a heading-limit decision of this node is within rounding noise of the threshold
     // ---- phase 0: node state into LDS, prefetch of the next node
     wave_prio(0);
     wave_sync();
     if (lane < F) s_node[lane] = nxt;
-    if (node + wave_stride < A.n_nodes && lane < F)
-      nxt = A.nodes[(int64_t)lane * A.node_stride + node + wave_stride];
+    if (it + wave_stride < A.n_nodes && lane < F)
+      nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(it + wave_stride)];
     if (lane < 2) s_misc[M_NMASK + lane] = 0;
     wave_sync();
 
@@ -309,12 +316,16 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       bool dead = false;
       if (vx0 != 0 || vy0 != 0) {
         double c0, s0;
-        sincos(wrap_angle((0.0 + 0.0) + s_node[4 * D]), &s0, &c0);
+        const double y0 = wrap_angle((0.0 + 0.0) + s_node[4 * D]);
+        if (pinned) { c0 = ytab[0]; s0 = ytab[1]; } else sincos(y0, &s0, &c0);
         const double sn = sqrt(vx0 * vx0 + vy0 * vy0);
-        dead = vx0 / sn * c0 + vy0 / sn * s0 < cos_lim;
+        const double d = vx0 / sn * c0 + vy0 / sn * s0;
+        dead = d < cos_lim;
+        yaw_amb = near_limit(d, cos_lim, A.yaw.margin, vy0, y0, A.yaw_max);
       }
       if (dead) {  // uniform
         if (lane == 0 && A.l_count) A.l_count[node] = 0;
+        if (lane == 0 && yaw_amb && A.yaw.amb) flag_node(A.yaw.amb, A.yaw.amb_cap, node);
         continue;
       }
     }
@@ -395,7 +406,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         s_yq[lane] = quantise(yT, 0.1, A.R01);
         if (A.yaw_max > 0) {
           double sn_, cs_;
-          sincos(yT, &sn_, &cs_);  // same values as cos() / sin() (one argument reduction instead of two)
+          if (pinned) { cs_ = ytab[2 + lane]; sn_ = ytab[2 + 16 + lane]; }
+          else sincos(yT, &sn_, &cs_);  // same values as cos() / sin() (one argument reduction instead of two)
           s_ycs[lane * 2 + 0] = cs_;
           s_ycs[lane * 2 + 1] = sn_;
         }
@@ -440,7 +452,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       const bool lim = A.yaw_max > 0;
       const double y0 = wrap_angle((0.0 + 0.0) + s_node[4 * D]);  // yaw polynomial at t = 0: (0.0 + u_yaw * 0.0) + yaw
       double c0 = 0.0, s0 = 0.0;
-      if (lim) sincos(y0, &s0, &c0);
+      if (lim) { if (pinned) { c0 = ytab[0]; s0 = ytab[1]; } else sincos(y0, &s0, &c0); }
       const float inv_n1 = 1.0f / (float)nd[1];
       for (int x = lane; x < nd[0] * nd[1]; x += 64) {
         const int j0 = (int)(((float)x + 0.5f) * inv_n1), j1 = x - j0 * nd[1];
@@ -454,6 +466,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
             const double sn = sqrt(vx0 * vx0 + vy0 * vy0);
             const double d = vx0 / sn * c0 + vy0 / sn * s0;
             if (d < cos_lim) mask = 0;
+            yaw_amb = yaw_amb || near_limit(d, cos_lim, A.yaw.margin, vy0, y0, A.yaw_max);
           }
           const double vxT = qx.template vel<true>(T), vyT = qy.template vel<true>(T);
           if (vxT != 0 || vyT != 0) {
@@ -462,11 +475,13 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
             for (int jy = 0; jy < ndy; jy++) {
               const double d = nx * s_ycs[jy * 2] + ny * s_ycs[jy * 2 + 1];
               if (d < cos_lim) mask &= ~(1u << jy);
+              yaw_amb = yaw_amb || near_limit(d, cos_lim, A.yaw.margin, vyT, s_yawT[jy], A.yaw_max);
             }
           }
         }
         s_hmask[j0 * ndp + j1] = (unsigned short)mask;
       }
+      if (A.yaw.amb && __ballot(yaw_amb) != 0ull && lane == 0) flag_node(A.yaw.amb, A.yaw.amb_cap, node);
     }
     wave_sync();
 

@@ -26,6 +26,7 @@
 // and for a forward primitive of control order K (1 VEL, 2 ACC, 3 JRK, 4 SNP)
 // only c[5-K] .. c5 are non-zero: c5 = pos, c4 = vel (or u for K = 1), ...
 #include "mplx_internal.h"
+#include "mplx_device_common.h"  // near_limit / flag_node of the yaw pinning
 
 #include <math.h>
 
@@ -205,11 +206,15 @@ struct Axis {
   }
 };
 
-// primitive.h:504-525, one end of the primitive
-__device__ __forceinline__ bool heading_ok(double vx, double vy, double yaw, double cos_lim) {
+// primitive.h:504-525, one end of the primitive.  cs: the host libm's {cos(yaw), sin(yaw)} in the override pass of
+// the yaw pinning (YawPin, mplx_internal.h), else null; *amb: the decision is within `margin` of the threshold.
+__device__ __forceinline__ bool heading_ok(double vx, double vy, double yaw, double cos_lim, const double *cs,
+                                           double margin, double yaw_max, bool *amb) {
   if (vx != 0 || vy != 0) {
     const double s = sqrt(vx * vx + vy * vy);
-    const double d = vx / s * cos(yaw) + vy / s * sin(yaw);
+    const double c = cs ? cs[0] : cos(yaw), sn = cs ? cs[1] : sin(yaw);
+    const double d = vx / s * c + vy / s * sn;
+    *amb = *amb || mplx::dev::near_limit(d, cos_lim, margin, vy, yaw, yaw_max);
     if (d < cos_lim) return false;
   }
   return true;
@@ -221,8 +226,9 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs A) {
   const int64_t n_slots = A.n_nodes * (int64_t)A.nU;
   const int64_t slot = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (slot >= n_slots) return;
-  const int64_t node = slot / A.nU;
-  const int ci = (int)(slot - node * A.nU);
+  const int64_t it = slot / A.nU;  // position in the launch; the override pass of the yaw pinning walks a node list
+  const int ci = (int)(slot - it * A.nU);
+  const int64_t node = (YAW && A.yaw.node_list) ? (int64_t)A.yaw.node_list[it] : it;
 
   // ---- load the node (broadcast within the wave) and the control (coalesced)
   const double *nd = A.nodes + node;
@@ -271,11 +277,19 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs A) {
   }
   bool valid = true;
   if (YAW && A.yaw_max > 0) {
-    const double cos_lim = cos(A.yaw_max);
+    // override pass (YawPin): per listed node {cos, sin} of yaw(0), then of yaw(T) for every control, and cos(yaw_max),
+    // all from the host libm
+    const double *tab = A.yaw.tab ? A.yaw.tab + it * A.yaw.tab_stride : nullptr;
+    const double cos_lim = tab ? A.yaw.cos_lim : cos(A.yaw_max);
     // evaluate(0): vel = 0.0 + c4 terms, yaw = wrap(0.0 + uyaw*0 + yaw)
     const double y0 = wrap_angle((0.0 + uyaw * 0.0) + cyaw);
-    valid = heading_ok(ax[0].template vel<true>(0.0), ax[1].template vel<true>(0.0), y0, cos_lim) &&
-            heading_ok(nvel[0], nvel[1], nyaw, cos_lim);
+    bool amb = false;
+    const bool ok0 = heading_ok(ax[0].template vel<true>(0.0), ax[1].template vel<true>(0.0), y0, cos_lim,
+                                tab ? tab : nullptr, A.yaw.margin, A.yaw_max, &amb);
+    const bool okT = heading_ok(nvel[0], nvel[1], nyaw, cos_lim, tab ? tab + 2 + 2 * ci : nullptr, A.yaw.margin,
+                                A.yaw_max, &amb);
+    valid = ok0 && okT;
+    if (amb && A.yaw.amb) mplx::dev::flag_node(A.yaw.amb, A.yaw.amb_cap, node);
   }
   if (K >= 2 && A.v_max > 0) {
 #pragma unroll
@@ -372,12 +386,13 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs A) {
   // ---- dense, coalesced slot writes
   // final outputs stream past L2 (never re-read by this kernel); scratch for the compaction stays cached
   const bool stream = A.stream_out != 0;
-  if (A.status) st_out(&A.status[slot], st, stream);
-  if (A.cost) st_out(&A.cost[slot], cost, stream);
-  if (A.hash) st_out(&A.hash[slot], h_next, stream);
-  if (A.iters) st_out(&A.iters[slot], iters, stream);
+  const int64_t oslot = node * A.nU + ci;  // == slot except in the override pass of the yaw pinning
+  if (A.status) st_out(&A.status[oslot], st, stream);
+  if (A.cost) st_out(&A.cost[oslot], cost, stream);
+  if (A.hash) st_out(&A.hash[oslot], h_next, stream);
+  if (A.iters) st_out(&A.iters[oslot], iters, stream);
   if (A.state) {
-    double *o = A.state + slot;
+    double *o = A.state + oslot;
     const int64_t ss = A.state_stride;
 #pragma unroll
     for (int i = 0; i < D; i++) {

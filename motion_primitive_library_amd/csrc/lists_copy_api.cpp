@@ -268,6 +268,7 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
     d.node_stride = S;
     if (int rc = lists_on_device(c, (const double *)hb, n_nodes, n_nodes, &d)) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rc = resolve_pending(c)) return rc;  // yaw pinning: lists final before the search reads them
     int64_t *offs = (int64_t *)(hb + o_off);
     for (int64_t k = 0; k <= n_nodes; k++) offs[k] = k * S;
     *out = PackedLists{};
@@ -311,6 +312,7 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
   if (want_state) { d.state = (double *)c->s_state.p; d.state_stride = n_slots; }
   d.node_stride = S;
   if (int rc = lists_on_device(c, (const double *)c->s_nodes.p, n_nodes, n_nodes, &d)) return rc;
+  if (int rc = resolve_pending(c)) return rc;  // yaw pinning: lists final before they are packed
   int32_t *cnt = (int32_t *)(hb + o_cnt);
   int64_t *offs = (int64_t *)(hb + o_off);
   HIP_TRY(c, hipMemcpyAsync(cnt, d.count, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, c->stream));

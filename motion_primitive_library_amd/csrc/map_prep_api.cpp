@@ -27,6 +27,7 @@ int mplx_update_potential_map(mplx_ctx *c, const double *pos, const double *radi
   if (!c->has_map) return fail(c, MPLX_ERR_STATE, "mplx_update_potential_map: set the map first");
   if (!(pow_ > 0)) return fail(c, MPLX_ERR_ARG, "mplx_update_potential_map: pow must be > 0 (the field must not grow with distance)");
   if (int rc = bind_device(c)) return rc;
+  if (int rc = resolve_pending(c)) return rc;
   const int D = c->dim;
   const double res = c->res;
   const int8_t H_MAX = 100;  // map_planner.h:104
@@ -94,6 +95,7 @@ int mplx_set_search_region_path(mplx_ctx *c, const double *path, int32_t n_point
     return fail(c, MPLX_ERR_ARG, "mplx_set_search_region_path: bad arguments");
   if (!c->has_map) return fail(c, MPLX_ERR_STATE, "mplx_set_search_region_path: set the map first");
   if (int rc = bind_device(c)) return rc;
+  if (int rc = resolve_pending(c)) return rc;
   const int D = c->dim;
   const double res = c->res;
   auto to_cell = [&](const double *pt) {

@@ -7,6 +7,7 @@
 // entry either runs the gfx950 kernels or returns an error.
 #include "mplx_ctx.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -26,6 +27,8 @@ std::string &create_error() {
 }  // namespace mplx_detail
 
 namespace {
+
+int yaw_slot(mplx_ctx *c, mplx::YawPin *y);  // yaw pinning, defined with the lists route below
 
 bool control_ok(int32_t control) {
   switch (control) {
@@ -119,6 +122,8 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
     c->tune.no_sat = getenv("MPLX_GRID_NOSAT") != nullptr;
     c->tune.no_lex = getenv("MPLX_GRID_NOLEX") != nullptr;
     c->tune.no_line_pad = getenv("MPLX_NO_LINE_PAD") != nullptr;
+    c->tune.yaw_pin = !(getenv("MPLX_YAW_PIN") && atoi(getenv("MPLX_YAW_PIN")) == 0);
+    c->tune.yaw_margin = getenv("MPLX_YAW_MARGIN") ? atof(getenv("MPLX_YAW_MARGIN")) : 0.0;
   }
   *out = c;
   return MPLX_OK;
@@ -134,6 +139,8 @@ void mplx_destroy(mplx_ctx *c) {
     release(*b);
   (void)mplx_comm_destroy(c);
   release(c->comm_meta);
+  c->yaw_pending.clear();
+  for (DevBuf *b : {&c->yaw_ring, &c->yaw_ids, &c->yaw_tab}) release(*b);
   mplx_detail::release_copy_buffers(c);
   release(c->s_arena);
   if (c->h_arena) (void)hipHostFree(c->h_arena);
@@ -156,6 +163,7 @@ int mplx_set_map(mplx_ctx *c, const int8_t *cells, const int32_t *dim, const dou
     return fail(c, MPLX_ERR_ARG, "mplx_set_map: %lld cells exceed the reference's int cell index",
                 (long long)n);
   if (int rc = bind_device(c)) return rc;
+  if (int rc = resolve_pending(c)) return rc;  // a pending launch read the old map
   {  // a different grid (size, shape, origin or resolution) invalidates potential and region
     bool same = n == c->n_cells && res == c->res;
     for (int i = 0; i < c->dim; i++) same = same && dim[i] == c->mdim[i] && origin[i] == c->origin[i];
@@ -180,6 +188,7 @@ int mplx_set_map(mplx_ctx *c, const int8_t *cells, const int32_t *dim, const dou
 
 int mplx_set_potential(mplx_ctx *c, const int8_t *cells) {
   if (!c) return MPLX_ERR_ARG;
+  if (int rc = resolve_pending(c)) return rc;
   if (!cells) { c->blk_ok = c->blk_ok && !c->has_pot; c->has_pot = false; return MPLX_OK; }
   if (!c->has_map) return fail(c, MPLX_ERR_STATE, "mplx_set_potential: set the map first");
   if (int rc = bind_device(c)) return rc;
@@ -193,6 +202,7 @@ int mplx_set_potential(mplx_ctx *c, const int8_t *cells) {
 
 int mplx_set_region(mplx_ctx *c, const uint8_t *cells) {
   if (!c) return MPLX_ERR_ARG;
+  if (int rc = resolve_pending(c)) return rc;
   if (!cells) { c->blk_ok = c->blk_ok && !c->has_region; c->has_region = false; return MPLX_OK; }
   if (!c->has_map) return fail(c, MPLX_ERR_STATE, "mplx_set_region: set the map first");
   if (int rc = bind_device(c)) return rc;
@@ -213,6 +223,7 @@ int mplx_set_params(mplx_ctx *c, const mplx_params *p) {
   if (!p) return fail(c, MPLX_ERR_ARG, "mplx_set_params: NULL");
   if (!control_ok(p->control)) return fail(c, MPLX_ERR_ARG, "mplx_set_params: unknown control flag 0x%x", p->control);
   if (!(p->dt > 0)) return fail(c, MPLX_ERR_ARG, "mplx_set_params: dt must be > 0");
+  if (int rc = resolve_pending(c)) return rc;
   c->prm = *p;
   c->has_params = true;
   return MPLX_OK;
@@ -224,12 +235,14 @@ int mplx_set_controls(mplx_ctx *c, const double *U, int32_t nU, int32_t udim) {
     return fail(c, MPLX_ERR_ARG, "mplx_set_controls: need U != NULL, nU > 0, udim in {%d,%d}", c->dim, c->dim + 1);
   MPLX_GUARD_BEGIN
   if (int rc = bind_device(c)) return rc;
+  if (int rc = resolve_pending(c)) return rc;
   const size_t bytes = (size_t)nU * udim * sizeof(double);
   if (int rc = ensure(c, c->U, bytes)) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->U.p, U, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->nU = nU;
   c->udim = udim;
+  c->h_U.assign(U, U + (size_t)nU * udim);
   c->u_absmax = 0;
   for (int32_t i = 0; i < nU; i++)
     for (int k = 0; k < c->dim; k++) {
@@ -275,6 +288,7 @@ int mplx_set_controls(mplx_ctx *c, const double *U, int32_t nU, int32_t udim) {
         c->u_lex = want == packed[(size_t)i];
       }
     }
+    std::memcpy(c->h_uyaw, vals[3], sizeof c->h_uyaw);
     if (int rc = ensure(c, c->uvals, sizeof vals)) return rc;
     if (int rc = ensure(c, c->uidx, (size_t)nU * 4)) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->uvals.p, vals, sizeof vals, hipMemcpyHostToDevice, c->stream));
@@ -300,7 +314,14 @@ int mplx_expand_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int6
   if (int rc = bind_device(c)) return rc;
   mplx::ExpandArgs a = make_args(c, d_nodes, n_nodes, node_stride, d_out);
   a.stream_out = 1;
+  if (int rc = yaw_slot(c, &a.yaw)) return rc;
   HIP_TRY(c, mplx::launch_expand(c->dim, c->prm.control, a, c->stream));
+  if (a.yaw.amb) {
+    mplx_ctx::YawPending p;
+    p.kind = 1;
+    p.e = a;
+    c->yaw_pending.push_back(p);
+  }
   return MPLX_OK;
 }
 
@@ -333,7 +354,15 @@ int mplx_expand(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t nod
   }
   mplx::ExpandArgs a = make_args(c, (const double *)c->s_nodes.p, n_nodes, n_nodes, &d);
   a.stream_out = 1;
+  if (int rc = yaw_slot(c, &a.yaw)) return rc;
   HIP_TRY(c, mplx::launch_expand(c->dim, c->prm.control, a, c->stream));
+  if (a.yaw.amb) {
+    mplx_ctx::YawPending p;
+    p.kind = 1;
+    p.e = a;
+    c->yaw_pending.push_back(p);
+    if (int rc = mplx_detail::resolve_pending(c)) return rc;
+  }
   if (h_out->status) HIP_TRY(c, hipMemcpyAsync(h_out->status, d.status, (size_t)n_slots, hipMemcpyDeviceToHost, c->stream));
   if (h_out->cost) HIP_TRY(c, hipMemcpyAsync(h_out->cost, d.cost, (size_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
   if (h_out->hash) HIP_TRY(c, hipMemcpyAsync(h_out->hash, d.hash, (size_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
@@ -452,6 +481,110 @@ GridPlan plan_grid(const mplx_ctx *c) {
   return g;
 }
 
+// ---------------------------------------------------------------- yaw pinning (YawPin, mplx_internal.h)
+constexpr int kAmbCap = 1023;          // flagged nodes recorded per launch; beyond that the whole launch is re-checked
+constexpr int kYawRing = 32;           // launches that may wait for their check
+constexpr double kYawMargin = 0x1p-46; // |d - cos(yaw_max)| below this is "within rounding noise": both libraries are
+                                       // within a few ulp (2^-53) of the true cos / sin, d is two products and a sum
+
+bool yaw_pin_active(const mplx_ctx *c) {
+  return c->tune.yaw_pin && (c->prm.control & 0x10) && c->prm.yaw_max > 0;
+}
+
+// The detection block of the next launch: a slot of the ring (older launches are resolved first when it is full).
+int yaw_slot(mplx_ctx *c, mplx::YawPin *y) {
+  *y = mplx::YawPin{};
+  if (!yaw_pin_active(c)) return MPLX_OK;
+  if ((int)c->yaw_pending.size() >= kYawRing)
+    if (int rc = mplx_detail::resolve_pending(c)) return rc;
+  if (!c->yaw_ring.p) {
+    const size_t bytes = (size_t)kYawRing * (1 + kAmbCap) * 4;
+    if (int rc = ensure(c, c->yaw_ring, bytes)) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->yaw_ring.p, 0, bytes, c->stream));
+  }
+  y->amb = (int32_t *)c->yaw_ring.p + c->yaw_pending.size() * (size_t)(1 + kAmbCap);
+  y->amb_cap = kAmbCap;
+  y->margin = c->tune.yaw_margin > 0 ? c->tune.yaw_margin : kYawMargin;
+  return MPLX_OK;
+}
+
+double host_wrap(double a) {  // mpl_basis/math.h:15-19
+  while (a > M_PI) a -= 2.0 * M_PI;
+  while (a < -M_PI) a += 2.0 * M_PI;
+  return a;
+}
+
+// Re-expands the nodes `ids` of a pending launch with every trig value of a heading-limit decision taken from the
+// HOST libm -- the library the reference itself calls (primitive.h:504-525 -> std::cos / std::sin).
+int yaw_fix_pass(mplx_ctx *c, const mplx_ctx::YawPending &p, const int32_t *ids, int64_t n) {
+  const int D = c->dim;
+  const double *nodes = p.kind == 0 ? p.g.nodes : p.e.nodes;
+  const int64_t nstride = p.kind == 0 ? p.g.node_stride : p.e.node_stride;
+  const double T = c->prm.dt;
+  // the nodes' yaw (row 4D of the frontier; device memory or a pinned host block the kernel read in place)
+  std::vector<double> yaw((size_t)n);
+  if (n <= 256) {
+    for (int64_t k = 0; k < n; k++)
+      HIP_TRY(c, hipMemcpyAsync(&yaw[(size_t)k], nodes + (int64_t)(4 * D) * nstride + ids[k], 8, hipMemcpyDefault, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  } else {
+    int32_t hi = 0;
+    for (int64_t k = 0; k < n; k++) hi = ids[k] > hi ? ids[k] : hi;
+    std::vector<double> row((size_t)hi + 1);
+    HIP_TRY(c, hipMemcpyAsync(row.data(), nodes + (int64_t)(4 * D) * nstride, ((size_t)hi + 1) * 8, hipMemcpyDefault, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int64_t k = 0; k < n; k++) yaw[(size_t)k] = row[(size_t)ids[k]];
+  }
+  const int nrate = p.kind == 0 ? 16 : c->nU;
+  const int stride = 2 + 2 * nrate;
+  std::vector<double> tab((size_t)n * stride, 0.0);
+  for (int64_t k = 0; k < n; k++) {
+    double *t = &tab[(size_t)k * stride];
+    const double cyaw = yaw[(size_t)k];
+    const double y0 = host_wrap((0.0 + 0.0) + cyaw);  // the yaw polynomial at t = 0 (primitive.h:329, 128-145)
+    t[0] = std::cos(y0);
+    t[1] = std::sin(y0);
+    if (p.kind == 0) {
+      // factorised kernel: [c0, s0, cT[16], sT[16]] over the distinct yaw rates
+      for (int j = 0; j < c->u_nd[3] && j < 16; j++) {
+        const double yT = host_wrap((0.0 + c->h_uyaw[j] * T) + cyaw);
+        t[2 + j] = std::cos(yT);
+        t[2 + 16 + j] = std::sin(yT);
+      }
+    } else {
+      // dense kernel: [c0, s0, {cT, sT} per control]
+      for (int i = 0; i < c->nU; i++) {
+        const double yT = host_wrap((0.0 + c->h_U[(size_t)i * c->udim + D] * T) + cyaw);
+        t[2 + 2 * i] = std::cos(yT);
+        t[2 + 2 * i + 1] = std::sin(yT);
+      }
+    }
+  }
+  if (int rc = ensure(c, c->yaw_ids, (size_t)n * 4)) return rc;
+  if (int rc = ensure(c, c->yaw_tab, tab.size() * 8)) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->yaw_ids.p, ids, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->yaw_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream));
+  mplx::YawPin y{};
+  y.node_list = (const int32_t *)c->yaw_ids.p;
+  y.tab = (const double *)c->yaw_tab.p;
+  y.tab_stride = stride;
+  y.cos_lim = std::cos(c->prm.yaw_max);
+  if (p.kind == 0) {
+    mplx::GridArgs a = p.g;
+    a.n_nodes = n;
+    a.yaw = y;
+    HIP_TRY(c, mplx::launch_expand_grid(c->dim, c->prm.control, a, c->stream));
+  } else {
+    mplx::ExpandArgs a = p.e;
+    a.n_nodes = n;
+    a.yaw = y;
+    HIP_TRY(c, mplx::launch_expand(c->dim, c->prm.control, a, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // `tab` and `ids` leave scope; yaw_ids / yaw_tab are reused
+  c->yaw_fix_passes++;
+  return MPLX_OK;
+}
+
 int ensure_blocked_bits(mplx_ctx *c) {
   if (c->blk_ok) return MPLX_OK;
   const int64_t words = (c->n_cells + 31) >> 5;
@@ -537,7 +670,14 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
     a.l_nstride = o->node_stride ? o->node_stride : c->nU;
     a.l_pad = (a.l_nstride % 32 == 0 && !c->tune.no_line_pad) ? 1 : 0;  // see expand_grid_kernel.hip
+    if (int rc = yaw_slot(c, &a.yaw)) return rc;
     HIP_TRY(c, mplx::launch_expand_grid(c->dim, c->prm.control, a, c->stream));
+    if (a.yaw.amb) {
+      mplx_ctx::YawPending p;
+      p.kind = 0;
+      p.g = a;
+      c->yaw_pending.push_back(p);
+    }
     c->last_route = MPLX_ROUTE_GRID;
     return MPLX_OK;
   }
@@ -592,7 +732,15 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     d.state_stride = cs;
     d.iters = o->iters ? (int32_t *)c->d_iters.p : nullptr;
     mplx::ExpandArgs a = make_args(c, d_nodes + k0, nk, node_stride, &d);
+    if (int rc = yaw_slot(c, &a.yaw)) return rc;
     HIP_TRY(c, mplx::launch_expand(c->dim, c->prm.control, a, c->stream));
+    if (a.yaw.amb) {  // the scratch slots must be final before they are compacted: check this chunk now
+      mplx_ctx::YawPending p;
+      p.kind = 1;
+      p.e = a;
+      c->yaw_pending.push_back(p);
+      if (int rc = mplx_detail::resolve_pending(c)) return rc;
+    }
     mplx::CompactArgs ca{};
     ca.status = d.status; ca.cost = d.cost; ca.hash = d.hash; ca.state = d.state; ca.iters = d.iters;
     ca.chunk_slots = cs; ca.nU = c->nU; ca.n_fields = F;
@@ -609,6 +757,43 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
 }  // namespace
 
 namespace mplx_detail {
+int resolve_pending(mplx_ctx *c) {
+  if (c->yaw_pending.empty()) return MPLX_OK;
+  MPLX_GUARD_BEGIN
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const size_t np = c->yaw_pending.size(), slot = (size_t)(1 + kAmbCap);
+  std::vector<int32_t> ring(np * slot);
+  HIP_TRY(c, hipMemcpyAsync(ring.data(), c->yaw_ring.p, ring.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::vector<mplx_ctx::YawPending> pend;
+  pend.swap(c->yaw_pending);  // the fix passes launch without detection; nothing new becomes pending meanwhile
+  bool any = false;
+  for (size_t i = 0; i < np; i++) {
+    const int32_t cnt = ring[i * slot];
+    if (cnt <= 0) continue;
+    any = true;
+    const mplx_ctx::YawPending &p = pend[i];
+    const int64_t n_all = p.kind == 0 ? p.g.n_nodes : p.e.n_nodes;
+    std::vector<int32_t> ids;
+    if (cnt <= kAmbCap) {
+      ids.assign(ring.begin() + (long)(i * slot + 1), ring.begin() + (long)(i * slot + 1 + cnt));
+      std::sort(ids.begin(), ids.end());
+      ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    } else {  // more flagged nodes than the block records: re-check the whole launch
+      ids.resize((size_t)n_all);
+      for (int64_t k = 0; k < n_all; k++) ids[(size_t)k] = (int32_t)k;
+    }
+    c->yaw_flagged += (int64_t)ids.size();
+    const int64_t chunk = 16384;
+    for (int64_t k0 = 0; k0 < (int64_t)ids.size(); k0 += chunk) {
+      const int64_t nk = std::min<int64_t>(chunk, (int64_t)ids.size() - k0);
+      if (int rc = yaw_fix_pass(c, p, ids.data() + k0, nk)) return rc;
+    }
+  }
+  if (any) HIP_TRY(c, hipMemsetAsync(c->yaw_ring.p, 0, np * slot * 4, c->stream));
+  return MPLX_OK;
+  MPLX_GUARD_END(c)
+}
 int ctx_ready(mplx_ctx *c) { return ready(c); }
 int lists_on_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride, const mplx_succ_lists *d) {
   return lists_device(c, d_nodes, n_nodes, node_stride, d);
@@ -689,6 +874,13 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
       if (!zero_copy)
         HIP_TRY(c, hipMemcpyAsync(hb + o_count, db + o_count, total - o_count, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (!c->yaw_pending.empty()) {  // a fix pass of the yaw pinning rewrites lists on the device side
+        if (int rc = resolve_pending(c)) return rc;
+        if (!zero_copy) {
+          HIP_TRY(c, hipMemcpyAsync(hb + o_count, db + o_count, total - o_count, hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+      }
       const int32_t *cnt = (const int32_t *)(hb + o_count);
       std::memcpy(h_out->count, cnt, (size_t)n_nodes * 4);
       for (int64_t k = 0; k < n_nodes; k++) {
@@ -727,6 +919,7 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
   // everything larger: only the used prefixes cross the link, packed on the device and pipelined through pinned
   // buffers (lists_copy_api.cpp)
   MPLX_GUARD_BEGIN
+  if (int rc = resolve_pending(c)) return rc;
   return mplx_detail::copy_lists_to_host(c, d, h_out, n_nodes);
   MPLX_GUARD_END(c)
 }
@@ -768,6 +961,7 @@ int mplx_device_free(mplx_ctx *c, void *dptr) {
   if (!c) return MPLX_ERR_ARG;
   if (!dptr) return MPLX_OK;
   if (int rc = bind_device(c)) return rc;
+  if (int rc = resolve_pending(c)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipFree(dptr));
   return MPLX_OK;
@@ -784,6 +978,7 @@ int mplx_memcpy_h2d(mplx_ctx *c, void *dst, const void *src, size_t bytes) {
 int mplx_memcpy_d2h(mplx_ctx *c, void *dst, const void *src, size_t bytes) {
   if (!c) return MPLX_ERR_ARG;
   if (int rc = bind_device(c)) return rc;
+  if (int rc = resolve_pending(c)) return rc;
   HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return MPLX_OK;
@@ -800,7 +995,7 @@ int mplx_synchronize(mplx_ctx *c) {
   if (!c) return MPLX_ERR_ARG;
   if (int rc = bind_device(c)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return MPLX_OK;
+  return resolve_pending(c);
 }
 
 int mplx_timer_begin(mplx_ctx *c) {
@@ -817,7 +1012,7 @@ int mplx_timer_end(mplx_ctx *c, float *ms) {
   HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
   HIP_TRY(c, hipEventSynchronize(c->ev1));
   HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
-  return MPLX_OK;
+  return resolve_pending(c);  // (after the measurement: a fix pass of the yaw pinning is not part of the timed launches)
 }
 
 int mplx_selftest_math(mplx_ctx *c, int op, const double *a, const double *b, double *out, int64_t n) {
@@ -850,6 +1045,13 @@ int mplx_set_lists_route(mplx_ctx *c, int route) {
 }
 
 int mplx_last_lists_route(const mplx_ctx *c) { return c ? c->last_route : MPLX_ERR_ARG; }
+
+int mplx_yaw_pin_stats(const mplx_ctx *c, int64_t *flagged_nodes, int64_t *fix_passes) {
+  if (!c) return MPLX_ERR_ARG;
+  if (flagged_nodes) *flagged_nodes = c->yaw_flagged;
+  if (fix_passes) *fix_passes = c->yaw_fix_passes;
+  return MPLX_OK;
+}
 
 int mplx_device_info(mplx_ctx *c, char *name, size_t cap, int32_t *compute_units) {
   if (!c) return MPLX_ERR_ARG;

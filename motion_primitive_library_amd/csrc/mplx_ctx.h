@@ -59,6 +59,8 @@ struct mplx_ctx {
     int zero_copy = 1;                                   // MPLX_ZERO_COPY=0: small batches through a device arena instead
     int arena_kb = 0;                                    // MPLX_ARENA_KB: largest batch served by the one-copy path
     bool no_sat = false, no_lex = false, no_line_pad = false;  // MPLX_GRID_NOSAT / MPLX_GRID_NOLEX / MPLX_NO_LINE_PAD
+    bool yaw_pin = true;       // MPLX_YAW_PIN=0: raw device trig decisions (to measure what the pinning is for)
+    double yaw_margin = 0;     // MPLX_YAW_MARGIN: detection band (tests widen it to drive many nodes through the fix pass)
   } tune;
   int lists_route = MPLX_ROUTE_AUTO;
   int last_route = MPLX_ROUTE_AUTO;
@@ -85,6 +87,18 @@ struct mplx_ctx {
   std::vector<int64_t> pk_hoffs;
   void *pk_hb = nullptr;  // pinned block of expand_lists_packed: nodes, counts, offsets
   size_t pk_hb_cap = 0;
+  // yaw pinning (YawPin, mplx_internal.h): launches whose heading-limit decisions have not been checked against
+  // the host libm yet; resolved by resolve_pending() at the next synchronising call
+  struct YawPending {
+    int kind = 0;  // 0: factorised lists kernel, 1: dense kernel
+    mplx::GridArgs g{};
+    mplx::ExpandArgs e{};
+  };
+  std::vector<YawPending> yaw_pending;
+  mplx_detail::DevBuf yaw_ring, yaw_ids, yaw_tab;  // flagged nodes per pending launch; node list + trig table of a fix pass
+  std::vector<double> h_U;          // host copy of the control table (the fix pass needs the yaw rates)
+  double h_uyaw[16] = {0};          // ... and of its distinct yaw rates, in the factorisation's order
+  int64_t yaw_flagged = 0, yaw_fix_passes = 0;  // statistics (mplx_yaw_pin_stats)
   // RCCL communicator of this context (comm_api.cpp); the library is loaded on first use
   void *comm = nullptr;
   int comm_rank = 0, comm_world = 1;
@@ -163,6 +177,11 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
 // mplx_api.cpp: readiness check and the route dispatch behind mplx_expand_lists*
 int ctx_ready(mplx_ctx *c);
 int lists_on_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride, const mplx_succ_lists *d);
+
+// mplx_api.cpp: synchronises the stream and, where a launch flagged heading-limit decisions within rounding noise of
+// their threshold, re-expands those nodes with the host libm's trig values (YawPin, mplx_internal.h).  Every
+// synchronising entry point and every call that changes what a pending launch read goes through it.
+int resolve_pending(mplx_ctx *c);
 
 // lists_copy_api.cpp: device lists -> host lists, only the used prefixes, pipelined through pinned memory
 int copy_lists_to_host(mplx_ctx *c, const mplx_succ_lists &d, const mplx_succ_lists *h_out, int64_t n_nodes);

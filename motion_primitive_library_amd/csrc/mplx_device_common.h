@@ -40,6 +40,22 @@ __device__ __forceinline__ int quantise(double x, double q, double Rq) {
   return (int)round(div_by(x, q, Rq));
 }
 
+// ---- yaw pinning (YawPin, mplx_internal.h): is the heading-limit decision `d < cos_lim` of validate_yaw
+// (primitive.h:504-525) within rounding noise of its threshold?  One case is exempt because it is an exact tie under
+// ANY libm with an even cosine: velocity along x (vy == 0: the y term is an exact zero and vx / |v| is exactly +-1)
+// with |yaw| == yaw_max gives d = +-cos(yaw) against cos(yaw_max) = cos(|yaw|) -- equal, or 2 cos(yaw_max) apart.
+// Lattice searches hit that tie all the time (yaw_max and the yaw steps are the same multiples of 0.5), so it must
+// not count as ambiguous; it is decided identically by the device and by the host.
+__device__ __forceinline__ bool near_limit(double d, double cos_lim, double margin, double vy, double yaw,
+                                           double yaw_max) {
+  if (vy == 0 && fabs(yaw) == yaw_max) return false;
+  return fabs(d - cos_lim) <= margin;
+}
+__device__ __forceinline__ void flag_node(int32_t *amb, int cap, int64_t node) {
+  const int k = atomicAdd(&amb[0], 1);
+  if (k < cap) amb[1 + k] = (int32_t)node;
+}
+
 template <int D, int K>
 __device__ __forceinline__ uint64_t lattice_hash(const double *pos, const double *vel, const double *acc,
                                                  const double *jrk, double R001, double R01) {

@@ -9,6 +9,25 @@
 
 namespace mplx {
 
+// validate_yaw (reference include/mpl_basis/primitive.h:504-525) compares d = v_hat . (cos yaw, sin yaw) with
+// cos(yaw_max), and the reference's cos / sin are the HOST libm's.  The device's (OCML) differ from glibc's in the
+// last place on a few per cent of arguments, so a decision within rounding noise of the threshold could come out
+// differently.  Pinning: the detection pass (amb != null) flags every node with a decision closer to the threshold
+// than `margin` (a bound on what the two libraries' rounding can move d - cos(yaw_max); decisions farther away are
+// the same under either library) and the host then re-expands exactly those nodes in an override pass (tab != null)
+// in which every cos / sin of a heading-limit decision and cos(yaw_max) come from a table the HOST filled with its
+// libm, so the decision is the reference's own arithmetic on the reference's own values.  The per-sample heading
+// COST (env_map.h:121-129) keeps device trig: it is continuous and held to north_star's 1e-6.
+struct YawPin {
+  int32_t *amb;               // detection: [0] = number of flagged nodes, [1 .. cap] their indices; null = off
+  int32_t amb_cap;
+  double margin;
+  const int32_t *node_list;   // override pass: the nodes to re-expand (kernel node k -> node_list[k]); null = all
+  const double *tab;          // override pass: per listed node the host's trig values (layout per kernel); null = off
+  int32_t tab_stride;         // doubles per listed node
+  double cos_lim;             // override pass: the host's cos(yaw_max)
+};
+
 // Everything one expansion launch needs, passed by value as the kernel
 // argument block (lives in SGPRs / constant cache: wave-uniform).
 struct ExpandArgs {
@@ -38,6 +57,7 @@ struct ExpandArgs {
   int64_t state_stride;
   int32_t *iters;
   int32_t stream_out;  // 1: the slots are final outputs (non-temporal stores); 0: scratch that is re-read soon
+  YawPin yaw;          // heading-limit decisions pinned to the host libm (see YawPin)
 };
 
 // Arguments of the tiled, list-producing kernel (expand_tile_kernel.hip).
@@ -126,6 +146,7 @@ struct GridArgs {
   int32_t *l_iters;
   int64_t l_nstride;  // entries reserved per node (>= nU)
   int32_t l_pad;      // 1: complete the last 128-byte line of every list row (node stride is a multiple of 32)
+  YawPin yaw;         // heading-limit decisions pinned to the host libm (see YawPin); tab row: [c0, s0, cT[16], sT[16]]
 };
 // Packing of the used list prefixes for the copy back to the host (pack_kernel.hip).
 constexpr int kPackRows = 24;

@@ -17,6 +17,7 @@ extern "C" int mplx_pack_lists_device(mplx_ctx *c, const mplx_succ_lists *L, int
   if (o->state && o->state_stride < o->capacity)
     return fail(c, MPLX_ERR_ARG, "mplx_pack_lists_device: state_stride < capacity");
   if (int rc = bind_device(c)) return rc;
+  if (int rc = resolve_pending(c)) return rc;  // yaw pinning: the lists must be final
   const int F = 4 * c->dim + 2;
   const int64_t S = L->node_stride ? L->node_stride : c->nU;
   HIP_TRY(c, mplx::launch_scan_counts(L->count, n_nodes, o->offs, c->stream));

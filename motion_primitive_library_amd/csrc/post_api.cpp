@@ -18,6 +18,7 @@ extern "C" int mplx_post_lists_device(mplx_ctx *c, const mplx_succ_lists *d_list
   if (!c->has_U) return fail(c, MPLX_ERR_STATE, "mplx_post_lists_device: controls not set");
   if (n_nodes == 0) return MPLX_OK;
   if (int rc = bind_device(c)) return rc;
+  if (int rc = resolve_pending(c)) return rc;  // yaw pinning: the lists must be final
   const int D = c->dim, F = 4 * D + 2;
   const int64_t S = d_lists->node_stride ? d_lists->node_stride : c->nU;
   const int64_t n = n_nodes * S;

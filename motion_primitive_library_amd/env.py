@@ -650,6 +650,12 @@ class EnvMap:
         return {_abi.ROUTE_AUTO: "none", _abi.ROUTE_DENSE: "dense", _abi.ROUTE_TILE: "tile",
                 _abi.ROUTE_GRID: "grid"}[code]
 
+    def yaw_pin_stats(self):
+        """(nodes re-expanded with the host libm's trig values, fix passes launched) since the context was made."""
+        a, b = C.c_int64(), C.c_int64()
+        _abi.check(self._ctx, _abi.lib().mplx_yaw_pin_stats(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def selftest_math(self, op, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float64)
         b = a if b is None else np.ascontiguousarray(b, dtype=np.float64)

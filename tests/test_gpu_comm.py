@@ -8,6 +8,8 @@ import socket
 
 import numpy as np
 import pytest
+import torch  # noqa: F401 -- first: PyTorch-ROCm brings its own librccl.so, and a process must use ONE RCCL (the
+#               library's mplx_comm_* then binds the copy that is already loaded)
 
 from helpers import engine_env
 
