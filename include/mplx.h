@@ -301,6 +301,8 @@ typedef struct {
   int32_t *cells;
   int32_t *cell_count;
   int32_t cell_cap;
+  uint8_t *outside;        /* [n_edges] non-zero when a sample of the edge fell outside the map (its `cells`
+                              entry is then the reference's own out-of-range int index arithmetic) */
 } mplx_edges_out;
 /* parents: field-major [4D+2][stride] (stride >= n_edges), actions: [n_edges]. */
 int mplx_check_edges(mplx_ctx *ctx, const double *h_parents, const int32_t *h_actions, int64_t n_edges,

@@ -33,9 +33,16 @@
 // cache.  The lists returned are identical with and without batching; only the
 // number of launches changes.  The cache is dropped whenever parameters, controls or
 // maps change, and at the start of every plan().
-// Errors never throw: a failed device call prints the engine's message and
-// returns an empty successor list (the reference's own error convention is
-// printf + sentinel, graph_search.h:149-161).  There is no CPU fallback.
+// Incremental re-planning (LPA*).  MapPlanner::getLinkedNodes and updateClearedNodes
+// (map_planner.cpp:125-157, 174-185) walk every stored edge with Primitive::sample /
+// env_map::is_free(Primitive); GpuMapPlanner shadows both with ONE batched device call
+// each (mplx_check_edges) and leaves lhm_ and the state space exactly as the
+// reference's loops would (updateBlockedNodes is pure host bookkeeping and is inherited).
+// Errors never throw: a failed device call prints the engine's message, latches it
+// (device_ok() / device_error(); GpuMapPlanner::plan then returns false with the
+// message instead of looking like "no trajectory exists") and returns an empty
+// successor list (the reference's own error convention is printf + sentinel,
+// graph_search.h:149-161).  There is no CPU fallback.
 #ifndef MPLX_ENV_MAP_HPP
 #define MPLX_ENV_MAP_HPP
 
@@ -47,6 +54,7 @@
 #include <cstdio>
 #include <cstring>
 #include <queue>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -73,6 +81,12 @@ class env_map_hip : public env_map<Dim> {
   env_map_hip &operator=(const env_map_hip &) = delete;
 
   bool ok() const { return ctx_ != nullptr; }
+  /// False once any device call of this env has failed (sticky until clear_device_error()); the text of the
+  /// first failure.  A search that ran into a device failure sees empty successor lists, i.e. "no path": callers
+  /// tell the two apart here (GpuMapPlanner::plan does).
+  bool device_ok() const { return ctx_ != nullptr && first_error_.empty(); }
+  const std::string &device_error() const { return first_error_; }
+  void clear_device_error() { first_error_.clear(); }
   /// Nodes per device launch (1 = one launch per get_succ, the default).
   void set_batch(int n) { batch_ = n < 1 ? 1 : n; drop_cache(); }
   /// env_map::get_succ also records every finite edge as a Primitive in expanded_edges_ (env_map.h:166, read by
@@ -109,7 +123,8 @@ class env_map_hip : public env_map<Dim> {
     succ_cost.clear();
     action_idx.clear();
     this->expanded_nodes_.push_back(curr.pos);
-    if (!ctx_ || !sync(curr.control)) return;
+    if (!ctx_) { latch("no device context (mplx_create failed)"); return; }
+    if (!sync(curr.control)) return;
     constexpr int F = 4 * Dim + 2;
     const int nU = (int)this->U_.size();
     double node[F];
@@ -153,7 +168,7 @@ class env_map_hip : public env_map<Dim> {
       buf_act_.resize((size_t)nU);
       launches_++;
       if (mplx_get_succ(ctx_, node, buf_succ_.data(), buf_cost_.data(), buf_act_.data(), &n) != MPLX_OK) {
-        printf(ANSI_COLOR_RED "[env_map_hip] get_succ: %s\n" ANSI_COLOR_RESET, mplx_last_error(ctx_));
+        complain();
         return;
       }
     }
@@ -177,7 +192,8 @@ class env_map_hip : public env_map<Dim> {
   bool device_update_potential_map(const Vecf<Dim> &pos, const Vecf<Dim> &radius, const Vecf<Dim> &range,
                                    decimal_t pow, const std::shared_ptr<MapUtil<Dim>> &map_util) {
     maps_stale_ = true;
-    if (!ctx_ || !sync_maps()) return false;
+    if (!ctx_) return latch("no device context (mplx_create failed)");
+    if (!sync_maps()) return false;
     double p[3] = {0, 0, 0}, r[3] = {0, 0, 0}, g[3] = {0, 0, 0};
     for (int i = 0; i < Dim; i++) { p[i] = pos(i); r[i] = radius(i); g[i] = range(i); }
     Tmap dmap(map_util->getMap().size());
@@ -190,7 +206,8 @@ class env_map_hip : public env_map<Dim> {
 
   /// MapPlanner::setSearchRegion on the device (map_planner.cpp:46-95).
   bool device_set_search_region(const vec_Vecf<Dim> &path, bool dense, const Vecf<Dim> &search_radius) {
-    if (!ctx_ || !sync_maps()) return false;
+    if (!ctx_) return latch("no device context (mplx_create failed)");
+    if (!sync_maps()) return false;
     std::vector<double> pts(path.size() * Dim);
     for (size_t k = 0; k < path.size(); k++)
       for (int i = 0; i < Dim; i++) pts[k * Dim + i] = path[k](i);
@@ -202,6 +219,51 @@ class env_map_hip : public env_map<Dim> {
     std::vector<bool> in_region(bytes.size());
     for (size_t i = 0; i < bytes.size(); i++) in_region[i] = bytes[i] != 0;
     env_map<Dim>::set_search_region(in_region);
+    region_fp_ = region_fingerprint();  // the device already holds exactly this region
+    return true;
+  }
+
+  /// pack() for callers outside the class (GpuMapPlanner's edge batches)
+  static void pack_row(const Waypoint<Dim> &w, double *row) { pack(w, row); }
+
+  /// Batched edge re-validation (mplx_check_edges; env_map::is_free(Primitive) env_map.h:60-76, intrinsic cost
+  /// env_base.h:343-345, the cells of MapPlanner::getLinkedNodes) for edges (parent waypoint, action id).  parents
+  /// are field-major [4D+2][n].  Any output may be null; `cells` rows hold *cell_cap entries (grown until no row is
+  /// truncated).
+  bool device_check_edges(int control, const std::vector<double> &parents_fm, const std::vector<int32_t> &actions,
+                          std::vector<uint8_t> *free_flag, std::vector<double> *cost, std::vector<int32_t> *cells,
+                          std::vector<int32_t> *cell_count, int *cell_cap, std::vector<uint8_t> *outside) const {
+    if (!ctx_) return latch("no device context (mplx_create failed)");
+    if (!sync(control)) return false;
+    const int64_t n = (int64_t)actions.size();
+    if (free_flag) free_flag->assign((size_t)n, 0);
+    if (cost) cost->assign((size_t)n, 0.0);
+    if (outside) outside->assign((size_t)n, 0);
+    std::vector<int32_t> cnt((size_t)n, 0);
+    int cap = 0;
+    if (cells) {
+      const double vb = this->v_max_ > 0 ? this->v_max_ : 4.0;
+      cap = (int)std::ceil(vb * this->dt_ / this->map_util_->getRes()) + 2;
+    }
+    for (;;) {
+      mplx_edges_out o{};
+      o.free_flag = free_flag ? free_flag->data() : nullptr;
+      o.cost = cost ? cost->data() : nullptr;
+      o.outside = outside ? outside->data() : nullptr;
+      if (cells) {
+        cells->assign((size_t)n * cap, 0);
+        o.cells = cells->data();
+        o.cell_count = cnt.data();
+        o.cell_cap = cap;
+      }
+      if (mplx_check_edges(ctx_, parents_fm.data(), actions.data(), n, n, &o) != MPLX_OK) return complain();
+      int need = 0;
+      for (int64_t e = 0; e < n; e++) need = cnt[(size_t)e] > need ? cnt[(size_t)e] : need;
+      if (!cells || need <= cap) break;
+      cap = need;  // a row was truncated: once more with room for the longest
+    }
+    if (cell_count) *cell_count = cnt;
+    if (cell_cap) *cell_cap = cap;
     return true;
   }
 
@@ -412,7 +474,24 @@ class env_map_hip : public env_map<Dim> {
     w.t = row[4 * Dim + 1];
   }
 
+  // env_base::set_search_region is not virtual (env_base.h:301-303), so a region installed behind the adapter's back
+  // is noticed by a fingerprint (size + 1024 strided probes, ~1 us) taken at every expansion.  A plan() marks the maps
+  // stale anyway (is_free(start)); an edit that changes none of the probed bits needs notify_map_changed().
+  uint64_t region_fingerprint() const {
+    const std::vector<bool> &r = this->search_region_;
+    uint64_t h = r.size() * 0x9e3779b97f4a7c15ULL;
+    if (r.empty()) return h;
+    const size_t step = r.size() / 1024 + 1;
+    for (size_t i = 0; i < r.size(); i += step) h = (h << 1 | h >> 63) ^ (r[i] ? 0xd6e8feb86659fd93ULL : 0x1ULL);
+    return h;
+  }
+
   bool sync_maps() const {
+    {
+      const uint64_t fp = region_fingerprint();
+      if (fp != region_fp_) maps_stale_ = true;
+      region_fp_ = fp;
+    }
     if (maps_stale_) {
       drop_cache();
       const Veci<Dim> dim = this->map_util_->getDim();
@@ -467,12 +546,16 @@ class env_map_hip : public env_map<Dim> {
     }
     return true;
   }
-  bool complain() const {
-    printf(ANSI_COLOR_RED "[env_map_hip] %s\n" ANSI_COLOR_RESET, mplx_last_error(ctx_));
+  bool complain() const { return latch(mplx_last_error(ctx_)); }
+  bool latch(const char *msg) const {
+    printf(ANSI_COLOR_RED "[env_map_hip] %s\n" ANSI_COLOR_RESET, msg);
+    if (first_error_.empty()) first_error_ = msg;
     return false;
   }
 
   mplx_ctx *ctx_ = nullptr;
+  mutable std::string first_error_;
+  mutable uint64_t region_fp_ = 0;
   mutable bool maps_stale_ = true, have_params_ = false;
   mutable mplx_params params_{};
   mutable std::vector<double> flatU_, sentU_, buf_succ_, buf_cost_;
@@ -532,7 +615,141 @@ class GpuMapPlanner : public MapPlanner<Dim> {
   }
   void set_pow(decimal_t p) { this->pow_ = p; }  // the reference has no setter for pow_ (map_planner.h:113)
 
+  /// Device failures of the env since the last clear (see env_map_hip::device_ok).
+  bool deviceOk() const { return this->ENV_ && env()->device_ok(); }
+  const std::string &deviceError() const { return env()->device_error(); }
+
+  /// Shadows PlannerBase::plan (not virtual): the reference's plan, then the check a CPU env never needs -- a
+  /// device failure during the search (empty successor lists) must not pass for "no trajectory exists".
+  bool plan(const Waypoint<Dim> &start, const Waypoint<Dim> &goal) {
+    const bool ok = MapPlanner<Dim>::plan(start, goal);
+    if (!deviceOk()) {
+      printf(ANSI_COLOR_RED "[GpuMapPlanner] device error during plan(): %s\n" ANSI_COLOR_RESET, deviceError().c_str());
+      return false;
+    }
+    return ok;
+  }
+
+  /// Shadows MapPlanner::getLinkedNodes (map_planner.cpp:125-157): the voxel -> edge table lhm_ and the list of
+  /// linked cell centres, from ONE batched device call over every stored edge instead of a Primitive::sample per
+  /// edge.  Edges are visited in the reference's own order (hm_ iteration, then pred index), so lhm_'s per-cell
+  /// vectors come out in the same order and updateBlockedNodes / updateClearedNodes behave identically.
+  vec_Vecf<Dim> getLinkedNodes() const {
+    constexpr int F = 4 * Dim + 2;
+    this->lhm_.clear();
+    vec_Vecf<Dim> linked_pts;
+    struct EdgeRef { const Waypoint<Dim> *node; const Waypoint<Dim> *parent; int i, action; };
+    std::vector<EdgeRef> edges;
+    for (const auto &it : this->ss_ptr_->hm_) {
+      if (!it.second) continue;
+      for (unsigned int i = 0; i < it.second->pred_coord.size(); i++)
+        edges.push_back({&it.second->coord, &this->ss_ptr_->hm_[it.second->pred_coord[i]]->coord, (int)i,
+                         it.second->pred_action_id[i]});
+    }
+    const size_t n = edges.size();
+    if (n == 0) return linked_pts;
+    std::vector<double> parents((size_t)F * n);
+    std::vector<int32_t> actions(n), cells, count;
+    std::vector<uint8_t> outside;
+    for (size_t e = 0; e < n; e++) {
+      double row[F];
+      env_map_hip<Dim>::pack_row(*edges[e].parent, row);
+      for (int f = 0; f < F; f++) parents[(size_t)f * n + e] = row[f];
+      actions[e] = edges[e].action;
+    }
+    int cap = 0;
+    if (!env()->device_check_edges(edges[0].parent->control, parents, actions, nullptr, nullptr, &cells, &count, &cap, &outside))
+      return linked_pts;
+    const Veci<Dim> dim = this->map_util_->getDim();
+    for (size_t e = 0; e < n; e++) {
+      if (outside[e]) {
+        // a sample left the map: the cell centres of outside cells cannot be told from the (reference-identical)
+        // int index alone, so this edge's points follow the reference's own statements (map_planner.cpp:140-153)
+        Primitive<Dim> pr;
+        this->ENV_->forward_action(*edges[e].parent, edges[e].action, pr);
+        decimal_t max_v = 0;
+        for (int k = 0; k < Dim; k++) max_v = std::max(max_v, pr.max_vel(k));
+        const int ns = 1.0 * std::ceil(max_v * pr.t() / this->map_util_->getRes());
+        int prev_id = -1;
+        for (const auto &w : pr.sample(ns)) {
+          const int id = this->map_util_->getIndex(this->map_util_->floatToInt(w.pos));
+          if (id != prev_id) {
+            linked_pts.push_back(this->map_util_->intToFloat(this->map_util_->floatToInt(w.pos)));
+            this->lhm_[id].push_back(std::make_pair(*edges[e].node, edges[e].i));
+            prev_id = id;
+          }
+        }
+        continue;
+      }
+      for (int k = 0; k < count[e]; k++) {
+        const int id = cells[e * (size_t)cap + k];
+        Veci<Dim> pn;
+        int rem = id;
+        for (int a = 0; a < Dim; a++) {
+          pn(a) = a + 1 < Dim ? rem % dim(a) : rem;
+          rem /= dim(a);
+        }
+        linked_pts.push_back(this->map_util_->intToFloat(pn));
+        this->lhm_[id].push_back(std::make_pair(*edges[e].node, edges[e].i));
+      }
+    }
+    return linked_pts;
+  }
+
+  /// Shadows MapPlanner::updateClearedNodes (map_planner.cpp:174-185) + StateSpace::decreaseCost
+  /// (state_space.h:230-253): the affected edges are re-validated in ONE device call (is_free(Primitive) and
+  /// calculate_intrinsic_cost), then the state space is updated by the reference's own statements in the
+  /// reference's own order.  The map edit must already be in the MapUtil (as for the reference).
+  void updateClearedNodes(const vec_Veci<Dim> &cleared_pns) {
+    constexpr int F = 4 * Dim + 2;
+    std::vector<std::pair<Waypoint<Dim>, int>> cleared_nodes;
+    for (const auto &it : cleared_pns) {
+      const int id = this->map_util_->getIndex(it);
+      auto search = this->lhm_.find(id);
+      if (search != this->lhm_.end())
+        for (const auto &node : search->second) cleared_nodes.push_back(node);
+    }
+    const size_t n = cleared_nodes.size();
+    if (n == 0) return;
+    auto &hm = this->ss_ptr_->hm_;
+    std::vector<double> parents((size_t)F * n);
+    std::vector<int32_t> actions(n);
+    for (size_t e = 0; e < n; e++) {
+      const auto &succ = hm[cleared_nodes[e].first];
+      const int i = cleared_nodes[e].second;
+      double row[F];
+      env_map_hip<Dim>::pack_row(succ->pred_coord[i], row);  // decreaseCost forwards from the stored parent coord
+      for (int f = 0; f < F; f++) parents[(size_t)f * n + e] = row[f];
+      actions[e] = succ->pred_action_id[i];
+    }
+    env()->notify_map_changed();  // the cells were cleared in the MapUtil: the device copy is stale
+    std::vector<uint8_t> free_flag;
+    std::vector<double> cost;
+    if (!env()->device_check_edges(cleared_nodes[0].first.control, parents, actions, &free_flag, &cost, nullptr, nullptr,
+                                   nullptr, nullptr))
+      return;
+    for (size_t e = 0; e < n; e++) {  // state_space.h:232-252
+      StatePtr<Waypoint<Dim>> &succNode_ptr = hm[cleared_nodes[e].first];
+      const int i = cleared_nodes[e].second;
+      if (std::isinf(succNode_ptr->pred_action_cost[i])) {
+        const Waypoint<Dim> parent_key = succNode_ptr->pred_coord[i];
+        if (free_flag[e]) {
+          succNode_ptr->pred_action_cost[i] = cost[e];
+          this->ss_ptr_->updateNode(succNode_ptr);
+          const int succ_act_id = succNode_ptr->pred_action_id[i];
+          for (size_t j = 0; j < hm[parent_key]->succ_action_id.size(); j++) {
+            if (succ_act_id == hm[parent_key]->succ_action_id[j]) {
+              hm[parent_key]->succ_action_cost[j] = succNode_ptr->pred_action_cost[i];
+              break;
+            }
+          }
+        }
+      }
+    }
+  }
+
  private:
+  env_map_hip<Dim> *env() const { return static_cast<env_map_hip<Dim> *>(this->ENV_.get()); }
   int device_;
   int batch_ = 1;
 };

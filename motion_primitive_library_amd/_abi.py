@@ -75,7 +75,7 @@ class GoalSpec(C.Structure):
 
 class EdgesOut(C.Structure):
     _fields_ = [("free_flag", C.c_void_p), ("cost", C.c_void_p), ("cells", C.c_void_p), ("cell_count", C.c_void_p),
-                ("cell_cap", C.c_int32)]
+                ("cell_cap", C.c_int32), ("outside", C.c_void_p)]
 
 
 class Post(C.Structure):

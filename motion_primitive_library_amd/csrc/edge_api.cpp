@@ -42,7 +42,13 @@ extern "C" int mplx_check_edges(mplx_ctx *c, const double *h_parents, const int3
     a.cells = (int32_t *)c->e_cells.p;
     a.cell_cap = h_out->cell_cap;
   }
+  if (h_out->outside) {  // (rides at the end of the free-flag staging buffer)
+    if (int rc = ensure(c, c->e_free, (size_t)n_edges * 2)) return rc;
+    if (h_out->free_flag) a.free_out = (uint8_t *)c->e_free.p;
+    a.outside_out = (uint8_t *)c->e_free.p + n_edges;
+  }
   HIP_TRY(c, mplx::launch_check_edges(c->dim, c->prm.control, a, c->stream));
+  if (h_out->outside) HIP_TRY(c, hipMemcpyAsync(h_out->outside, a.outside_out, (size_t)n_edges, hipMemcpyDeviceToHost, c->stream));
   if (h_out->free_flag) HIP_TRY(c, hipMemcpyAsync(h_out->free_flag, a.free_out, (size_t)n_edges, hipMemcpyDeviceToHost, c->stream));
   if (h_out->cost) HIP_TRY(c, hipMemcpyAsync(h_out->cost, a.cost, (size_t)n_edges * 8, hipMemcpyDeviceToHost, c->stream));
   if (h_out->cell_count) HIP_TRY(c, hipMemcpyAsync(h_out->cell_count, a.cell_count, (size_t)n_edges * 4, hipMemcpyDeviceToHost, c->stream));

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void edge_kernel(const EdgeArgs A) {
   }
   const int n = (int)ceil(max_v * T / A.res);  // env_map.h:65 (no lower bound of 5 here)
   bool is_free = n > 0;
+  bool any_outside = false;
   int n_cells = 0;
   if (n > 0) {
     const double sdt = T / n;  // primitive.h:417
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void edge_kernel(const EdgeArgs A) {
         cell[k] = (int)round((ax[k].template pos<false>(t) - org[k]) / A.res - 0.5);  // map_util.h:103-108
         outside = outside || cell[k] < 0 || cell[k] >= dims[k];
       }
+      any_outside = any_outside || outside;
       int idx = cell[0] + dims[0] * cell[1];  // map_util.h:34-41, in the reference's int arithmetic
       if (D == 3) idx += dims[0] * dims[1] * cell[2];
       if (A.cells) {  // map_planner.cpp:145-152
@@ -75,12 +77,13 @@ __global__ __launch_bounds__(256) void edge_kernel(const EdgeArgs A) {
         else if (A.map[idx] == 100) is_free = false;
         else if (A.region != nullptr && !((A.region[(unsigned)idx >> 5] >> (idx & 31)) & 1u)) is_free = false;
       }
-      if (!is_free && !A.cells) break;
+      if (!is_free && !A.cells && !A.outside_out) break;
     }
   }
   if (A.free_out) A.free_out[e] = is_free ? 1 : 0;
   if (A.cost) A.cost[e] = is_free ? J + A.w * A.dt : INFINITY;
   if (A.cell_count) A.cell_count[e] = n_cells;
+  if (A.outside_out) A.outside_out[e] = any_outside ? 1 : 0;
 }
 
 template <int D, int K>

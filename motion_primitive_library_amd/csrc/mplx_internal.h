@@ -192,6 +192,7 @@ struct EdgeArgs {
   int32_t *cells;          // [n_edges][cell_cap]
   int32_t *cell_count;
   int32_t cell_cap;
+  uint8_t *outside_out;    // [n_edges] some sample outside the map, or null
 };
 hipError_t launch_check_edges(int dim, int control, const EdgeArgs &args, hipStream_t s);
 
