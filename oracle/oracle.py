@@ -359,3 +359,34 @@ def search_region(map_dim, origin, res, path, search_radius, dense=False, ref=Fa
     if rc != 0:
         raise RuntimeError("search_region failed: %d" % rc)
     return out
+
+
+def ref_lpastar(env, start_row, goal_row, use_gpu=False, box_half=3):
+    """The reference's LPA* (PlannerBase::setLPAstar) with a map edit between plans: plan, getLinkedNodes, block a box
+    of (2 box_half + 1)^D free cells around the middle of the trajectory + updateBlockedNodes, plan, clear the box +
+    updateClearedNodes, plan -- on the reference's MapPlanner (CPU) or on MPL::GpuMapPlanner (use_gpu; the edge work
+    of getLinkedNodes / updateClearedNodes batched on the device).  Returns the three plans' summaries and the
+    statistics of the voxel -> edge table."""
+    lib = _LIBS.setdefault("ref_planner", C.CDLL(REF_PLANNER_SO))
+    lib.mpl_ref_lpastar.restype = C.c_int
+    lib.mpl_ref_lpastar.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(RefPlanOut),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    s = np.ascontiguousarray(start_row, dtype=np.float64)
+    g = np.ascontiguousarray(goal_row, dtype=np.float64)
+    out = (RefPlanOut * 3)()
+    chk = (C.c_double * 3)()
+    st = (C.c_int64 * 8)()
+    ce = env._c()
+    rc = lib.mpl_ref_lpastar(C.byref(ce), s.ctypes.data, g.ctypes.data, int(use_gpu), int(box_half), out, chk, st)
+    if rc != 0:
+        raise RuntimeError("mpl_ref_lpastar failed: %d" % rc)
+    plans = []
+    for i in range(3):
+        o = out[i]
+        plans.append({"ok": bool(o.ok), "closed": o.closed, "opened": o.opened, "expansions": o.expansions,
+                      "segments": o.segments, "cost": o.cost, "total_time": o.total_time, "J": list(o.J),
+                      "wall_ms": o.wall_ms, "traj_checksum": chk[i]})
+    lp = np.array([st[4]], dtype=np.int64).view(np.float64)[0]
+    table = {"cells": st[0], "entries": st[1], "checksum": st[2], "linked_points": st[3], "points_checksum": float(lp),
+             "edited_cells": st[5], "get_linked_nodes_us": st[6], "update_cleared_us": st[7]}
+    return plans, table

@@ -395,3 +395,184 @@ extern "C" int mpl_ref_search_region(int32_t dim, const int32_t *map_dim, const 
   if (dim == 3) return ref_region<3, PrepPlanner<3>>(map_dim, origin, res, path, n_points, dense, search_radius, region_out);
   return -1;
 }
+
+/* ---- incremental re-planning: the reference's LPA* (PlannerBase::setLPAstar, graph_search.h:194-365) with a map
+ * edit between plans, through MapPlanner::getLinkedNodes / updateBlockedNodes / updateClearedNodes
+ * (map_planner.cpp:125-185) -- on MPL::MapPlanner (CPU) or MPL::GpuMapPlanner (edge work batched on the device). ---- */
+namespace {
+
+template <class Base>
+struct PeekPlanner : Base {  // lhm_ is protected
+  PeekPlanner() : Base(false) {}
+  using Base::lhm_;
+};
+
+template <int D, class PlannerT>
+int run_lpastar(const mpl_oracle_env *e, const double *start_row, const double *goal_row, int box_half,
+                mpl_ref_plan_out *out3, double *checksum3, int64_t *stats /* [8] */) {
+  std::shared_ptr<MPL::MapUtil<D>> mu = std::make_shared<MPL::MapUtil<D>>();
+  Vecf<D> ori;
+  Veci<D> dim;
+  size_t n = 1;
+  for (int i = 0; i < D; i++) { ori(i) = e->origin[i]; dim(i) = e->map_dim[i]; n *= (size_t)e->map_dim[i]; }
+  MPL::Tmap cells(e->map, e->map + n);
+  mu->setMap(ori, dim, cells, e->res);
+  vec_E<VecDf> U;
+  for (int i = 0; i < e->nU; i++) {
+    VecDf u(e->udim);
+    for (int k = 0; k < e->udim; k++) u(k) = e->U[(size_t)i * e->udim + k];
+    U.push_back(u);
+  }
+  auto load = [&](const double *r) {
+    Waypoint<D> w((Control::Control)e->control);
+    for (int i = 0; i < D; i++) { w.pos(i) = r[i]; w.vel(i) = r[D + i]; w.acc(i) = r[2 * D + i]; w.jrk(i) = r[3 * D + i]; }
+    w.yaw = r[4 * D];
+    w.t = r[4 * D + 1];
+    return w;
+  };
+  const Waypoint<D> start = load(start_row), goal = load(goal_row);
+  PlannerT pl;
+  pl.setMapUtil(mu);
+  pl.setVmax(e->v_max);
+  pl.setAmax(e->a_max);
+  pl.setJmax(e->j_max);
+  pl.setDt(e->dt);
+  pl.setW(e->w);
+  pl.setEpsilon(1.0);
+  pl.setU(U);
+  pl.setLPAstar(true);
+  for (int i = 0; i < 3; i++) { out3[i] = mpl_ref_plan_out{}; checksum3[i] = 0; }
+  for (int i = 0; i < 8; i++) stats[i] = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(now() - t0).count();
+  };
+  // ---- plan 1
+  auto t0 = now();
+  bool ok = pl.plan(start, goal);
+  fill_out<D>(pl, ok, ms_since(t0), 0, &out3[0], &checksum3[0]);
+  if (!ok) return 0;
+  // ---- the voxel -> edge table
+  t0 = now();
+  const vec_Vecf<D> linked = pl.getLinkedNodes();
+  stats[6] = (int64_t)(ms_since(t0) * 1000.0);  // microseconds
+  stats[0] = (int64_t)pl.lhm_.size();
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&h](uint64_t v) { h ^= v; h *= 1099511628211ull; };
+  int64_t entries = 0;
+  {
+    // order-independent over cells (the map's iteration order is an implementation detail), order-DEPENDENT
+    // within a cell (updateBlockedNodes / updateClearedNodes walk that vector front to back)
+    uint64_t acc = 0;
+    for (const auto &kv : pl.lhm_) {
+      h = 1469598103934665603ull;
+      mix((uint64_t)(int64_t)kv.first);
+      for (const auto &pr : kv.second) {
+        mix((uint64_t)hash_value(pr.first));
+        mix((uint64_t)pr.second);
+        entries++;
+      }
+      acc += h;
+    }
+    stats[2] = (int64_t)acc;
+  }
+  stats[1] = entries;
+  stats[3] = (int64_t)linked.size();
+  {
+    double c = 0;
+    size_t k = 1;
+    for (const auto &p : linked) {
+      for (int i = 0; i < D; i++) c += (double)((k * 2654435761u) % 1009) * p(i);
+      k++;
+    }
+    std::memcpy(&stats[4], &c, 8);
+  }
+  // ---- block a box of free cells around the middle of the trajectory
+  const Trajectory<D> traj = pl.getTraj();
+  const auto wps = traj.getWaypoints();
+  const Veci<D> mid = mu->floatToInt(wps[wps.size() / 2].pos);
+  const Veci<D> sc = mu->floatToInt(start.pos), gc = mu->floatToInt(goal.pos);
+  vec_Veci<D> edit;
+  {
+    Veci<D> pn;
+    const int w = 2 * box_half + 1;
+    int total = 1;
+    for (int i = 0; i < D; i++) total *= w;
+    for (int q = 0; q < total; q++) {
+      int r = q;
+      for (int i = 0; i < D; i++) { pn(i) = mid(i) + (r % w) - box_half; r /= w; }
+      if (mu->isOutside(pn) || !mu->isFree(pn)) continue;
+      bool keep = true;
+      for (int i = 0; i < D && keep; i++) keep = std::abs(pn(i) - sc(i)) > 2 || std::abs(pn(i) - gc(i)) > 2;
+      bool near_s = true, near_g = true;
+      for (int i = 0; i < D; i++) { near_s = near_s && std::abs(pn(i) - sc(i)) <= 2; near_g = near_g && std::abs(pn(i) - gc(i)) <= 2; }
+      if (near_s || near_g) continue;
+      edit.push_back(pn);
+    }
+  }
+  stats[5] = (int64_t)edit.size();
+  for (const auto &pn : edit) cells[(size_t)mu->getIndex(pn)] = 100;
+  mu->setMap(ori, dim, cells, e->res);
+  pl.updateBlockedNodes(edit);
+  t0 = now();
+  ok = pl.plan(start, goal);
+  fill_out<D>(pl, ok, ms_since(t0), 0, &out3[1], &checksum3[1]);
+  // ---- clear them again
+  pl.getLinkedNodes();  // the table of the grown graph
+  for (const auto &pn : edit) cells[(size_t)mu->getIndex(pn)] = 0;
+  mu->setMap(ori, dim, cells, e->res);
+  t0 = now();
+  pl.updateClearedNodes(edit);
+  stats[7] = (int64_t)(ms_since(t0) * 1000.0);
+  t0 = now();
+  ok = pl.plan(start, goal);
+  fill_out<D>(pl, ok, ms_since(t0), 0, &out3[2], &checksum3[2]);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mpl_ref_lpastar(const mpl_oracle_env *env, const double *start, const double *goal, int use_gpu,
+                               int box_half, mpl_ref_plan_out *out3, double *checksum3, int64_t *stats8) {
+  if (!env || !start || !goal || !out3 || !checksum3 || !stats8) return -1;
+  if (env->dim == 2) {
+    if (use_gpu) return run_lpastar<2, PeekPlanner<MPL::GpuMapPlanner<2>>>(env, start, goal, box_half, out3, checksum3, stats8);
+    return run_lpastar<2, PeekPlanner<MPL::MapPlanner<2>>>(env, start, goal, box_half, out3, checksum3, stats8);
+  }
+  if (env->dim == 3) {
+    if (use_gpu) return run_lpastar<3, PeekPlanner<MPL::GpuMapPlanner<3>>>(env, start, goal, box_half, out3, checksum3, stats8);
+    return run_lpastar<3, PeekPlanner<MPL::MapPlanner<3>>>(env, start, goal, box_half, out3, checksum3, stats8);
+  }
+  return -1;
+}
+
+/* ---- adapter robustness: a device failure must be distinguishable from "no trajectory" ---- */
+extern "C" int mpl_gpu_plan_on_device(const mpl_oracle_env *e, const double *start_row, const double *goal_row,
+                                      int device, int32_t *plan_ok, int32_t *device_ok, char *err, int err_cap) {
+  if (!e || e->dim != 2 || !plan_ok || !device_ok) return -1;
+  constexpr int D = 2;
+  std::shared_ptr<MPL::MapUtil<D>> mu = std::make_shared<MPL::MapUtil<D>>();
+  Vecf<D> ori;
+  Veci<D> dim;
+  size_t n = 1;
+  for (int i = 0; i < D; i++) { ori(i) = e->origin[i]; dim(i) = e->map_dim[i]; n *= (size_t)e->map_dim[i]; }
+  mu->setMap(ori, dim, MPL::Tmap(e->map, e->map + n), e->res);
+  MPL::GpuMapPlanner<D> pl(false, device, 1);
+  pl.setMapUtil(mu);
+  pl.setVmax(e->v_max);
+  pl.setAmax(e->a_max);
+  pl.setDt(e->dt);
+  vec_E<VecDf> U;
+  for (int i = 0; i < e->nU; i++) {
+    VecDf u(e->udim);
+    for (int k = 0; k < e->udim; k++) u(k) = e->U[(size_t)i * e->udim + k];
+    U.push_back(u);
+  }
+  pl.setU(U);
+  Waypoint<D> s((Control::Control)e->control), g((Control::Control)e->control);
+  for (int i = 0; i < D; i++) { s.pos(i) = start_row[i]; g.pos(i) = goal_row[i]; }
+  *plan_ok = pl.plan(s, g) ? 1 : 0;
+  *device_ok = pl.deviceOk() ? 1 : 0;
+  if (err && err_cap > 0) snprintf(err, (size_t)err_cap, "%s", pl.deviceError().c_str());
+  return 0;
+}
