@@ -37,7 +37,11 @@ def _lists_resident(env, nodes, want_state=False):
 
 
 def full_size_workload(engine, name):
-    wl = engine.workloads.make(name.split("-")[0])  # BASELINE.json size: full map, full frontier
+    # BASELINE.json size: full map, full frontier.  C5's potential map is made the way SURVEY 8(d) writes it: the
+    # reference-semantics MapPlanner::updatePotentialMap on the device (checked against the numpy restatement and the
+    # reference's own MapPlanner in test_c5_potential_map_is_made_on_the_device below)
+    W = engine.workloads
+    wl = W.make(name.split("-")[0], potential_fn=W.device_potential_fn(0) if name.startswith("C5") else None)
     if name == "C5-tunnel":
         # SURVEY 8(d)'s second C5 variant: a search region of radius 0.5 m around a straight start-goal path
         edge = wl.map_dim[0]
@@ -130,3 +134,27 @@ def test_full_size_c4_permutation_and_idempotence(engine):
         mask = np.arange(S)[None, :] < B["count"][:, None]
         assert np.array_equal(a[mask].view(np.uint64 if a.dtype.itemsize == 8 else a.dtype),
                               b[mask].view(np.uint64 if b.dtype.itemsize == 8 else b.dtype)), key
+
+
+def test_c5_potential_map_is_made_on_the_device(engine, oracle_lib):
+    """C5 end to end as SURVEY 8(d) specifies it: 256^3 occupancy map -> updatePotentialMap (map_planner.cpp:286-391,
+    radius 1 m, pow 1, global range) ON THE DEVICE -> the expansion.  The device map is bit-identical to the numpy
+    restatement at full size and to the reference's own MapPlanner::updatePotentialMap (oracle/_ref) at 128^3 (the
+    reference's scatter takes ~100 s at 256^3)."""
+    import time
+    W = engine.workloads
+    grid = W.box_map([256] * 3, 0.1, 0.15, 1005)
+    stats = {}
+    dev = W.device_potential_fn(0, stats)(grid, [0, 0, 0], 0.1, [1.0, 1.0, 1.0])
+    t0 = time.time()
+    host = W.potential_field(grid, 0.1, 1.0, 1.0)
+    t_host = time.time() - t0
+    assert np.array_equal(np.asarray(dev, np.int8).ravel(), host.ravel())
+    print("C5 potential map 256^3: %.1f ms on the device (H2D + kernels + D2H), %.1f s numpy restatement" % (
+        stats["potential_map_ms"], t_host))
+    assert 0 < np.count_nonzero((host > 0) & (host < 100)) < host.size
+    if os.path.exists(oracle_lib.REF_PLANNER_SO):
+        g2 = W.box_map([128] * 3, 0.1, 0.15, 1005)
+        d2 = W.device_potential_fn(0)(g2, [0, 0, 0], 0.1, [1.0, 1.0, 1.0])
+        ref = oracle_lib.update_potential_map(g2, [128] * 3, [0, 0, 0], 0.1, [0, 0, 0], [1, 1, 1], ref=True)
+        assert np.array_equal(np.asarray(d2, np.int8).ravel(), ref)
