@@ -1071,12 +1071,16 @@ hipError_t launch_grid_inst(const GridArgs &a, hipStream_t stream) {
   const int64_t n_wg = (a.n_nodes + kWPB - 1) / kWPB;
   const int64_t blocks = n_wg < (int64_t)a.grid_limit ? n_wg : (int64_t)a.grid_limit;
   const size_t lds = grid_lds_bytes(D, K, a.nU, a.ndp, a.n_max, a.rmax, a.boxcap, YAW ? (a.wyaw > 0 ? 2 : 1) : 0, a.ndy);
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the dynamic-LDS ceiling is a per-device attribute of the kernel: set it once per (instantiation, device), not
+  // once per process -- a second context on another GPU of the same process needs it too
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+  if (!attr_set[dev] || dev == 63) {
     hipError_t e = hipFuncSetAttribute((const void *)expand_grid_kernel<D, K, YAW, POT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL((expand_grid_kernel<D, K, YAW, POT>), dim3((unsigned)blocks), dim3(kBT), lds, stream, a);
   return hipGetLastError();

@@ -473,12 +473,14 @@ hipError_t launch_tile_inst(const TileArgs &a, hipStream_t stream) {
   const int64_t n_tiles = (a.n_nodes + a.npb - 1) / a.npb;
   const int64_t blocks = n_tiles < (int64_t)a.grid_limit ? n_tiles : (int64_t)a.grid_limit;
   const size_t lds = tile_lds_bytes(a.tile_pairs, a.npb, a.wl_cap, a.n_max, 4 * D + 2, a.nU * a.udim, nullptr);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};  // per device: see expand_grid_kernel.hip
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+  if (!attr_set[dev] || dev == 63) {
     hipError_t e = hipFuncSetAttribute((const void *)expand_tile_kernel<D, K, ONE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL((expand_tile_kernel<D, K, ONE>), dim3((unsigned)blocks), dim3(kBT), lds, stream, a);
   return hipGetLastError();
