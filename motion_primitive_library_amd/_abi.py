@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libmplx.so")
+LIB_PATH = os.environ.get("MPLX_LIB") or os.path.join(HERE, "csrc", "libmplx.so")  # MPLX_LIB: a diagnostic build
 
 OK = 0
 ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_STATE = -1, -2, -3, -4

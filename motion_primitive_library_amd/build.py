@@ -43,6 +43,18 @@ def is_stale():
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"]
 
 
+def build_variant(out_path, defines, verbose=False):
+    """A diagnostic build of the whole library with extra -D flags into `out_path` (never the in-tree libmplx.so):
+    e.g. build_variant(".../libmplx_pt.so", ["MPLX_PHASE_TIMING"]) for profiles/micro/phase_times.py."""
+    cmd = [hipcc_path()] + FLAGS + ["-D" + d for d in defines] + ["-shared", "-o", out_path] + SOURCES
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    proc = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n%s\n%s" % (proc.stdout, proc.stderr))
+    return out_path
+
+
 def build(force=False, verbose=False, jobs=None):
     """Compile libmplx.so if missing or older than its sources; returns its path.  One object per source
     (csrc/build/, git-ignored), compiled in parallel, only the stale ones; then one link."""
@@ -84,4 +96,9 @@ def build(force=False, verbose=False, jobs=None):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--define" in sys.argv:
+        i = sys.argv.index("--define")
+        out = sys.argv[sys.argv.index("--out") + 1]
+        print(build_variant(os.path.abspath(out), sys.argv[i + 1].split(","), verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -82,7 +82,7 @@ namespace mplx {
 // LDS carve-up, shared by host (size) and device (offsets).
 struct GridLds {
   // shared by the workgroup (read-only after set-up)
-  int o_uval, o_uidx, o_tc, o_wave0;
+  int o_uval, o_uidx, o_tc, o_tt, tt_rows, o_wave0;
   // per wave, relative to the wave's block
   int w_node, w_est, w_hp, w_eq, w_eflag, w_box, w_misc, w_rowmap, w_list, w_cell, wave_bytes;
   int o_uyaw, w_yaw, w_ycs, w_yq, w_hmask, w_vs, w_ycsr;  // yaw controls only
@@ -100,6 +100,11 @@ struct GridLds {
     o_uval = b; b += EN * 8;
     o_uidx = b; b += ((nU + 1) & ~1) * 2;  // 4 bits per axis
     o_tc = b; b += 64;
+    // the accumulated sample times of every sample count up to n_max (launch_make_tables), shared by the workgroup,
+    // when they fit 8 KiB: one global round trip less per pass of every node
+    b = (b + 7) & ~7;
+    tt_rows = ((n_max + 1) * tts * 8 <= 8192) ? n_max + 1 : 0;
+    o_tt = b; b += tt_rows * tts * 8;
     o_uyaw = b; b += ym ? 16 * 8 : 0;
     b = (b + 15) & ~15;
     o_wave0 = b;
@@ -129,6 +134,19 @@ struct GridLds {
     total = o_wave0 + waves * wave_bytes;
   }
 };
+
+#ifdef MPLX_PHASE_TIMING
+// Diagnostic build only (python -m motion_primitive_library_amd.build --define MPLX_PHASE_TIMING --out ...): shader
+// clock ticks spent between the phase markers of expand_grid_kernel, summed over all waves (profiles/micro/phase_times.py).
+__device__ unsigned long long g_phase_ticks[16];
+#define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PT(i) do { const unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
+#define PT_FLUSH do { if (lane == 0) for (int pi = 0; pi < 10; pi++) atomicAdd(&g_phase_ticks[pi], pt_acc[pi]); } while (0)
+#else
+#define PT_DECL
+#define PT(i)
+#define PT_FLUSH
+#endif
 
 namespace {
 
@@ -231,6 +249,10 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   constexpr int F = 4 * D + 2;
   const int nU = A.nU, ndp = A.ndp, RM = A.rmax;
   const bool ycost = YAW && A.wyaw > 0;  // env_map.h:121: per-sample heading cost
+  // gather mode: no box staging -- the sample loops read the blocked-bit map (L2) directly.  Staging pays when a
+  // node's pairs make many more look-ups than its box has rows (|U| = 729: ~5 200 samples against ~600 rows); with a
+  // small control table it is the other way round (|U| = 125: ~700 samples against up to 1 156 rows).
+  const bool gather = A.gather != 0;
   const int ndy = YAW ? A.ndy : 0;
   const GridLds L(D, K, kWPB, nU, ndp, A.n_max, RM, A.boxcap, YAW ? (ycost ? 2 : 1) : 0, ndy);
   const int lane = threadIdx.x & 63;
@@ -238,6 +260,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   const double *s_uval = (const double *)(smem + L.o_uval);
   const unsigned short *s_uidx = (const unsigned short *)(smem + L.o_uidx);
   const unsigned char *s_tc = smem + L.o_tc;
+  const double *s_tt = L.tt_rows ? (const double *)(smem + L.o_tt) : nullptr;  // [n][tts] sample times, or not resident
   unsigned char *wb = smem + L.o_wave0 + wv * L.wave_bytes;
   double *s_node = (double *)(wb + L.w_node);
   double *s_est = (double *)(wb + L.w_est);
@@ -282,6 +305,11 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
     }
     if (YAW && threadIdx.x < ndy) ((double *)(smem + L.o_uyaw))[threadIdx.x] = A.uvals[3 * 16 + threadIdx.x];
     if (threadIdx.x < 64) smem[L.o_tc + threadIdx.x] = A.tcnt[threadIdx.x];
+    double *tt = (double *)(smem + L.o_tt);
+    for (int i = threadIdx.x; i < L.tt_rows * L.tts; i += kBT) {
+      const int nn = i / L.tts, k = i - nn * L.tts;
+      tt[i] = A.ttab[nn * kTabStride + k];
+    }
   }
   __syncthreads();  // the only workgroup barrier
 
@@ -296,7 +324,9 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   if (wave_id < A.n_nodes && lane < F) nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(wave_id)];
   asm volatile("" ::"v"(nxt));  // arrived before the loop: no wait for it at the loop head (see the pin after phase A)
 
+  PT_DECL;
   for (int64_t it = wave_id; it < A.n_nodes; it += wave_stride) {
+    PT(9);  // (loop overhead / tail of the previous node)
     const int64_t node = node_of(it);
     const double *ytab = pinned ? A.yaw.tab + it * A.yaw.tab_stride : nullptr;  // [c0, s0, cT[16], sT[16]]
     bool yaw_amb = false;  // a heading-limit decision of this node is within rounding noise of the threshold
@@ -330,6 +360,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       }
     }
 
+    PT(0);
     // ---- phase T1: axis entries; the node's own lattice integers (lanes 48..)
     int flag = 0;
     if (lane < EN) {
@@ -377,8 +408,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
             }
           }
           if (K >= 3) { pmin = p - mv * T; pmax = p + mv * T; }
-          s_rb[lane * 2 + 0] = (int)floor((pmin - org[ax]) / A.res) - 1;
-          s_rb[lane * 2 + 1] = (int)floor((pmax - org[ax]) / A.res) + 1;
+          s_rb[lane * 2 + 0] = (int)floor(div_by(pmin - org[ax], A.res, A.Rres)) - 1;  // (same quotient as `/`)
+          s_rb[lane * 2 + 1] = (int)floor(div_by(pmax - org[ax], A.res, A.Rres)) + 1;
         }
         if (jv == 0) {
           // the node's own cell on this axis (map_util.h:103-108); the codes are offsets from it.
@@ -425,6 +456,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       }
     }
     wave_sync();
+    PT(1);
 
     // ---- prefix tables over the first D-1 axes
     for (int x = lane; x < PN; x += 64) {
@@ -484,6 +516,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       if (A.yaw.amb && __ballot(yaw_amb) != 0ull && lane == 0) flag_node(A.yaw.amb, A.yaw.amb_cap, node);
     }
     wave_sync();
+    PT(2);
 
     uint64_t hcur = 0;  // hash of the node, folded by every lane alike (no divergence)
 #pragma unroll
@@ -534,6 +567,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
 #pragma unroll
     for (int i = 0; i < 3; i++) base_c[i] = (i < D) ? __builtin_amdgcn_readfirstlane(s_misc[M_BASE + i]) : 0;
 
+    PT(3);
     // ---- phase A: every pair; ordered list of the emitted ones; sample counts in use.
     // When the control table enumerates its per-axis values in lexicographic order (A.ulex: the nested loops every
     // reference test builds U with, test/test_planner_2d.cpp:52-53), only the combinations of entries that pass
@@ -612,6 +646,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       safe = sat_inside && !ycost && __builtin_amdgcn_readfirstlane((int)term) == 0;
     }
 
+    PT(4);
     wave_prio(1);
     // ---- rounds of up to RM sample counts
     for (int pass = 0; pass == 0 || nm != 0ull; pass++) {
@@ -629,7 +664,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       nm &= ~sub;
       wave_sync();
       s_rowmap[lane] = ((sub >> lane) & 1ull) ? (unsigned char)__popcll(sub & ((1ull << lane) - 1ull)) : 0xff;
-      if (!safe) {
+      if (!safe && !s_tt) {
         // the accumulated sample times of this pass' rows: one global round trip for all of them
         const int n_sub = __popcll(sub);
         for (int i = lane; i < n_sub * tts; i += 64) {
@@ -641,6 +676,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         }
       }
       wave_sync();
+      PT(5);
       // rows: cell-offset codes of every axis entry at t_0 .. t_{cnt-1} of each sample count;
       // lanes = (value, k) of ONE axis at a time, so everything per axis is scalar
       int lo_l[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi_l[3] = {-1, -1, -1};  // per lane, reduced below
@@ -651,7 +687,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
           const int nn = __ffsll((long long)t) - 1;
           const int cn = (int)s_tc[nn];
           const float inv_cn = 1.0f / (float)cn;
-          const double *trow = s_trow + row * tts;
+          const double *trow = s_tt ? s_tt + nn * tts : s_trow + row * tts;
 #pragma unroll
           for (int ax = 0; ax < D; ax++) {
             const double p0 = s_node[0 * D + ax];
@@ -701,12 +737,13 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
           }
         }
       }
+      PT(6);
       // the box of codes the valid entries reach: butterfly min / max over the wave (no LDS
       // atomics: hipcc serialises a divergent LDS atomic into a 64-trip scalar loop)
       int lo[3] = {0, 0, 0}, nb[3] = {1, 1, 1};
-      bool have_box = true;
+      bool have_box = !gather;
 #pragma unroll
-      for (int i = 0; i < D; i++) {
+      for (int i = 0; i < D && !gather; i++) {
         int mn = lo_l[i], mx = hi_l[i];
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -762,6 +799,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         }
       }
       wave_sync();
+      PT(7);
 
       // ---- phase D: the list, 64 dense lanes at a time
       const int rowc = lo[1] + nb[1] * lo[2];
@@ -934,22 +972,32 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               }
             }
           } else {
-            // box too large for LDS: straight from the blocked-bit map, one sample per step
-            for (int k = 0; __ballot(!done) != 0ull; k++) {
-              if (!done) {
-                bool inside = true;
+            // straight from the blocked-bit map (gather mode, or a box too large for LDS): kUB samples per step,
+            // their look-ups in flight together -- one round trip to L2 per kUB samples
+            for (int k0 = 0; __ballot(!done) != 0ull; k0 += kUB) {
+              unsigned int wd[kUB];
+              int sh[kUB];
+#pragma unroll
+              for (int q = 0; q < kUB; q++) {
+                int k = k0 + q;
+                k = k < cntl ? k : (cntl > 0 ? cntl - 1 : 0);
+                bool inside = !done;
                 int64_t cell = 0, mul = 1;
 #pragma unroll
                 for (int i = 0; i < D; i++) {
-                  const int c = base_c[i] + (int)s_cell[ptr[i] + k] - half;
+                  const int c = base_c[i] + (done ? 0 : (int)s_cell[ptr[i] + k]) - half;
                   inside = inside && c >= 0 && c < dims[i];
                   cell += mul * c;
                   mul *= dims[i];
                 }
-                const bool blocked = !inside || ((A.blk[inside ? (cell >> 5) : 0] >> (cell & 31)) & 1u);
-                if (blocked) { fb = k; done = true; }
-                if (k + 1 >= cntl) done = true;
+                sh[q] = inside ? (int)(cell & 31) : -1;  // -1: outside the map = blocked (env_map.h:104)
+                wd[q] = A.blk[inside ? (cell >> 5) : 0];
               }
+#pragma unroll
+              for (int q = 0; q < kUB; q++) {
+                if (!done && k0 + q < cntl && (sh[q] < 0 || ((wd[q] >> sh[q]) & 1u))) { fb = k0 + q; done = true; }
+              }
+              if (k0 + kUB >= cntl) done = true;
             }
           }
         }
@@ -988,8 +1036,10 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         }
         wave_prio(1);
       }
+      PT(8);
     }
   }
+  PT_FLUSH;
 }
 
 // Summed-area table of the blocked-bit map: sat[z][y][x] (sizes d+1, zero border at index 0) = number of
@@ -1087,6 +1137,17 @@ hipError_t launch_grid_inst(const GridArgs &a, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef MPLX_PHASE_TIMING
+extern "C" int mplx_debug_phase_ticks(unsigned long long *out16, int reset) {
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_ticks), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap, int yaw_mode, int ndy) {
   return (size_t)GridLds(dim, order, kWPB, nU, ndp, n_max, rmax, boxcap, yaw_mode, ndy).total;

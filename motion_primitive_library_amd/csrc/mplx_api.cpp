@@ -116,6 +116,9 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
     c->tune.grid_rmax = env_int("MPLX_GRID_RMAX");
     c->tune.grid_boxcap = env_int("MPLX_GRID_BOXCAP");
     c->tune.grid_blocks = env_int("MPLX_GRID_BLOCKS");
+    c->tune.grid_waves_per_cu = env_int("MPLX_GRID_WAVES_PER_CU");
+    c->tune.grid_gather = getenv("MPLX_GRID_GATHER") ? env_int("MPLX_GRID_GATHER") : -1;
+    c->tune.grid_sat = getenv("MPLX_GRID_SAT") ? env_int("MPLX_GRID_SAT") : -1;
     c->tune.dbg = env_int("MPLX_TILE_DBG");
     c->tune.arena_kb = env_int("MPLX_ARENA_KB");
     c->tune.zero_copy = getenv("MPLX_ZERO_COPY") ? env_int("MPLX_ZERO_COPY") : 1;
@@ -428,6 +431,7 @@ TilePlan plan_tile(const mplx_ctx *c) {
 struct GridPlan {
   bool ok = false;
   int ndp = 1, n_max = 0, rmax = 0, boxcap = 0, grid = 0, order = 0;
+  bool gather = false, use_sat = true;
 };
 
 // Does the factorised kernel cover the current configuration, and how is it sized?
@@ -459,6 +463,17 @@ GridPlan plan_grid(const mplx_ctx *c) {
   int rmax = 4, boxcap = (c->dim == 3) ? (n_max + 3) * (n_max + 3) : 4 * (n_max + 3);
   if (boxcap < 64) boxcap = 64;
   if (boxcap > 1024) boxcap = 1024;
+  if (c->has_pot) boxcap = 64;  // potential maps are sampled from the int8 map itself: no staged bits (LDS buys occupancy)
+  // Gather mode (the sample loops read the blocked-bit map directly instead of staging the reach box in LDS): fewer
+  // look-ups than box rows for small control tables, yet slower in practice -- a look-up costs 35 instructions
+  // against 17 from LDS.
+  g.gather = false;  // measured slower than staging on C2 / C3 (profiles/README.md round 2): kept as a forced mode
+  if (c->tune.grid_gather >= 0) g.gather = c->tune.grid_gather != 0;
+  // Free-box query: exact reach boxes exist for K <= 2; for K = 3 the box is the conservative |p - p0| <= max_vel * T,
+  // rarely free, and the query is one more dependent round trip per node (C3: -6 % without it)
+  g.use_sat = (!g.gather || c->has_pot) && order <= 2;
+  if (c->tune.grid_sat >= 0) g.use_sat = c->tune.grid_sat != 0;
+  if (g.gather) boxcap = 64;
   if (c->tune.grid_rmax > 0) rmax = c->tune.grid_rmax;
   if (c->tune.grid_boxcap > 0) boxcap = c->tune.grid_boxcap;
   if (rmax < 1) rmax = 1;
@@ -469,7 +484,11 @@ GridPlan plan_grid(const mplx_ctx *c) {
   const int wpb = mplx::grid_waves_per_block();
   // 16 waves per CU is the measured optimum on C4: 20 fit the LDS, but the kernel needs 105 VGPRs (4 waves per
   // SIMD), and capped to 96 VGPRs with 20 waves resident it is 7-15 % slower (profiles/README.md)
-  if (per_cu * wpb > 16) per_cu = 16 / wpb;
+  {
+    const int cap = c->tune.grid_waves_per_cu > 0 ? c->tune.grid_waves_per_cu : 16;
+    if (per_cu * wpb > cap) per_cu = cap / wpb;
+    if (per_cu < 1) per_cu = 1;
+  }
   g.ok = true;
   g.ndp = ndp;
   g.n_max = n_max;
@@ -646,8 +665,9 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.pot_w = c->prm.potential_weight;
     const bool yaw = (c->prm.control & 0x10) != 0;
     // the free-box shortcut skips the sample loops, which a per-sample heading cost (wyaw > 0) still needs
-    a.sat = (c->sat_ok && gp.order <= 3 && !(yaw && c->prm.wyaw > 0) && !c->tune.no_sat)
+    a.sat = (c->sat_ok && gp.order <= 3 && !(yaw && c->prm.wyaw > 0) && !c->tune.no_sat && gp.use_sat)
                 ? (const uint32_t *)c->sat.p : nullptr;
+    a.gather = gp.gather ? 1 : 0;
     a.yaw_max = c->prm.yaw_max; a.wyaw = c->prm.wyaw; a.ndy = yaw ? c->u_nd[3] : 0;
     a.dim0 = c->mdim[0]; a.dim1 = c->mdim[1]; a.dim2 = c->mdim[2];
     a.org0 = c->origin[0]; a.org1 = c->origin[1]; a.org2 = c->origin[2];

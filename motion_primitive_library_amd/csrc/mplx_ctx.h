@@ -55,6 +55,8 @@ struct mplx_ctx {
   // for tests and profiling scripts; all off / automatic in production.
   struct Tuning {
     int grid_rmax = 0, grid_boxcap = 0, grid_blocks = 0;  // MPLX_GRID_RMAX / _BOXCAP / _BLOCKS (0 = automatic)
+    int grid_waves_per_cu = 0;                            // MPLX_GRID_WAVES_PER_CU: occupancy cap (0 = automatic)
+    int grid_gather = -1, grid_sat = -1;                  // MPLX_GRID_GATHER / MPLX_GRID_SAT: force 0 / 1 (-1 = automatic)
     int dbg = 0;                                         // MPLX_TILE_DBG ablation bits
     int zero_copy = 1;                                   // MPLX_ZERO_COPY=0: small batches through a device arena instead
     int arena_kb = 0;                                    // MPLX_ARENA_KB: largest batch served by the one-copy path

@@ -132,6 +132,7 @@ struct GridArgs {
   int32_t n_max;         // largest sample count n (<= 61)
   int32_t rmax;          // sample counts handled per round (rows of cell codes per axis entry)
   int32_t boxcap;        // dwords of LDS per wave for the staged blocked bits
+  int32_t gather;        // 1: no box staging, the sample loops read the blocked-bit map directly (small control tables)
   int32_t dbg;           // timing ablations (env MPLX_TILE_DBG); 0 in production
   int32_t grid_limit;    // persistent workgroups to launch
   const double *ttab;    // tables of launch_make_tables

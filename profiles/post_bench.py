@@ -47,6 +47,21 @@ for name, want_canon in (("heuristic + goal flags", False), ("heuristic + goal f
     out["post C4: " + name] = {"ms": ms, "successors": n_emit, "G successors/s": n_emit / ms / 1e6}
 first = int(np.count_nonzero(flags.download(np.uint8, (ns,)) & 4))
 out["post C4: unique lattice states"] = first
+# the same on the frontier with realistic locality (open list of a search): how many successors are FIRST occurrences,
+# i.e. what a fused "state only for first occurrences" store mode could save
+wf = m.workloads.wavefront_frontier(wl, wl.n_nodes, 0)
+fr2 = env.upload_frontier(wf)
+env.expand_lists_resident(fr2, lists)
+env.synchronize()
+n_emit_wf = int(lists.count.download(np.int32, (wl.n_nodes,)).sum(dtype=np.int64))
+o = _abi.Post()
+o.heur, o.flags, o.canon = heur.ptr, flags.ptr, canon.ptr
+_abi.check(env._ctx, L.mplx_memset(env._ctx, flags.ptr, 0, ns))
+_abi.check(env._ctx, L.mplx_post_lists_device(env._ctx, C.byref(s), wl.n_nodes, C.byref(g), C.byref(o)))
+env.synchronize()
+first_wf = int(np.count_nonzero(flags.download(np.uint8, (ns,)) & 4))
+out["post C4 wavefront frontier"] = {"successors": n_emit_wf, "unique lattice states": first_wf,
+                                     "first-occurrence share": first_wf / max(n_emit_wf, 1)}
 env.close()
 
 for edge in (256, 512):
