@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       }
       if (dead) {  // uniform
         if (lane == 0 && A.l_count) A.l_count[node] = 0;
-        if (lane == 0 && yaw_amb && A.yaw.amb) flag_node(A.yaw.amb, A.yaw.amb_cap, node);
+        if (lane == 0 && yaw_amb && A.yaw.amb) flag_node(A.yaw.amb, A.yaw.amb_cap, node, A.yaw.any_host);
         continue;
       }
     }
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         }
         s_hmask[j0 * ndp + j1] = (unsigned short)mask;
       }
-      if (A.yaw.amb && __ballot(yaw_amb) != 0ull && lane == 0) flag_node(A.yaw.amb, A.yaw.amb_cap, node);
+      if (A.yaw.amb && __ballot(yaw_amb) != 0ull && lane == 0) flag_node(A.yaw.amb, A.yaw.amb_cap, node, A.yaw.any_host);
     }
     wave_sync();
     PT(2);

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs A) {
     const bool okT = heading_ok(nvel[0], nvel[1], nyaw, cos_lim, tab ? tab + 2 + 2 * ci : nullptr, A.yaw.margin,
                                 A.yaw_max, &amb);
     valid = ok0 && okT;
-    if (amb && A.yaw.amb) mplx::dev::flag_node(A.yaw.amb, A.yaw.amb_cap, node);
+    if (amb && A.yaw.amb) mplx::dev::flag_node(A.yaw.amb, A.yaw.amb_cap, node, A.yaw.any_host);
   }
   if (K >= 2 && A.v_max > 0) {
 #pragma unroll

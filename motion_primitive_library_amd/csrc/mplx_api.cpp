@@ -144,6 +144,7 @@ void mplx_destroy(mplx_ctx *c) {
   release(c->comm_meta);
   c->yaw_pending.clear();
   for (DevBuf *b : {&c->yaw_ring, &c->yaw_ids, &c->yaw_tab}) release(*b);
+  if (c->yaw_any_host) (void)hipHostFree(c->yaw_any_host);
   mplx_detail::release_copy_buffers(c);
   release(c->s_arena);
   if (c->h_arena) (void)hipHostFree(c->h_arena);
@@ -521,11 +522,23 @@ int yaw_slot(mplx_ctx *c, mplx::YawPin *y) {
     if (int rc = ensure(c, c->yaw_ring, bytes)) return rc;
     HIP_TRY(c, hipMemsetAsync(c->yaw_ring.p, 0, bytes, c->stream));
   }
+  if (!c->yaw_any_host) {
+    HIP_TRY(c, hipHostMalloc((void **)&c->yaw_any_host, 64, hipHostMallocDefault));
+    *c->yaw_any_host = 0;
+  }
+  y->any_host = c->yaw_any_host;
   y->amb = (int32_t *)c->yaw_ring.p + c->yaw_pending.size() * (size_t)(1 + kAmbCap);
   y->amb_cap = kAmbCap;
   y->margin = c->tune.yaw_margin > 0 ? c->tune.yaw_margin : kYawMargin;
   return MPLX_OK;
 }
+
+// cos and sin of one heading the way the reference's binary gets them: primitive.h:519-520 calls cos(w.yaw) and
+// sin(w.yaw) in one expression, and GCC (the reference's compiler, at -O1 and above) fuses such a pair into ONE glibc
+// sincos() call.  glibc's sincos is not bit-identical to its separate sin() / cos() on every argument (measured: 2 of
+// 40 000 threshold headings, profiles/README.md round 2), so the pinning asks sincos() too.  cos(yaw_max) stands
+// alone in the reference (primitive.h:521) and stays a plain cos().
+void host_sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
 
 double host_wrap(double a) {  // mpl_basis/math.h:15-19
   while (a > M_PI) a -= 2.0 * M_PI;
@@ -561,21 +574,18 @@ int yaw_fix_pass(mplx_ctx *c, const mplx_ctx::YawPending &p, const int32_t *ids,
     double *t = &tab[(size_t)k * stride];
     const double cyaw = yaw[(size_t)k];
     const double y0 = host_wrap((0.0 + 0.0) + cyaw);  // the yaw polynomial at t = 0 (primitive.h:329, 128-145)
-    t[0] = std::cos(y0);
-    t[1] = std::sin(y0);
+    host_sincos(y0, &t[1], &t[0]);
     if (p.kind == 0) {
       // factorised kernel: [c0, s0, cT[16], sT[16]] over the distinct yaw rates
       for (int j = 0; j < c->u_nd[3] && j < 16; j++) {
         const double yT = host_wrap((0.0 + c->h_uyaw[j] * T) + cyaw);
-        t[2 + j] = std::cos(yT);
-        t[2 + 16 + j] = std::sin(yT);
+        host_sincos(yT, &t[2 + 16 + j], &t[2 + j]);
       }
     } else {
       // dense kernel: [c0, s0, {cT, sT} per control]
       for (int i = 0; i < c->nU; i++) {
         const double yT = host_wrap((0.0 + c->h_U[(size_t)i * c->udim + D] * T) + cyaw);
-        t[2 + 2 * i] = std::cos(yT);
-        t[2 + 2 * i + 1] = std::sin(yT);
+        host_sincos(yT, &t[2 + 2 * i + 1], &t[2 + 2 * i]);
       }
     }
   }
@@ -781,6 +791,13 @@ int resolve_pending(mplx_ctx *c) {
   if (c->yaw_pending.empty()) return MPLX_OK;
   MPLX_GUARD_BEGIN
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->yaw_any_host && *(volatile int32_t *)c->yaw_any_host == 0) {
+    // nothing was flagged by any launch since the last resolve (the common case: the kernels set this pinned word
+    // themselves): the lists are final as they are, no copy, no second synchronisation
+    c->yaw_pending.clear();
+    return MPLX_OK;
+  }
+  if (c->yaw_any_host) *c->yaw_any_host = 0;
   const size_t np = c->yaw_pending.size(), slot = (size_t)(1 + kAmbCap);
   std::vector<int32_t> ring(np * slot);
   HIP_TRY(c, hipMemcpyAsync(ring.data(), c->yaw_ring.p, ring.size() * 4, hipMemcpyDeviceToHost, c->stream));

@@ -97,6 +97,7 @@ struct mplx_ctx {
     mplx::ExpandArgs e{};
   };
   std::vector<YawPending> yaw_pending;
+  int32_t *yaw_any_host = nullptr;  // pinned word: some launch since the last resolve flagged a node
   mplx_detail::DevBuf yaw_ring, yaw_ids, yaw_tab;  // flagged nodes per pending launch; node list + trig table of a fix pass
   std::vector<double> h_U;          // host copy of the control table (the fix pass needs the yaw rates)
   double h_uyaw[16] = {0};          // ... and of its distinct yaw rates, in the factorisation's order

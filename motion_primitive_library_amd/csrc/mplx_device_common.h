@@ -51,9 +51,10 @@ __device__ __forceinline__ bool near_limit(double d, double cos_lim, double marg
   if (vy == 0 && fabs(yaw) == yaw_max) return false;
   return fabs(d - cos_lim) <= margin;
 }
-__device__ __forceinline__ void flag_node(int32_t *amb, int cap, int64_t node) {
+__device__ __forceinline__ void flag_node(int32_t *amb, int cap, int64_t node, int32_t *any_host) {
   const int k = atomicAdd(&amb[0], 1);
   if (k < cap) amb[1 + k] = (int32_t)node;
+  if (any_host) __hip_atomic_store(any_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int D, int K>

@@ -20,6 +20,8 @@ namespace mplx {
 // COST (env_map.h:121-129) keeps device trig: it is continuous and held to north_star's 1e-6.
 struct YawPin {
   int32_t *amb;               // detection: [0] = number of flagged nodes, [1 .. cap] their indices; null = off
+  int32_t *any_host;          // detection: a word of pinned host memory set to 1 by any flagging wave (plain store), so
+                              // that the host learns "nothing flagged" from its own memory, without a copy
   int32_t amb_cap;
   double margin;
   const int32_t *node_list;   // override pass: the nodes to re-expand (kernel node k -> node_list[k]); null = all

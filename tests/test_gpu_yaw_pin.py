@@ -23,7 +23,10 @@ def threshold_world(engine, n_each=1500, seed=3):
     """2D ACCxYAW on an empty map; nodes whose heading-limit decisions sit within a few ulp of the threshold."""
     m = engine
     rng = np.random.default_rng(seed)
-    yaw, yaw_max = 0.3, 0.5
+    # a different heading per node: the device's cos / sin differ from glibc's on ~3 % of arguments, so with many
+    # distinct arguments some of the decisions below really do depend on whose libm is asked
+    yaw_max = 0.5
+    yaw = np.round(rng.uniform(-2.6, 2.6, size=2 * n_each), 3)
     U = m.workloads.grid_controls([-1.0, 0.0, 1.0], 2, yaw_rates=[-0.5, 0.0, 0.5])
     delta = rng.integers(-48, 49, size=2 * n_each) * 2.0 ** -55       # a few ulp of an angle near 0.8
     sign = rng.choice([-1.0, 1.0], size=2 * n_each)                   # either side of the heading
@@ -35,8 +38,10 @@ def threshold_world(engine, n_each=1500, seed=3):
     nodes[1] = rng.uniform(8.0, 12.0, size=2 * n_each).round(2)
     # first half: the node's own velocity is on the threshold (decision at t = 0, the same for every control)
     nodes[2:4, :n_each] = w[:, :n_each]
-    # second half: vel(T) = v + u is on the threshold for u = (-1, 0), yaw rate 0, while vel(0) passes clearly
-    nodes[2:4, n_each:] = w[:, n_each:] + np.array([[1.0], [0.0]])
+    # second half: vel(T) = v + u is on the threshold for the control u = -round(heading direction), yaw rate 0, while
+    # vel(0) = v = w - u leans towards the heading and passes
+    e = np.stack([np.cos(yaw[n_each:]), np.sin(yaw[n_each:])])
+    nodes[2:4, n_each:] = w[:, n_each:] + np.round(e)
     nodes[8] = yaw
     nodes[9] = np.arange(2 * n_each) % 7
     grid = np.zeros((200, 200), np.int8)
