@@ -323,10 +323,51 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   double nxt = 0.0;  // lanes < F: one field of the next node (prefetched)
   if (wave_id < A.n_nodes && lane < F) nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(wave_id)];
   asm volatile("" ::"v"(nxt));  // arrived before the loop: no wait for it at the loop head (see the pin after phase A)
+  // ---- node assignment.  Static: wave w takes nodes w, w + W, ...  Dynamic (GridArgs::work): chunks of `ck` nodes;
+  // chunk w is wave w's, the later ones are claimed from this workgroup's counter.  The chunk after the current one is
+  // always claimed already (its first node is being prefetched), so the atomic's round trip is never waited for.
+  const bool dyn = A.work != nullptr;
+  const int64_t ck = dyn ? A.work_chunk : 1;
+  int64_t dyn_beg = 0, dyn_len = 0;  // this counter's share of the claimable chunks
+  unsigned int *ctr = nullptr;
+  if (dyn) {
+    if (blockIdx.x == 0 && threadIdx.x < kWorkCounters) A.work_zero[threadIdx.x * 32] = 0u;  // for the next launch
+    const int64_t n_chunks = (A.n_nodes + ck - 1) / ck, n_dyn = n_chunks > wave_stride ? n_chunks - wave_stride : 0;
+    const int cx = (int)(blockIdx.x % kWorkCounters);
+    const int64_t base = n_dyn / kWorkCounters, rem = n_dyn % kWorkCounters;
+    dyn_beg = wave_stride + cx * base + (cx < rem ? cx : rem);
+    dyn_len = base + (cx < rem ? 1 : 0);
+    ctr = A.work + cx * 32;
+  }
+  auto claim = [&]() -> int64_t {  // first node of the next chunk of this counter, or past the end
+    unsigned int v = 0;
+    if (lane == 0) v = atomicAdd(ctr, 1u);
+    const int64_t j = (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+    return j < dyn_len ? (dyn_beg + j) * ck : A.n_nodes;
+  };
+  int64_t it0 = dyn ? wave_id * ck : wave_id;
+  int64_t chunk_end = dyn ? (it0 + ck < A.n_nodes ? it0 + ck : A.n_nodes) : 0;
+  int64_t next_chunk = A.n_nodes;  // (dynamic) first node of the chunk claimed ahead
+  if (dyn && it0 < A.n_nodes) next_chunk = claim();
+  if (dyn) {  // the first node of a dynamic launch is wave_id * ck, not wave_id: redo the prefetch
+    nxt = 0.0;
+    if (it0 < A.n_nodes && lane < F) nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(it0)];
+    asm volatile("" ::"v"(nxt));
+  }
+  int64_t it_next = 0;
 
   PT_DECL;
-  for (int64_t it = wave_id; it < A.n_nodes; it += wave_stride) {
+  for (int64_t it = it0; it < A.n_nodes; it = it_next) {
     PT(9);  // (loop overhead / tail of the previous node)
+    if (!dyn) {
+      it_next = it + wave_stride;
+    } else if (it + 1 < chunk_end) {
+      it_next = it + 1;
+    } else {  // last node of the chunk: move on to the chunk claimed ahead and claim the one after it
+      it_next = next_chunk;
+      chunk_end = it_next + ck < A.n_nodes ? it_next + ck : A.n_nodes;
+      next_chunk = it_next < A.n_nodes ? claim() : A.n_nodes;
+    }
     const int64_t node = node_of(it);
     const double *ytab = pinned ? A.yaw.tab + it * A.yaw.tab_stride : nullptr;  // [c0, s0, cT[16], sT[16]]
     bool yaw_amb = false;  // a heading-limit decision of this node is within rounding noise of the threshold
@@ -334,8 +375,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
     wave_prio(0);
     wave_sync();
     if (lane < F) s_node[lane] = nxt;
-    if (it + wave_stride < A.n_nodes && lane < F)
-      nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(it + wave_stride)];
+    if (it_next < A.n_nodes && lane < F)
+      nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(it_next)];
     if (lane < 2) s_misc[M_NMASK + lane] = 0;
     wave_sync();
 
@@ -738,21 +779,14 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         }
       }
       PT(6);
-      // the box of codes the valid entries reach: butterfly min / max over the wave (no LDS
-      // atomics: hipcc serialises a divergent LDS atomic into a 64-trip scalar loop)
+      // the box of codes the valid entries reach: DPP min / max over the wave (no LDS atomics: hipcc serialises
+      // a divergent LDS atomic into a 64-trip scalar loop; no ds_bpermute butterfly: 36 dependent LDS round trips)
       int lo[3] = {0, 0, 0}, nb[3] = {1, 1, 1};
       bool have_box = !gather;
 #pragma unroll
       for (int i = 0; i < D && !gather; i++) {
-        int mn = lo_l[i], mx = hi_l[i];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int omn = __shfl_xor(mn, d, 64), omx = __shfl_xor(mx, d, 64);
-          mn = omn < mn ? omn : mn;
-          mx = omx > mx ? omx : mx;
-        }
-        lo[i] = __builtin_amdgcn_readfirstlane(mn);
-        const int hi = __builtin_amdgcn_readfirstlane(mx);
+        lo[i] = wave_reduce_minmax<false>(lo_l[i]);
+        const int hi = wave_reduce_minmax<true>(hi_l[i]);
         if (hi < lo[i]) have_box = false;
         nb[i] = hi - lo[i] + 1;
       }

@@ -29,6 +29,7 @@ std::string &create_error() {
 namespace {
 
 int yaw_slot(mplx_ctx *c, mplx::YawPin *y);  // yaw pinning, defined with the lists route below
+int grid_work(mplx_ctx *c, mplx::GridArgs *a);
 
 bool control_ok(int32_t control) {
   switch (control) {
@@ -117,6 +118,8 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
     c->tune.grid_boxcap = env_int("MPLX_GRID_BOXCAP");
     c->tune.grid_blocks = env_int("MPLX_GRID_BLOCKS");
     c->tune.grid_waves_per_cu = env_int("MPLX_GRID_WAVES_PER_CU");
+    c->tune.grid_static = getenv("MPLX_GRID_STATIC") != nullptr;
+    c->tune.grid_chunk = env_int("MPLX_GRID_CHUNK");
     c->tune.grid_gather = getenv("MPLX_GRID_GATHER") ? env_int("MPLX_GRID_GATHER") : -1;
     c->tune.grid_sat = getenv("MPLX_GRID_SAT") ? env_int("MPLX_GRID_SAT") : -1;
     c->tune.dbg = env_int("MPLX_TILE_DBG");
@@ -143,7 +146,7 @@ void mplx_destroy(mplx_ctx *c) {
   (void)mplx_comm_destroy(c);
   release(c->comm_meta);
   c->yaw_pending.clear();
-  for (DevBuf *b : {&c->yaw_ring, &c->yaw_ids, &c->yaw_tab}) release(*b);
+  for (DevBuf *b : {&c->yaw_ring, &c->yaw_ids, &c->yaw_tab, &c->work_counter}) release(*b);
   if (c->yaw_any_host) (void)hipHostFree(c->yaw_any_host);
   mplx_detail::release_copy_buffers(c);
   release(c->s_arena);
@@ -501,6 +504,34 @@ GridPlan plan_grid(const mplx_ctx *c) {
   return g;
 }
 
+// Dynamic node assignment of the factorised kernel (GridArgs::work): two sets of counters in the context, used
+// alternately; a launch finds its set zero and zeroes the other one for the next launch.
+int grid_work(mplx_ctx *c, mplx::GridArgs *a) {
+  a->work = nullptr;
+  a->work_zero = nullptr;
+  a->work_chunk = 1;
+  const int64_t wpb = mplx::grid_waves_per_block();
+  const int64_t n_wg = (a->n_nodes + wpb - 1) / wpb;
+  const int64_t W = (n_wg < (int64_t)a->grid_limit ? n_wg : (int64_t)a->grid_limit) * wpb;
+  if (c->tune.grid_static || a->n_nodes <= W) return MPLX_OK;  // one node per wave at most: nothing to balance
+  const size_t set_bytes = (size_t)mplx::kWorkCounters * 128;
+  if (!c->work_counter.p) {
+    if (int rc = ensure(c, c->work_counter, 2 * set_bytes)) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->work_counter.p, 0, 2 * set_bytes, c->stream));
+    c->work_parity = 0;
+  }
+  a->work = (unsigned int *)((char *)c->work_counter.p + (c->work_parity ? set_bytes : 0));
+  a->work_zero = (unsigned int *)((char *)c->work_counter.p + (c->work_parity ? 0 : set_bytes));
+  c->work_parity ^= 1;
+  // chunk: whole nodes per claim; 1 while a wave gets fewer than ~16 nodes (balance matters most), more beyond
+  int64_t per_wave = a->n_nodes / W, ck = per_wave / 16;
+  if (ck < 1) ck = 1;
+  if (ck > 8) ck = 8;
+  if (c->tune.grid_chunk > 0) ck = c->tune.grid_chunk;
+  a->work_chunk = (int32_t)ck;
+  return MPLX_OK;
+}
+
 // ---------------------------------------------------------------- yaw pinning (YawPin, mplx_internal.h)
 constexpr int kAmbCap = 1023;          // flagged nodes recorded per launch; beyond that the whole launch is re-checked
 constexpr int kYawRing = 32;           // launches that may wait for their check
@@ -602,6 +633,7 @@ int yaw_fix_pass(mplx_ctx *c, const mplx_ctx::YawPending &p, const int32_t *ids,
     mplx::GridArgs a = p.g;
     a.n_nodes = n;
     a.yaw = y;
+    if (int rc = grid_work(c, &a)) return rc;
     HIP_TRY(c, mplx::launch_expand_grid(c->dim, c->prm.control, a, c->stream));
   } else {
     mplx::ExpandArgs a = p.e;
@@ -701,6 +733,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.l_nstride = o->node_stride ? o->node_stride : c->nU;
     a.l_pad = (a.l_nstride % 32 == 0 && !c->tune.no_line_pad) ? 1 : 0;  // see expand_grid_kernel.hip
     if (int rc = yaw_slot(c, &a.yaw)) return rc;
+    if (int rc = grid_work(c, &a)) return rc;
     HIP_TRY(c, mplx::launch_expand_grid(c->dim, c->prm.control, a, c->stream));
     if (a.yaw.amb) {
       mplx_ctx::YawPending p;

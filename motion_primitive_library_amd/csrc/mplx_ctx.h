@@ -57,6 +57,8 @@ struct mplx_ctx {
     int grid_rmax = 0, grid_boxcap = 0, grid_blocks = 0;  // MPLX_GRID_RMAX / _BOXCAP / _BLOCKS (0 = automatic)
     int grid_waves_per_cu = 0;                            // MPLX_GRID_WAVES_PER_CU: occupancy cap (0 = automatic)
     int grid_gather = -1, grid_sat = -1;                  // MPLX_GRID_GATHER / MPLX_GRID_SAT: force 0 / 1 (-1 = automatic)
+    bool grid_static = false;                             // MPLX_GRID_STATIC: static node striding instead of the work counters
+    int grid_chunk = 0;                                   // MPLX_GRID_CHUNK: nodes per claim (0 = automatic)
     int dbg = 0;                                         // MPLX_TILE_DBG ablation bits
     int zero_copy = 1;                                   // MPLX_ZERO_COPY=0: small batches through a device arena instead
     int arena_kb = 0;                                    // MPLX_ARENA_KB: largest batch served by the one-copy path
@@ -102,6 +104,8 @@ struct mplx_ctx {
   std::vector<double> h_U;          // host copy of the control table (the fix pass needs the yaw rates)
   double h_uyaw[16] = {0};          // ... and of its distinct yaw rates, in the factorisation's order
   int64_t yaw_flagged = 0, yaw_fix_passes = 0;  // statistics (mplx_yaw_pin_stats)
+  mplx_detail::DevBuf work_counter;       // dynamic node assignment of the factorised kernel (GridArgs::work)
+  int work_parity = 0;                    // which of the two counter sets the next launch uses
   // RCCL communicator of this context (comm_api.cpp); the library is loaded on first use
   void *comm = nullptr;
   int comm_rank = 0, comm_world = 1;

@@ -40,6 +40,24 @@ __device__ __forceinline__ int quantise(double x, double q, double Rq) {
   return (int)round(div_by(x, q, Rq));
 }
 
+// ---- wave-wide min / max of an int over all 64 lanes (all lanes must be active), result uniform.  Seven DPP moves
+// (row_shr 1, 2, 3, 4, 8, row_bcast 15, 31: the gfx9 cross-lane reduction) instead of six rounds of ds_bpermute -- no
+// trip through the LDS crossbar, no dependent ~100-cycle waits.
+template <bool MAX>
+__device__ __forceinline__ int wave_reduce_minmax(int v) {
+  const int id = MAX ? (int)0x80000000 : 0x7fffffff;
+  auto op = [](int a, int b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+  int x = v;
+  x = op(x, __builtin_amdgcn_update_dpp(id, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+  x = op(x, __builtin_amdgcn_update_dpp(id, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+  x = op(x, __builtin_amdgcn_update_dpp(id, v, 0x113, 0xf, 0xf, false));  // row_shr:3
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x114, 0xf, 0xe, false));  // row_shr:4, banks 1-3
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x118, 0xf, 0xc, false));  // row_shr:8, banks 2-3: lane 15 of a row = the row
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1, 3
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2, 3: lane 63 = the wave
+  return __builtin_amdgcn_readlane(x, 63);
+}
+
 // ---- yaw pinning (YawPin, mplx_internal.h): is the heading-limit decision `d < cos_lim` of validate_yaw
 // (primitive.h:504-525) within rounding noise of its threshold?  One case is exempt because it is an exact tie under
 // ANY libm with an even cosine: velocity along x (vy == 0: the y term is an exact zero and vx / |v| is exactly +-1)

@@ -135,6 +135,16 @@ struct GridArgs {
   int32_t rmax;          // sample counts handled per round (rows of cell codes per axis entry)
   int32_t boxcap;        // dwords of LDS per wave for the staged blocked bits
   int32_t gather;        // 1: no box staging, the sample loops read the blocked-bit map directly (small control tables)
+  // Dynamic node assignment (work == null: static striding).  Nodes differ a lot in work (dead at t = 0, free box, one
+  // or several passes), and with a static assignment the waves lived only 46 % (C5) - 83 % (C4) of the kernel's
+  // duration (SQ_WAVE_CYCLES against SQ_BUSY_CYCLES).  Chunks of work_chunk nodes: chunk w < W (the waves launched)
+  // belongs to wave w, the others are claimed from kWorkCounters counters (a single counter serialises at ~15 ns per
+  // claim: measured 3 x slower than static), counter blockIdx % kWorkCounters owning an equal share of them; each
+  // counter sits on its own 128-byte line.  `work` is zero when the launch begins; the launch zeroes `work_zero`, the
+  // set the NEXT launch of the stream will use (ping-pong: no memset, no bookkeeping between launches).
+  unsigned int *work;
+  unsigned int *work_zero;
+  int32_t work_chunk;
   int32_t dbg;           // timing ablations (env MPLX_TILE_DBG); 0 in production
   int32_t grid_limit;    // persistent workgroups to launch
   const double *ttab;    // tables of launch_make_tables
@@ -151,6 +161,7 @@ struct GridArgs {
   int32_t l_pad;      // 1: complete the last 128-byte line of every list row (node stride is a multiple of 32)
   YawPin yaw;         // heading-limit decisions pinned to the host libm (see YawPin); tab row: [c0, s0, cT[16], sT[16]]
 };
+constexpr int kWorkCounters = 64;
 // Packing of the used list prefixes for the copy back to the host (pack_kernel.hip).
 constexpr int kPackRows = 24;
 struct PackArgs {
