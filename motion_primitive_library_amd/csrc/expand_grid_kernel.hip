@@ -100,11 +100,11 @@ struct GridLds {
     o_uval = b; b += EN * 8;
     o_uidx = b; b += ((nU + 1) & ~1) * 2;  // 4 bits per axis
     o_tc = b; b += 64;
-    // the accumulated sample times of every sample count up to n_max (launch_make_tables), shared by the workgroup,
-    // when they fit 8 KiB: one global round trip less per pass of every node
+    // (tried in round 2: the sample-time rows of every n <= n_max resident in shared LDS, to save the per-pass round
+    // trip to the global table -- no measurable gain on any configuration, 3.9 KB per workgroup at C4: not kept)
     b = (b + 7) & ~7;
-    tt_rows = ((n_max + 1) * tts * 8 <= 8192) ? n_max + 1 : 0;
-    o_tt = b; b += tt_rows * tts * 8;
+    tt_rows = 0;
+    o_tt = b;
     o_uyaw = b; b += ym ? 16 * 8 : 0;
     b = (b + 15) & ~15;
     o_wave0 = b;
