@@ -251,12 +251,10 @@ def ref_plan(env, start_row, goal_row, use_gpu=False, epsilon=1.0, reps=1):
     """Runs the reference's unmodified MapPlanner<Dim>::plan (A*).  use_gpu=True
     swaps in MPL::GpuMapPlanner from include/mplx_env_map.hpp (the drop-in
     adapter over libmplx.so) -- needs a GPU."""
-    if "ref_planner" not in _LIBS:
-        lib = C.CDLL(REF_PLANNER_SO)
-        lib.mpl_ref_plan.restype = C.c_int
-        lib.mpl_ref_plan.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int,
-                                     C.POINTER(RefPlanOut)]
-        _LIBS["ref_planner"] = lib
+    lib = _LIBS.setdefault("ref_planner", C.CDLL(REF_PLANNER_SO))
+    lib.mpl_ref_plan.restype = C.c_int
+    lib.mpl_ref_plan.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int,
+                                 C.POINTER(RefPlanOut)]
     s = np.ascontiguousarray(start_row, dtype=np.float64)
     g = np.ascontiguousarray(goal_row, dtype=np.float64)
     out = RefPlanOut()
