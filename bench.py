@@ -349,6 +349,11 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the engine has no CPU fallback")
+    # MPLX_BENCH_BACKEND=gloo (diagnostic): several ranks may then share one GPU -- RCCL refuses two ranks on one device,
+    # gloo moves CUDA tensors through the host -- so the whole N > 1 flow can be rehearsed on a one-GPU box
+    backend = os.environ.get("MPLX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     # MPLX_BENCH_FORCE_DIST=1 runs the N > 1 code path (RCCL init, barrier, all-reduce of the timing, the list
     # gather) with whatever world size the launcher gave, including 1 -- the only way to exercise it on a one-GPU box
@@ -357,7 +362,10 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- the workload; rank r owns block r of ITS frontier
     stats = {}
