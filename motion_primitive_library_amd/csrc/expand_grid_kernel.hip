@@ -84,7 +84,7 @@ struct GridLds {
   // shared by the workgroup (read-only after set-up)
   int o_uval, o_uidx, o_tc, o_tt, tt_rows, o_wave0;
   // per wave, relative to the wave's block
-  int w_node, w_est, w_hp, w_eq, w_eflag, w_box, w_misc, w_rowmap, w_list, w_cell, wave_bytes;
+  int w_node, w_est, w_hp, w_eq, w_eflag, w_box, w_misc, w_rowmap, w_list, w_cell, w_uq, wave_bytes;
   int o_uyaw, w_yaw, w_ycs, w_yq, w_hmask, w_vs, w_ycsr;  // yaw controls only
   int total;
   int F, EN, PN, tts, KQ;
@@ -123,6 +123,7 @@ struct GridLds {
     w_list = w; w += ((nU + 1) & ~1) * 2;
     w_cell = w; w += EN * rmax * tts + 8;  // + 8: the sample loop reads up to 7 codes past a row
     w = (w + 15) & ~15;
+    w_uq = w; w += K >= 3 ? EN * 8 : 0;         // per entry: the top coefficient's quotient (u / 6, u / 24) for the rows
     w_yaw = w; w += ym ? 16 * 8 : 0;            // yaw(T) per yaw value
     w_ycs = w; w += ym ? 16 * 16 : 0;           // cos, sin of yaw(T)
     w_yq = w; w += ym ? 16 * 4 : 0;             // lattice integer of yaw(T)
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   double *s_ycs = (double *)(wb + L.w_ycs);
   int *s_yq = (int *)(wb + L.w_yq);
   unsigned short *s_hmask = (unsigned short *)(wb + L.w_hmask);
+  double *s_uq = (double *)(wb + L.w_uq);
   double *s_vs = (double *)(wb + L.w_vs);
   double *s_ycsr = (double *)(wb + L.w_ycsr);
 
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         const double nj_ = q.template jrk<true>(T);
         // fields of order < K - 1; order K - 1 is (0.0 + u*T) + x0, order K is 0.0 + u, higher ones are 0
         // (primitive.h:128-145; the same expressions Ax<K>::pos/vel/acc/jrk<true> evaluate)
+        if (K >= 3) s_uq[lane] = q.top_quotient();
         if (K >= 2) s_est[lane * (K - 1) + 0] = np_;
         if (K >= 3) s_est[lane * (K - 1) + 1] = nv_;
         if (K >= 4) s_est[lane * (K - 1) + 2] = na_;
@@ -745,7 +748,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               Ax<K> q;
               q.init(p0, v0, a0, j0, s_uval[aj]);
               // map_util.h:103-108: cell = round((pos - origin) / res - 0.5)
-              const double qd = div_by(q.template pos<false>(trow[k]) - org[ax], A.res, A.Rres);
+              const double qd = div_by(q.pos_q(trow[k], K >= 3 ? s_uq[aj] : 0.0) - org[ax], A.res, A.Rres);
               // qd - 0.5 > -0.5 <=> the rounded cell is >= 0; then qd > 0 and (qd - 0.5 being exact
               // for qd >= 0.5) round-half-away(qd - 0.5) == trunc(qd).  Negative cells: see M_BASE.
               const int c = (qd - 0.5 > -0.5) ? (int)qd : -1;

@@ -117,6 +117,16 @@ struct Ax {
     if (EXACT) s = 0.0 + s;
     return (((s + (c2 / 6) * t3) + ((c3 / 2) * t) * t) + c4 * t) + c5;
   }
+  // pos<false>(t) with the quotient of the highest-order coefficient given (c2 / 6 for K = 3, c1 / 24 for K = 4): it
+  // depends only on the control value, so the row builder takes it from a per-entry table instead of dividing per
+  // sample (an f64 division by 6 is ~30 instructions; the value is the same one, so is the result)
+  __device__ __forceinline__ double pos_q(double t, double qtop) const {
+    if (K <= 2) return pos<false>(t);
+    if (K == 3) return ((qtop * ((t * t) * t) + ((c3 / 2) * t) * t) + c4 * t) + c5;
+    const double t3 = (t * t) * t;
+    return (((qtop * (t3 * t) + (c2 / 6) * t3) + ((c3 / 2) * t) * t) + c4 * t) + c5;
+  }
+  __device__ __forceinline__ double top_quotient() const { return K == 3 ? c2 / 6 : (K == 4 ? c1 / 24 : 0.0); }
   template <bool EXACT>
   __device__ __forceinline__ double vel(double t) const {
     double s;
