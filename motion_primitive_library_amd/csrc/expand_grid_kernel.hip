@@ -335,8 +335,9 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   if (dyn) {
     if (blockIdx.x == 0 && threadIdx.x < kWorkCounters) A.work_zero[threadIdx.x * 32] = 0u;  // for the next launch
     const int64_t n_chunks = (A.n_nodes + ck - 1) / ck, n_dyn = n_chunks > wave_stride ? n_chunks - wave_stride : 0;
-    const int cx = (int)(blockIdx.x % kWorkCounters);
-    const int64_t base = n_dyn / kWorkCounters, rem = n_dyn % kWorkCounters;
+    const int nc = gridDim.x < (unsigned)kWorkCounters ? (int)gridDim.x : kWorkCounters;  // counters in use
+    const int cx = (int)(blockIdx.x % nc);
+    const int64_t base = n_dyn / nc, rem = n_dyn % nc;
     dyn_beg = wave_stride + cx * base + (cx < rem ? cx : rem);
     dyn_len = base + (cx < rem ? 1 : 0);
     ctr = A.work + cx * 32;

@@ -30,6 +30,7 @@ namespace {
 
 int yaw_slot(mplx_ctx *c, mplx::YawPin *y);  // yaw pinning, defined with the lists route below
 int grid_work(mplx_ctx *c, mplx::GridArgs *a);
+int launch_grid(mplx_ctx *c, mplx::GridArgs *a);
 
 bool control_ok(int32_t control) {
   switch (control) {
@@ -522,13 +523,29 @@ int grid_work(mplx_ctx *c, mplx::GridArgs *a) {
   }
   a->work = (unsigned int *)((char *)c->work_counter.p + (c->work_parity ? set_bytes : 0));
   a->work_zero = (unsigned int *)((char *)c->work_counter.p + (c->work_parity ? 0 : set_bytes));
-  c->work_parity ^= 1;
+  // (the caller flips work_parity once the launch is enqueued: launch_grid below)
   // chunk: whole nodes per claim; 1 while a wave gets fewer than ~16 nodes (balance matters most), more beyond
   int64_t per_wave = a->n_nodes / W, ck = per_wave / 16;
   if (ck < 1) ck = 1;
   if (ck > 8) ck = 8;
   if (c->tune.grid_chunk > 0) ck = c->tune.grid_chunk;
   a->work_chunk = (int32_t)ck;
+  return MPLX_OK;
+}
+
+// Enqueues the factorised kernel.  The counter sets change hands only when the launch went in: a launch that failed
+// has not zeroed the other set, so the sets are dropped and made afresh (zeroed) on the next use.
+int launch_grid(mplx_ctx *c, mplx::GridArgs *a) {
+  if (int rc = grid_work(c, a)) return rc;
+  const hipError_t e = mplx::launch_expand_grid(c->dim, c->prm.control, *a, c->stream);
+  if (e != hipSuccess) {
+    if (a->work) {
+      (void)hipStreamSynchronize(c->stream);
+      release(c->work_counter);
+    }
+    return fail(c, MPLX_ERR_HIP, "expand_grid_kernel launch failed: %s", hipGetErrorString(e));
+  }
+  if (a->work) c->work_parity ^= 1;
   return MPLX_OK;
 }
 
@@ -633,8 +650,7 @@ int yaw_fix_pass(mplx_ctx *c, const mplx_ctx::YawPending &p, const int32_t *ids,
     mplx::GridArgs a = p.g;
     a.n_nodes = n;
     a.yaw = y;
-    if (int rc = grid_work(c, &a)) return rc;
-    HIP_TRY(c, mplx::launch_expand_grid(c->dim, c->prm.control, a, c->stream));
+    if (int rc = launch_grid(c, &a)) return rc;
   } else {
     mplx::ExpandArgs a = p.e;
     a.n_nodes = n;
@@ -733,8 +749,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.l_nstride = o->node_stride ? o->node_stride : c->nU;
     a.l_pad = (a.l_nstride % 32 == 0 && !c->tune.no_line_pad) ? 1 : 0;  // see expand_grid_kernel.hip
     if (int rc = yaw_slot(c, &a.yaw)) return rc;
-    if (int rc = grid_work(c, &a)) return rc;
-    HIP_TRY(c, mplx::launch_expand_grid(c->dim, c->prm.control, a, c->stream));
+    if (int rc = launch_grid(c, &a)) return rc;
     if (a.yaw.amb) {
       mplx_ctx::YawPending p;
       p.kind = 0;

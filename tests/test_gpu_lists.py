@@ -518,3 +518,39 @@ def test_tiny_and_lopsided_maps(engine, oracle_lib, dims, control):
         assert_lists_equal(got, ref, n_nodes, U.shape[0], cost_rtol=YAW_COST_RTOL if control & 0x10 else 0.0,
                            what="tiny map %s ctrl0x%x route %s" % (dims, control, route))
     env.close()
+
+
+@pytest.mark.parametrize("name,blocks,chunk", [("C2", "8", "1"), ("C2", "8", "3"), ("C2", "5", "8"), ("C5", "16", "2"),
+                                               ("C3", "7", "1"), ("C2", "8", "static")])
+def test_dynamic_node_assignment_small_grids_and_chunks(engine, oracle_lib, monkeypatch, name, blocks, chunk):
+    """The factorised kernel's waves claim nodes from counters (GridArgs::work): with few workgroups every wave walks
+    many chunks, chunk sizes that do not divide the frontier leave ragged last chunks, and consecutive launches swap
+    the two counter sets -- the lists must be the oracle's every time (and the same with static striding)."""
+    monkeypatch.setenv("MPLX_GRID_BLOCKS", blocks)
+    if chunk == "static":
+        monkeypatch.setenv("MPLX_GRID_STATIC", "1")
+    else:
+        monkeypatch.setenv("MPLX_GRID_CHUNK", chunk)
+    wl = engine.workloads.make(name, scale=0.25, n_nodes=2311)  # a prime: no chunk size divides it
+    nU = wl.U.shape[0]
+    env = engine_env(engine, wl)
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+    rtol = YAW_COST_RTOL if wl.control & 0x10 else 0.0
+    fr = env.upload_frontier(wl.nodes)
+    lists = env.alloc_lists(wl.n_nodes, want_state=True, want_iters=True)
+    for launch in range(4):  # both counter sets, twice
+        env.expand_lists_resident(fr, lists)
+        env.synchronize()
+        assert env.last_lists_route() == "grid"
+        assert_lists_equal(lists.download(), ref, wl.n_nodes, nU, cost_rtol=rtol,
+                           what="%s blocks %s chunk %s launch %d" % (name, blocks, chunk, launch))
+    # a shorter frontier in the same buffers right after: fewer claims than the launch before
+    env.expand_lists_resident(fr, lists, n_nodes=700)
+    env.synchronize()
+    got = lists.download()
+    got["count"] = got["count"][:700]
+    sub = {k: (v[:700 * nU] if k != "state" else v[:, :700 * nU]) for k, v in ref.items() if k != "stats"}
+    assert_lists_equal(got, sub, 700, nU, cost_rtol=rtol, what="%s shorter frontier" % name)
+    lists.free()
+    fr.free()
+    env.close()
