@@ -119,7 +119,7 @@ struct GridLds {
     w_box = w; w += (boxcap * 4 > rmax * tts * 8) ? boxcap * 4 : rmax * tts * 8;  // also the sample times while rows are built
     w = (w + 15) & ~15;
     w_misc = w; w += 40 * 4;
-    w_rowmap = w; w += 64;
+    w_rowmap = w; w += 64 * 2;  // per sample count n: offset of its row inside an entry's block this pass (0xffff: not this pass)
     w_list = w; w += ((nU + 1) & ~1) * 2;
     w_cell = w; w += EN * rmax * tts + 8;  // + 8: the sample loop reads up to 7 codes past a row
     w = (w + 15) & ~15;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   int *s_rb = (int *)(wb + L.w_box);  // [EN][2] reach ranges of the entries (live between T1 and the box query)
   double *s_trow = (double *)(wb + L.w_box);  // [RM][tts] sample times, live only while the rows are built
   int *s_misc = (int *)(wb + L.w_misc);
-  unsigned char *s_rowmap = wb + L.w_rowmap;
+  unsigned short *s_rowmap = (unsigned short *)(wb + L.w_rowmap);
   unsigned short *s_list = (unsigned short *)(wb + L.w_list);
   unsigned char *s_cell = wb + L.w_cell;
   const double *s_uyaw = (const double *)(smem + L.o_uyaw);
@@ -285,6 +285,11 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   double *s_ycsr = (double *)(wb + L.w_ycsr);
 
   const int tts = L.tts, EN = L.EN, PN = L.PN;
+  // Rows are PACKED: the row of sample count n takes tc[n] (= n or n + 1) slots, and a pass takes as many of the
+  // smallest pending counts as fit `rowcap` slots per entry -- with the fixed [RM][tts] layout of round 1 a pass held
+  // RM counts whatever their length, and a JRK node (counts 5 .. 31) needed ~3 passes, each of which re-runs the row
+  // builder, the box staging and a sparsely occupied sweep over the node's list.
+  const int rowcap = RM * tts;
   constexpr int KQ = K == 3 ? 4 : K;
   const int half = A.n_max + 2;  // cell-offset code = offset from the node's cell + half
   const double T = A.dt;
@@ -700,24 +705,36 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       if (safe) {
         sub = ~0ull;  // nothing to sample: every successor is handled in this one pass
       } else {
-        unsigned long long t = nm;
-        for (int r = 0; r < RM && t; r++) {
-          sub |= t & (~t + 1ull);
-          t &= t - 1ull;
+        int used = 0;  // slots taken so far (uniform)
+        for (unsigned long long t = nm; t; t &= t - 1ull) {
+          const int nn = __ffsll((long long)t) - 1;
+          const int cn = (int)s_tc[nn];
+          if (used + cn > rowcap && sub) break;  // (the first count always fits: cn <= tts <= rowcap)
+          sub |= 1ull << nn;
+          used += cn;
         }
       }
       nm &= ~sub;
       wave_sync();
-      s_rowmap[lane] = ((sub >> lane) & 1ull) ? (unsigned char)__popcll(sub & ((1ull << lane) - 1ull)) : 0xff;
-      if (!safe && !s_tt) {
-        // the accumulated sample times of this pass' rows: one global round trip for all of them
-        const int n_sub = __popcll(sub);
-        for (int i = lane; i < n_sub * tts; i += 64) {
-          const int row = i / tts, k = i - row * tts;
-          unsigned long long t = sub;
-          for (int r = 0; r < row; r++) t &= t - 1ull;
+      {
+        // offset of every selected count's row: slots of the selected counts below it
+        int off = 0;
+        unsigned short mine_off = 0xffff;
+        for (unsigned long long t = safe ? 0ull : sub; t; t &= t - 1ull) {
           const int nn = __ffsll((long long)t) - 1;
-          s_trow[i] = A.ttab[nn * kTabStride + k];
+          if (nn == lane) mine_off = (unsigned short)off;
+          off += (int)s_tc[nn];
+        }
+        s_rowmap[lane] = mine_off;
+      }
+      if (!safe && !s_tt) {
+        // the accumulated sample times of this pass' rows (independent loads: one round trip for all of them)
+        int off = 0;
+        for (unsigned long long t = sub; t; t &= t - 1ull) {
+          const int nn = __ffsll((long long)t) - 1;
+          const int cn = (int)s_tc[nn];
+          if (lane < cn) s_trow[off + lane] = A.ttab[nn * kTabStride + lane];
+          off += cn;
         }
       }
       wave_sync();
@@ -727,12 +744,12 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       int lo_l[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi_l[3] = {-1, -1, -1};  // per lane, reduced below
       bool ovf = false;
       {
-        int row = 0;
-        for (unsigned long long t = safe ? 0ull : sub; t; t &= t - 1ull, row++) {
+        int row = 0;  // slot offset of the row being built
+        for (unsigned long long t = safe ? 0ull : sub; t; t &= t - 1ull) {
           const int nn = __ffsll((long long)t) - 1;
           const int cn = (int)s_tc[nn];
           const float inv_cn = 1.0f / (float)cn;
-          const double *trow = s_tt ? s_tt + nn * tts : s_trow + row * tts;
+          const double *trow = s_tt ? s_tt + nn * tts : s_trow + row;
 #pragma unroll
           for (int ax = 0; ax < D; ax++) {
             const double p0 = s_node[0 * D + ax];
@@ -759,11 +776,11 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               // is checked and a pass with an escaped code samples by direct evaluation instead.
               const int code = c + shift;
               ovf = ovf || code < 0 || code > 2 * half;
-              s_cell[__umul24(__umul24(aj, RM) + row, tts) + k] = (unsigned char)code;
+              s_cell[__umul24(aj, rowcap) + row + k] = (unsigned char)code;
               lo_l[ax] = code < lo_l[ax] ? code : lo_l[ax];
               hi_l[ax] = code > hi_l[ax] ? code : hi_l[ax];
               if (YAW && ax < 2 && ycost)  // Waypoint::vel of the sample (primitive.h:321-331), x and y
-                s_vs[__umul24(__umul24(aj, RM) + row, tts) + k] = q.template vel<false>(trow[k]);
+                s_vs[__umul24(aj, rowcap) + row + k] = q.template vel<false>(trow[k]);
             }
           }
           if (YAW && ycost) {
@@ -773,13 +790,14 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
               const int jy = (int)(((float)x + 0.5f) * inv_cn);
               const int k = x - __umul24(jy, cn);
               const double yw = wrap_angle(s_uyaw[jy] * trow[k] + cyaw);
-              double *o = s_ycsr + (__umul24(__umul24(jy, RM) + row, tts) + k) * 2;
+              double *o = s_ycsr + (__umul24(jy, rowcap) + row + k) * 2;
               double sn_, cs_;
               sincos(yw, &sn_, &cs_);
               o[0] = cs_;
               o[1] = sn_;
             }
           }
+          row += cn;
         }
       }
       PT(6);
@@ -895,14 +913,14 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         int fb = -1;                              // first blocked sample
         double csum = 0.0;                        // traverse_primitive's accumulated cost (potential maps)
         {
-          const int r = smp ? (int)s_rowmap[n] : 0;
+          const int r = smp ? (int)s_rowmap[n] : 0;  // slot offset of the pair's row
           int ptr[3] = {0, 0, 0};
 #pragma unroll
-          for (int i = 0; i < D; i++) ptr[i] = __umul24(__umul24(en[i], RM) + r, tts);
+          for (int i = 0; i < D; i++) ptr[i] = __umul24(en[i], rowcap) + r;
           bool done = !smp || safe;  // a node whose whole reach box is free has nothing to look up
           const double sdt = (smp && (POT || ycost)) ? T / n : 0.0;  // env_map.h:96
           // env_map.h:121-129: heading cost of sample k (after the potential term of the same sample)
-          const int pyr = YAW ? __umul24(__umul24(jy, RM) + r, tts) : 0;
+          const int pyr = YAW ? __umul24(jy, rowcap) + r : 0;
           auto heading_cost = [&](int k) {
             const double vx = s_vs[ptr[0] + k], vy = s_vs[ptr[1] + k];
             const double sn = sqrt(vx * vx + vy * vy);
@@ -1045,8 +1063,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
           int ptr[3] = {0, 0, 0};
           const int r = smp ? (int)s_rowmap[n] : 0;
 #pragma unroll
-          for (int i = 0; i < 2; i++) ptr[i] = __umul24(__umul24(en[i], RM) + r, tts);
-          const int pyr = __umul24(__umul24(jy, RM) + r, tts);
+          for (int i = 0; i < 2; i++) ptr[i] = __umul24(en[i], rowcap) + r;
+          const int pyr = __umul24(jy, rowcap) + r;
           const double sdt = go ? T / n : 0.0;
           for (int k = 0; __ballot(go && k < cntl) != 0ull; k++) {
             if (go && k < cntl) {
