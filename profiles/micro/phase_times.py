@@ -12,7 +12,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "profiles", "micro", "libmplx_pt.so")  # git-ignored; built here when missing
-if not os.path.exists(LIB):
+SRC = os.path.join(ROOT, "motion_primitive_library_amd", "csrc", "expand_grid_kernel.hip")
+if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
     subprocess.run([sys.executable, "-m", "motion_primitive_library_amd.build", "--define", "MPLX_PHASE_TIMING", "--out", LIB],
                    check=True, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 os.environ["MPLX_LIB"] = LIB
