@@ -82,7 +82,7 @@ namespace mplx {
 // LDS carve-up, shared by host (size) and device (offsets).
 struct GridLds {
   // shared by the workgroup (read-only after set-up)
-  int o_uval, o_uidx, o_tc, o_tt, tt_rows, o_wave0;
+  int o_uval, o_uidx, o_tc, o_wave0;
   // per wave, relative to the wave's block
   int w_node, w_est, w_hp, w_eq, w_eflag, w_box, w_misc, w_rowmap, w_list, w_cell, w_uq, wave_bytes;
   int o_uyaw, w_yaw, w_ycs, w_yq, w_hmask, w_vs, w_ycsr;  // yaw controls only
@@ -103,8 +103,6 @@ struct GridLds {
     // (tried in round 2: the sample-time rows of every n <= n_max resident in shared LDS, to save the per-pass round
     // trip to the global table -- no measurable gain on any configuration, 3.9 KB per workgroup at C4: not kept)
     b = (b + 7) & ~7;
-    tt_rows = 0;
-    o_tt = b;
     o_uyaw = b; b += ym ? 16 * 8 : 0;
     b = (b + 15) & ~15;
     o_wave0 = b;
@@ -261,7 +259,6 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   const double *s_uval = (const double *)(smem + L.o_uval);
   const unsigned short *s_uidx = (const unsigned short *)(smem + L.o_uidx);
   const unsigned char *s_tc = smem + L.o_tc;
-  const double *s_tt = L.tt_rows ? (const double *)(smem + L.o_tt) : nullptr;  // [n][tts] sample times, or not resident
   unsigned char *wb = smem + L.o_wave0 + wv * L.wave_bytes;
   double *s_node = (double *)(wb + L.w_node);
   double *s_est = (double *)(wb + L.w_est);
@@ -297,42 +294,16 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   const int dims[3] = {A.dim0, A.dim1, A.dim2};
   const int nd[3] = {A.nd0, A.nd1, A.nd2};
 
-  // ---- once per (persistent) workgroup: shared read-only tables
-  {
-    double *uv = (double *)(smem + L.o_uval);
-    for (int i = threadIdx.x; i < EN; i += kBT) {
-      const int ax = i / ndp, j = i - ax * ndp;
-      uv[i] = A.uvals[ax * 16 + j];
-    }
-    unsigned short *ui = (unsigned short *)(smem + L.o_uidx);
-    for (int i = threadIdx.x; i < nU; i += kBT) {
-      const unsigned int pk = A.uidx[i];  // j0 | j1 << 8 | j2 << 16, each < 16
-      ui[i] = (unsigned short)((pk & 15u) | (((pk >> 8) & 15u) << 4) | (((pk >> 16) & 15u) << 8) |
-                               (((pk >> 24) & 15u) << 12));  // bits 12..15: the yaw value
-    }
-    if (YAW && threadIdx.x < ndy) ((double *)(smem + L.o_uyaw))[threadIdx.x] = A.uvals[3 * 16 + threadIdx.x];
-    if (threadIdx.x < 64) smem[L.o_tc + threadIdx.x] = A.tcnt[threadIdx.x];
-    double *tt = (double *)(smem + L.o_tt);
-    for (int i = threadIdx.x; i < L.tt_rows * L.tts; i += kBT) {
-      const int nn = i / L.tts, k = i - nn * L.tts;
-      tt[i] = A.ttab[nn * kTabStride + k];
-    }
-  }
-  __syncthreads();  // the only workgroup barrier
-
-  // primitive.h:521; in the override pass the host libm's value (see YawPin in mplx_internal.h)
+  // ---- which nodes are this wave's, and the first one's state on its way BEFORE the shared tables are fetched: the
+  // two round trips to memory overlap (a launch's first node otherwise waits for the tables, then for its own state).
+  // Static: wave w takes nodes w, w + W, ...  Dynamic (GridArgs::work): chunks of `ck` nodes; chunk w is wave w's, the
+  // later ones are claimed from this workgroup's counter.  The chunk after the current one is always claimed already
+  // (its first node is being prefetched), so the atomic's round trip is never waited for.
   const bool pinned = YAW && A.yaw.tab != nullptr;
-  const double cos_lim = (YAW && A.yaw_max > 0) ? (pinned ? A.yaw.cos_lim : cos(A.yaw_max)) : 0.0;
   const int64_t wave_id = (int64_t)blockIdx.x * kWPB + wv;
   const int64_t wave_stride = (int64_t)gridDim.x * kWPB;
   // the override pass of the yaw pinning walks a list of nodes; everything else the whole frontier in order
   auto node_of = [&](int64_t it) -> int64_t { return (YAW && A.yaw.node_list) ? (int64_t)A.yaw.node_list[it] : it; };
-  double nxt = 0.0;  // lanes < F: one field of the next node (prefetched)
-  if (wave_id < A.n_nodes && lane < F) nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(wave_id)];
-  asm volatile("" ::"v"(nxt));  // arrived before the loop: no wait for it at the loop head (see the pin after phase A)
-  // ---- node assignment.  Static: wave w takes nodes w, w + W, ...  Dynamic (GridArgs::work): chunks of `ck` nodes;
-  // chunk w is wave w's, the later ones are claimed from this workgroup's counter.  The chunk after the current one is
-  // always claimed already (its first node is being prefetched), so the atomic's round trip is never waited for.
   const bool dyn = A.work != nullptr;
   const int64_t ck = dyn ? A.work_chunk : 1;
   int64_t dyn_beg = 0, dyn_len = 0;  // this counter's share of the claimable chunks
@@ -353,15 +324,34 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
     const int64_t j = (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
     return j < dyn_len ? (dyn_beg + j) * ck : A.n_nodes;
   };
-  int64_t it0 = dyn ? wave_id * ck : wave_id;
-  int64_t chunk_end = dyn ? (it0 + ck < A.n_nodes ? it0 + ck : A.n_nodes) : 0;
+  const int64_t it0 = wave_id * ck;
+  int64_t chunk_end = it0 + ck < A.n_nodes ? it0 + ck : A.n_nodes;
+  double nxt = 0.0;  // lanes < F: one field of the next node (prefetched)
+  if (it0 < A.n_nodes && lane < F) nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(it0)];
   int64_t next_chunk = A.n_nodes;  // (dynamic) first node of the chunk claimed ahead
   if (dyn && it0 < A.n_nodes) next_chunk = claim();
-  if (dyn) {  // the first node of a dynamic launch is wave_id * ck, not wave_id: redo the prefetch
-    nxt = 0.0;
-    if (it0 < A.n_nodes && lane < F) nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(it0)];
-    asm volatile("" ::"v"(nxt));
+
+  // ---- once per (persistent) workgroup: shared read-only tables
+  {
+    double *uv = (double *)(smem + L.o_uval);
+    for (int i = threadIdx.x; i < EN; i += kBT) {
+      const int ax = i / ndp, j = i - ax * ndp;
+      uv[i] = A.uvals[ax * 16 + j];
+    }
+    unsigned short *ui = (unsigned short *)(smem + L.o_uidx);
+    for (int i = threadIdx.x; i < nU; i += kBT) {
+      const unsigned int pk = A.uidx[i];  // j0 | j1 << 8 | j2 << 16, each < 16
+      ui[i] = (unsigned short)((pk & 15u) | (((pk >> 8) & 15u) << 4) | (((pk >> 16) & 15u) << 8) |
+                               (((pk >> 24) & 15u) << 12));  // bits 12..15: the yaw value
+    }
+    if (YAW && threadIdx.x < ndy) ((double *)(smem + L.o_uyaw))[threadIdx.x] = A.uvals[3 * 16 + threadIdx.x];
+    if (threadIdx.x < 64) smem[L.o_tc + threadIdx.x] = A.tcnt[threadIdx.x];
   }
+  __syncthreads();  // the only workgroup barrier
+  asm volatile("" ::"v"(nxt));  // arrived before the loop: no wait for it at the loop head (see the pin after phase A)
+
+  // primitive.h:521; in the override pass the host libm's value (see YawPin in mplx_internal.h)
+  const double cos_lim = (YAW && A.yaw_max > 0) ? (pinned ? A.yaw.cos_lim : cos(A.yaw_max)) : 0.0;
   int64_t it_next = 0;
 
   PT_DECL;
@@ -727,7 +717,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
         }
         s_rowmap[lane] = mine_off;
       }
-      if (!safe && !s_tt) {
+      if (!safe) {
         // the accumulated sample times of this pass' rows (independent loads: one round trip for all of them)
         int off = 0;
         for (unsigned long long t = sub; t; t &= t - 1ull) {
@@ -749,7 +739,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
           const int nn = __ffsll((long long)t) - 1;
           const int cn = (int)s_tc[nn];
           const float inv_cn = 1.0f / (float)cn;
-          const double *trow = s_tt ? s_tt + nn * tts : s_trow + row;
+          const double *trow = s_trow + row;
 #pragma unroll
           for (int ax = 0; ax < D; ax++) {
             const double p0 = s_node[0 * D + ax];
