@@ -266,7 +266,6 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   int *s_eq = (int *)(wb + L.w_eq);
   int *s_eflag = (int *)(wb + L.w_eflag);
   unsigned int *s_box = (unsigned int *)(wb + L.w_box);
-  int *s_rb = (int *)(wb + L.w_box);  // [EN][2] reach ranges of the entries (live between T1 and the box query)
   double *s_trow = (double *)(wb + L.w_box);  // [RM][tts] sample times, live only while the rows are built
   int *s_misc = (int *)(wb + L.w_misc);
   unsigned short *s_rowmap = (unsigned short *)(wb + L.w_rowmap);
@@ -402,6 +401,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
     PT(0);
     // ---- phase T1: axis entries; the node's own lattice integers (lanes 48..)
     int flag = 0;
+    int rb_lo = 0x7fffffff, rb_hi = (int)0x80000000;  // this lane's entry: cells its p(t) spans (free-box query)
     if (lane < EN) {
       const int ax = lane / ndp, jv = lane - ax * ndp;
       if (jv < nd[ax]) {
@@ -448,8 +448,8 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
             }
           }
           if (K >= 3) { pmin = p - mv * T; pmax = p + mv * T; }
-          s_rb[lane * 2 + 0] = (int)floor(div_by(pmin - org[ax], A.res, A.Rres)) - 1;  // (same quotient as `/`)
-          s_rb[lane * 2 + 1] = (int)floor(div_by(pmax - org[ax], A.res, A.Rres)) + 1;
+          rb_lo = (int)floor(div_by(pmin - org[ax], A.res, A.Rres)) - 1;  // (same quotient as `/`)
+          rb_hi = (int)floor(div_by(pmax - org[ax], A.res, A.Rres)) + 1;
         }
         if (jv == 0) {
           // the node's own cell on this axis (map_util.h:103-108); the codes are offsets from it.
@@ -579,18 +579,14 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
       bool inside = true;
 #pragma unroll
       for (int i = 0; i < D; i++) {
-        int lo_ = 0x7fffffff, hi_ = -0x7fffffff;
-        const int nv = s_misc[M_NV + i];
-        const unsigned char *vl = (const unsigned char *)(s_misc + M_VL) + i * 16;
-        for (int j = 0; j < nv; j++) {  // uniform loop, broadcast LDS reads
-          const int en_ = i * ndp + (int)vl[j];
-          const int a = s_rb[en_ * 2 + 0], b = s_rb[en_ * 2 + 1];
-          lo_ = a < lo_ ? a : lo_;
-          hi_ = b > hi_ ? b : hi_;
-        }
+        // per axis the span of the entries inside the limits: a DPP min / max over the lanes of that axis (the lanes
+        // hold their entries' spans since T1; the others carry the identities) -- no loop, no trip through LDS
+        const bool mine_ax = lane >= i * ndp && lane < (i + 1) * ndp;
+        const int lo_ = wave_reduce_minmax<false>(mine_ax ? rb_lo : 0x7fffffff);
+        const int hi_ = wave_reduce_minmax<true>(mine_ax ? rb_hi : (int)0x80000000);
         rlo[i] = lo_;
         rhi[i] = hi_;
-        inside = inside && nv > 0 && lo_ >= 0 && hi_ < dims[i];
+        inside = inside && hi_ >= lo_ && lo_ >= 0 && hi_ < dims[i];  // (hi < lo: no entry of the axis is inside the limits)
       }
       sat_inside = inside;
       if (inside && lane < (1 << D)) {
