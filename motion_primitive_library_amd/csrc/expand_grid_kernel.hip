@@ -243,8 +243,17 @@ __device__ __forceinline__ double wrap_angle(double a) {
 }
 
 template <int D, int K, bool YAW, bool POT>
-__global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
+__global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
+  // The argument block is ~100 SGPRs' worth and the kernel's SGPR budget is 102: preloaded, it alone forces hundreds
+  // of v_writelane / v_readlane spills.  So it is read where it lies, through the kernarg segment pointer (scalar
+  // loads from the constant cache), and the pointer is laundered at the top of every node so that the loads stay
+  // inside the iteration, next to their uses, instead of being hoisted and kept live across the whole kernel.
+  // (the pointer keeps the CONSTANT address space: only then are the loads scalar s_load's)
+  typedef const GridArgs __attribute__((address_space(4))) *KernargPtr;
+  KernargPtr Ak = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)A_kernarg;
+#define A (*Ak)
   constexpr int F = 4 * D + 2;
   const int nU = A.nU, ndp = A.ndp, RM = A.rmax;
   const bool ycost = YAW && A.wyaw > 0;  // env_map.h:121: per-sample heading cost
@@ -356,6 +365,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
   PT_DECL;
   for (int64_t it = it0; it < A.n_nodes; it = it_next) {
     PT(9);  // (loop overhead / tail of the previous node)
+    asm volatile("" : "+s"(Ak));  // see the top of the kernel
     if (!dyn) {
       it_next = it + wave_stride;
     } else if (it + 1 < chunk_end) {
@@ -1082,6 +1092,7 @@ __global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A) {
     }
   }
   PT_FLUSH;
+#undef A
 }
 
 // Summed-area table of the blocked-bit map: sat[z][y][x] (sizes d+1, zero border at index 0) = number of
