@@ -78,10 +78,11 @@ __device__ __forceinline__ int block_scan(bool f, int *total, int *s_wsum) {
 template <int D, int K, bool ONE>
 struct NodeLoad {
   double p[D], v[D], a[D], j[D];
-  __device__ __forceinline__ void load(const TileArgs &A, const double *s_node, int64_t node0, int nl) {
+  __device__ __forceinline__ void load(const double *nodes, int64_t node_stride, const double *s_node, int64_t node0,
+                                       int nl) {
     if (ONE) {
-      const double *nd = A.nodes + node0;
-      const int64_t st = A.node_stride;
+      const double *nd = nodes + node0;
+      const int64_t st = node_stride;
 #pragma unroll
       for (int i = 0; i < D; i++) {
         p[i] = nd[(0 * D + i) * st];
@@ -115,8 +116,15 @@ __device__ __forceinline__ void split_pair(int p, int nU, float inv_nU, int *nl,
 constexpr int kUB = 4;  // samples in flight per lane in phase B
 
 template <int D, int K, bool ONE>
-__global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A) {
+__global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
+  // The argument block is read where it lies, through the kernarg segment pointer (constant address space: scalar
+  // loads), laundered once per tile so that the loads stay next to their uses -- preloaded, the block takes most of
+  // the 102 SGPRs and a quarter of the kernel's VALU instructions were lane spills (see expand_grid_kernel.hip).
+  typedef const TileArgs __attribute__((address_space(4))) *KernargPtr;
+  KernargPtr Ak = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)A_kernarg;
+#define A (*Ak)
   constexpr int F = 4 * D + 2;
   // ---- LDS carve-up; must match tile_lds_bytes()
   const int P_cap = A.tile_pairs;
@@ -156,6 +164,7 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A) {
 
   const int64_t n_tiles = (A.n_nodes + A.npb - 1) / A.npb;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  asm volatile("" : "+s"(Ak));
   __syncthreads();  // LDS of the previous tile is free; tables visible
   const int64_t node0 = tile * A.npb;
   const int nn = ONE ? 1 : (int)((A.n_nodes - node0) < (int64_t)A.npb ? (A.n_nodes - node0) : (int64_t)A.npb);
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A) {
   }
   for (int nl = tid; nl < nn; nl += kBT) {
     NodeLoad<D, K, ONE> nd;
-    nd.load(A, s_node, node0, nl);
+    nd.load(A.nodes, A.node_stride, s_node, node0, nl);
     s_hcur[nl] = lattice_hash<D, K>(nd.p, nd.v, nd.a, nd.j, A.R001, A.R01);
     s_ncnt[nl] = 0;
     s_nbase[nl] = 0;
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A) {
       int nl, ci;
       split_pair<ONE>(p, nU, inv_nU, &nl, &ci);
       NodeLoad<D, K, ONE> nd;
-      nd.load(A, s_node, node0, nl);
+      nd.load(A.nodes, A.node_stride, s_node, node0, nl);
       const double *u = s_U + ci * udim;
       double max_v = 0;
       valid = true;
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A) {
       const int p = s_vlist[v];
       split_pair<ONE>(p, nU, inv_nU, &nl, &ci);
       NodeLoad<D, K, ONE> nd;
-      nd.load(A, s_node, node0, nl);
+      nd.load(A.nodes, A.node_stride, s_node, node0, nl);
       ct = ONE ? A.nodes[(4 * D + 1) * A.node_stride + node0] : s_node[nl * F + 4 * D + 1];
       const double *u = s_U + ci * udim;
       bool same_pos = true;
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A) {
 #pragma unroll
     for (int q = 0; q < kUB; q++) {
       NodeLoad<D, K, ONE> nd;
-      nd.load(A, s_node, node0, nl[q]);
+      nd.load(A.nodes, A.node_stride, s_node, node0, nl[q]);
       bool in = true;
       int cell[D];
 #pragma unroll
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A) {
       // sample count beyond the time table: walk this pair serially, exactly like
       // expand_kernel.hip does (not reachable when v_max bounds n)
       NodeLoad<D, K, ONE> nd;
-      nd.load(A, s_node, node0, nl);
+      nd.load(A.nodes, A.node_stride, s_node, node0, nl);
       Ax<K> ax[D];
       double max_v = 0;
 #pragma unroll
@@ -451,6 +460,7 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A) {
     if (A.l_count) A.l_count[node0 + nl] = s_ncnt[nl];
   }  // tile loop
 }
+#undef A
 
 // Sequentially accumulated sample times: row n holds t_0 .. t_{cnt-1} of
 // `for (t = 0; t < T; t += T/n)` and tcnt[n] the number of iterations.
