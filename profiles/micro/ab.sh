@@ -6,8 +6,8 @@ cp $L /tmp/new.so
 for rep in 1 2; do
   for which in old new; do
     if [ $which = old ]; then cp profiles/micro/ab_old/libmplx.so $L; else cp /tmp/new.so $L; fi
-    for w in C4 C3 C2; do
-      python bench.py --workload $w --no-cpu-baseline --steps 50 --warmup 5 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$which $w', d['roofline']['kernel_ms'], d['ms_per_step'])"
+    for w in C4 C3 C5 C2; do
+      python bench.py --workload $w --no-extras --no-cpu-baseline --steps 50 --warmup 5 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$which $w', d['roofline']['kernel_ms'], d['ms_per_step'])"
     done
   done
 done
