@@ -1,0 +1,49 @@
+"""Parity fuzz on the GPU box: many random "odd" worlds (tests/helpers.py::odd_world) with frontiers large enough for the
+dynamic node assignment, small forced grids and chunk sizes, resident launches, every route -- against the oracle.
+
+    python profiles/micro/fuzz_parity.py [first_seed] [n_seeds]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import motion_primitive_library_amd as m  # noqa: E402
+from helpers import assert_lists_equal, engine_env, odd_world, oracle_env  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+bad = 0
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    n_nodes = int(rng.choice([700, 1500, 2311, 5000]))
+    os.environ["MPLX_GRID_BLOCKS"] = str(int(rng.choice([3, 8, 40, 256])))
+    os.environ["MPLX_GRID_CHUNK"] = str(int(rng.choice([0, 1, 2, 5])))
+    try:
+        wl, control, pot = odd_world(m, seed, n_nodes)
+        ref = O.expand(oracle_env(wl), wl.nodes, threads=os.cpu_count())
+        env = engine_env(m, wl)
+        rtol = 1e-6 if control & 0x10 else 0.0
+        fr = env.upload_frontier(wl.nodes)
+        lists = env.alloc_lists(n_nodes, want_state=True, want_iters=True)
+        for launch in range(2):
+            env.expand_lists_resident(fr, lists)
+            env.synchronize()
+            assert_lists_equal(lists.download(), ref, n_nodes, wl.U.shape[0], cost_rtol=rtol,
+                               what="seed %d launch %d route %s" % (seed, launch, env.last_lists_route()))
+        route = env.last_lists_route()
+        lists.free()
+        fr.free()
+        env.close()
+        print("seed %d ok: dim %d control 0x%x %d nodes route %s blocks %s chunk %s%s" % (
+            seed, wl.dim, control, n_nodes, route, os.environ["MPLX_GRID_BLOCKS"], os.environ["MPLX_GRID_CHUNK"],
+            " potential" if pot is not None else ""))
+    except AssertionError as e:
+        bad += 1
+        print("seed %d FAILED: %s" % (seed, str(e)[:300]))
+print("fuzz: %d of %d seeds failed" % (bad, count))
+sys.exit(1 if bad else 0)

@@ -4,7 +4,7 @@ dense+compaction route) against the oracle."""
 import numpy as np
 import pytest
 
-from helpers import (assert_lists_equal, engine_env, engine_env_from_case, golden_cases, oracle_env,
+from helpers import (assert_lists_equal, engine_env, engine_env_from_case, golden_cases, odd_world, oracle_env,
                      oracle_env_from_case)
 from test_gpu_parity import YAW_COST_RTOL, _small_world
 
@@ -429,44 +429,8 @@ def test_irregular_parameters_all_routes(engine, oracle_lib, seed):
     durations, map origins off the lattice, velocities that are not lattice values, control values like 1/3, odd
     weights.  (The hoisted divisions by res / 0.01 / 0.1, the accumulated sample times and the per-axis sample
     counts are the places where a shortcut would show.)  Every route against the oracle, bit for bit."""
-    rng = np.random.default_rng(1000 + seed)
-    W = engine.workloads
-    dim = 2 + seed % 2
-    control = [0x01, 0x03, 0x07, 0x0F, 0x11, 0x13, 0x17, 0x03][seed % 8]
-    res = float(rng.choice([0.07, 0.05, 0.13, 0.25, 0.1 / 3, 0.2]))
-    dt = float(rng.choice([0.3, 0.7, 1.0, 1.25, 0.45, 2.0 / 3]))
-    edge = 44
-    origin = [float(x) for x in np.round(rng.uniform(-4.0, 3.0, size=dim), 3)]
-    grid = W.box_map([edge] * dim, res, 0.12, 77 + seed, side_m=(3 * res, 9 * res))
-    vals = np.array([-1.0, -1.0 / 3, 0.0, 0.4, 1.1]) if dim == 2 else np.array([-0.9, 0.0, 0.7])
-    vals = vals * (res / 0.1) / dt  # keep the per-step displacement a few cells
-    U = W.grid_controls(list(vals), dim, yaw_rates=[-0.37, 0.0, 0.52] if control & 0x10 else None)
-    n_nodes = 90
-    nodes = np.zeros((4 * dim + 2, n_nodes))
-    free = np.argwhere(grid.reshape([edge] * dim) == 0)
-    pick = free[rng.integers(0, len(free), size=n_nodes)][:, ::-1]  # (x, y[, z]) cell coordinates
-    for i in range(dim):
-        nodes[i] = origin[i] + (pick[:, i] + rng.uniform(0.0, 1.0, size=n_nodes)) * res
-    vscale = 6 * res / dt
-    if control & 0x02:
-        nodes[dim:2 * dim] = rng.uniform(-vscale, vscale, size=(dim, n_nodes))
-    if control & 0x04:
-        nodes[2 * dim:3 * dim] = rng.uniform(-1, 1, size=(dim, n_nodes)) * vscale / dt * 0.5
-    if control & 0x08:
-        nodes[3 * dim:4 * dim] = rng.uniform(-1, 1, size=(dim, n_nodes)) * vscale / dt / dt * 0.25
-    if control & 0x10:
-        nodes[4 * dim] = np.arctan2(nodes[dim + 1], nodes[dim]) + rng.uniform(-0.5, 0.5, size=n_nodes) if control & 0x02 \
-            else rng.uniform(-3.1, 3.1, size=n_nodes)
-    nodes[4 * dim + 1] = rng.uniform(0, 9, size=n_nodes)
-    params = {"dt": dt, "w": float(rng.uniform(0.5, 12.0)), "v_max": 1.3 * vscale, "a_max": 1.7 * vscale / dt,
-              "j_max": 2.9 * vscale / dt / dt, "wyaw": float(rng.choice([0.0, 0.8, 1.0]))}
-    if control & 0x10:
-        params["yaw_max"] = 0.9
-    pot = None
-    if seed % 4 == 1:
-        pot = W.potential_field(grid, res, 4 * res, 4 * res if dim == 3 else None)
-        params.update({"potential_weight": 0.37, "gradient_weight": 0.0})
-    wl = W.Workload("odd", dim, control, pot if pot is not None else grid, origin, res, U, nodes, params, potential=pot)
+    wl, control, pot = odd_world(engine, seed, 90)
+    n_nodes, U = wl.n_nodes, wl.U
     ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
     st = ref["status"]
     assert np.count_nonzero(st == 1) > 30 and np.count_nonzero(st == 2) > 10, np.bincount(st, minlength=4)
