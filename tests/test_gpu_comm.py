@@ -124,3 +124,33 @@ def test_torch_distributed_gather_of_engine_buffers_world_of_one(engine):
         env.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo(tmp_path):
+    """The whole `bench.py --gpus 2` flow (one process per rank under torch.distributed.run) rehearsed on the one GPU of
+    the box: MPLX_BENCH_BACKEND=gloo lets both ranks use device 0 (RCCL refuses two ranks on one device).  THE frontier
+    is partitioned, both legs run, the packed lists of both ranks are gathered on both, the timed lists pass the
+    parity check.  Timings of this rehearsal mean nothing; the logic is what N = 2 ... 8 on a real node runs."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MPLX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "C4", "--scale", "0.25", "--nodes", "6001"]
+    proc = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["parity_sample_ok"] is True
+    assert d["config"]["frontier_nodes"] == 6001 and d["config"]["frontier_nodes_per_gpu"] == 3001  # rank 0's block
+    assert d["weak"]["frontier_nodes_per_gpu"] == 6001
+    g = d["allgather"]
+    assert "error" not in g, g
+    assert g["edges"]["entries"] == g["full"]["entries"] == d["roofline"]["emitted_all_ranks"] > 0
