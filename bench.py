@@ -465,6 +465,29 @@ def main():
                 bpe = 20 + (8 * (4 * wl.dim + 2) if ws else 0)
                 gather[label] = {"ms": dt_ * 1e3, "entries": entries, "bytes_per_entry": bpe,
                                  "received_GBps_per_rank": entries * bpe * (world - 1) / max(world, 1) / dt_ / 1e9}
+            # ---- the consumer of the gather: the on-device merge of ALL ranks' successors (mplx_post_packed_device on
+            # the gathered lists: heuristic, goal flags, first occurrence of every lattice state across the whole frontier)
+            cnt_all, offs_all, rows_all = res[0], res[1], res[2]
+            ps = shard.packed_struct(cnt_all, offs_all, rows_all)
+            goal_row = np.ascontiguousarray(wl.nodes[:, 0])
+            n_all = int(res[3][-1])
+            bufs = env.post_packed(ps, n_all, goal_row, alloc=alloc, download=False)  # warm-up
+            env.synchronize()
+            for b_ in bufs.values():
+                if b_ is not None:
+                    b_.free()
+            barrier()
+            t0 = time.perf_counter()
+            bufs = env.post_packed(ps, n_all, goal_row, alloc=alloc, download=False)
+            env.synchronize()
+            merge_ms = (time.perf_counter() - t0) * 1e3
+            unique = int((bufs["flags"].view(torch.uint8, int(res[4][-1])) & 4).ne(0).sum().item())
+            gather["merge"] = {"ms": merge_ms, "entries": int(res[4][-1]), "first_occurrences": unique,
+                               "what": "mplx_post_packed_device on the gathered lists of all ranks, on every rank: "
+                                       "heuristic + goal flags + node identity (first occurrence of each lattice state)"}
+            for b_ in bufs.values():
+                if b_ is not None:
+                    b_.free()
             gather["what"] = ("pack on the device + torch.distributed all_gather_into_tensor (RCCL) of the packed rows of every "
                               "rank, padded to the largest rank, compacted on the device; edges = action + cost + hash, "
                               "full = + the 4D+2 state rows")
@@ -549,14 +572,24 @@ def main():
             env.close()
             env = None
             extras(m, args, wl, out)
-        print(json.dumps(out), flush=True)
 
     if env is not None:
         slots.free()
         frontier.free()
         env.close()
+    # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which (buffered when
+    # stdout is a pipe or a file) would otherwise land after it at exit.  Every rank flushes, then rank 0 prints.
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
     if distributed:
         dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -254,6 +254,14 @@ typedef struct {
 int mplx_pack_lists_device(mplx_ctx *ctx, const mplx_succ_lists *d_lists, int64_t n_nodes,
                            const mplx_packed_lists *d_out, int64_t *h_total_or_null);
 
+/* mplx_post_lists_device on PACKED lists (entry i of the outputs belongs to packed entry i; `canon` holds packed
+ * indices): the consumer of the all-gather -- every rank runs it on the gathered set and so learns, without the
+ * host, which successors of the whole frontier are first occurrences of their lattice state (the search's node
+ * identity, waypoint.h:128-135), their heuristic (env_base.h:46-64) and goal flags (env_map.h:25-37): the on-device
+ * open-list merge north_star names as the reason to gather at all.  d_packed needs offs, hash and state.         */
+int mplx_post_packed_device(mplx_ctx *ctx, const mplx_packed_lists *d_packed, int64_t n_nodes,
+                            const mplx_goal_spec *goal, const mplx_post *d_out);
+
 /* RCCL communicator of the context (one context = one GPU = one rank; one process
  * per GPU or several contexts in one process).  The 128-byte id is RCCL's
  * ncclUniqueId: rank 0 makes it, the application hands it to the other ranks by

@@ -19,7 +19,7 @@ SYMBOLS = [
     "mplx_set_map", "mplx_set_potential", "mplx_set_region", "mplx_set_params", "mplx_set_controls",
     "mplx_update_potential_map", "mplx_set_search_region_path",
     "mplx_expand_device", "mplx_expand", "mplx_expand_lists_device", "mplx_expand_lists", "mplx_get_succ",
-    "mplx_post_lists_device",
+    "mplx_post_lists_device", "mplx_post_packed_device",
     "mplx_pack_lists_device", "mplx_comm_unique_id", "mplx_comm_init", "mplx_comm_destroy", "mplx_comm_broadcast_map",
     "mplx_comm_allgather_lists",
     "mplx_check_edges",
@@ -143,6 +143,7 @@ def lib():
         "mplx_post_lists_device": (C.c_int, [vp, C.POINTER(SuccLists), i64, C.POINTER(GoalSpec), C.POINTER(Post)]),
         "mplx_check_edges": (C.c_int, [vp, vp, vp, i64, i64, C.POINTER(EdgesOut)]),
         "mplx_pack_lists_device": (C.c_int, [vp, C.POINTER(SuccLists), i64, C.POINTER(PackedLists), C.POINTER(i64)]),
+        "mplx_post_packed_device": (C.c_int, [vp, C.POINTER(PackedLists), i64, C.POINTER(GoalSpec), C.POINTER(Post)]),
         "mplx_comm_unique_id": (C.c_int, [vp]),
         "mplx_comm_init": (C.c_int, [vp, vp, i32, i32]),
         "mplx_comm_destroy": (C.c_int, [vp]),

@@ -8,8 +8,9 @@
 
 using namespace mplx_detail;
 
-extern "C" int mplx_post_lists_device(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t n_nodes,
-                                      const mplx_goal_spec *goal, const mplx_post *d_out) {
+// max_entries: an upper bound on the emitted successors (sizes the identity table)
+static int post_lists_impl(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t n_nodes, const mplx_goal_spec *goal,
+                           const mplx_post *d_out, uint64_t max_entries) {
   if (!c) return MPLX_ERR_ARG;
   if (!d_lists || !goal || !d_out || n_nodes < 0 || !goal->goal)
     return fail(c, MPLX_ERR_ARG, "mplx_post_lists_device: NULL argument");
@@ -43,8 +44,8 @@ extern "C" int mplx_post_lists_device(mplx_ctx *c, const mplx_succ_lists *d_list
   a.canon = d_out->canon;
   if (d_out->canon) {
     uint64_t cap = 1024;
-    while (cap < (uint64_t)n_nodes * (uint64_t)c->nU) cap <<= 1;  // >= the emitted successors whatever the frontier
-    if (cap < 2 * (uint64_t)n_nodes * (uint64_t)c->nU && cap < (1ull << 27)) cap <<= 1;
+    while (cap < max_entries) cap <<= 1;  // >= the emitted successors whatever the frontier
+    if (cap < 2 * max_entries && cap < (1ull << 27)) cap <<= 1;
     if (int rc = ensure(c, c->post_keys, (cap + 1) * sizeof(mplx::PostArgs::Slot))) return rc;
     // all bytes 0xff: key = ~0 (empty), val = 0xffffffff (above every list index, unsigned atomicMin)
     HIP_TRY(c, hipMemsetAsync(c->post_keys.p, 0xff, (cap + 1) * sizeof(mplx::PostArgs::Slot), c->stream));
@@ -53,4 +54,30 @@ extern "C" int mplx_post_lists_device(mplx_ctx *c, const mplx_succ_lists *d_list
   }
   HIP_TRY(c, mplx::launch_post_lists(D, a, c->stream));
   return MPLX_OK;
+}
+
+extern "C" int mplx_post_lists_device(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t n_nodes,
+                                      const mplx_goal_spec *goal, const mplx_post *d_out) {
+  if (!c) return MPLX_ERR_ARG;
+  return post_lists_impl(c, d_lists, n_nodes, goal, d_out, (uint64_t)(n_nodes > 0 ? n_nodes : 0) * (uint64_t)c->nU);
+}
+
+// Packed lists are one long list: entry i of every row, offs[n_nodes] entries in all.  The strided kernel reads them as
+// a single "node" whose count is that total -- the low word of the last prefix sum, where it lies on the device.
+extern "C" int mplx_post_packed_device(mplx_ctx *c, const mplx_packed_lists *p, int64_t n_nodes, const mplx_goal_spec *goal,
+                                       const mplx_post *d_out) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!p || !goal || !d_out || n_nodes < 0 || !p->offs || !p->hash || !p->state)
+    return fail(c, MPLX_ERR_ARG, "mplx_post_packed_device: the packed lists need offs, hash and state");
+  if (p->capacity <= 0 || p->capacity >= 0x7f7f7f7fLL)
+    return fail(c, MPLX_ERR_ARG, "mplx_post_packed_device: capacity %lld outside the int32 index", (long long)p->capacity);
+  if (!c->has_U) return fail(c, MPLX_ERR_STATE, "mplx_post_packed_device: controls not set");
+  mplx_succ_lists one{};
+  one.count = (int32_t *)(p->offs + n_nodes);  // little-endian low word of offs[n_nodes] (< 2^31, checked above)
+  one.hash = p->hash;
+  one.state = p->state;
+  one.state_stride = p->state_stride;
+  one.node_stride = p->capacity;
+  // the identity table is sized by the caller-visible bound on the entries: capacity
+  return post_lists_impl(c, &one, 1, goal, d_out, (uint64_t)p->capacity);
 }

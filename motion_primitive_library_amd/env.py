@@ -104,6 +104,18 @@ def _alloc(env, nbytes, alloc=None):
     return DeviceArray(env, nbytes) if alloc is None else alloc(int(nbytes))
 
 
+class DeviceArrayView:
+    """A raw device pointer the engine did not allocate (e.g. a field of a ready C struct): read-back helper."""
+
+    def __init__(self, env, ptr):
+        self._env, self.ptr = env, int(ptr)
+
+    def download_i64(self, index):
+        out = np.empty(1, dtype=np.int64)
+        _abi.check(self._env._ctx, _abi.lib().mplx_memcpy_d2h(self._env._ctx, out.ctypes.data, self.ptr + 8 * int(index), 8))
+        return out[0]
+
+
 class Slots:
     """HBM-resident dense successor slots for n_nodes x nU pairs."""
 
@@ -583,6 +595,39 @@ class EnvMap:
         out = {"heur": heur.download(np.float64, (ns,)), "flags": flags.download(np.uint8, (ns,))}
         if canon:
             out["canon"] = canon.download(np.int32, (ns,))
+            canon.free()
+        heur.free()
+        flags.free()
+        return out
+
+    def post_packed(self, packed, n_nodes, goal_row, w=None, v_max=None, tol_pos=0.5, tol_vel=-1.0, tol_acc=-1.0,
+                    tol_yaw=-1.0, want_canon=True, alloc=None, download=True):
+        """mplx_post_packed_device: heuristic, goal flags and node identity of PACKED lists (e.g. the gathered lists
+        of all ranks).  `packed`: an env.PackedLists or a ready _abi.PackedLists struct (device pointers).  Returns
+        host arrays (download=True) or the device buffers {"heur", "flags", "canon"} (asynchronous)."""
+        self._flush()
+        ps = packed.c_struct() if hasattr(packed, "c_struct") else packed
+        cap = int(ps.capacity)
+        goal = np.ascontiguousarray(goal_row, dtype=np.float64)
+        g = _abi.GoalSpec()
+        g.goal, g.control = goal.ctypes.data, int(self._p.control)
+        g.w = float(self._p.w if w is None else w)
+        g.v_max = float(self._p.v_max if v_max is None else v_max)
+        g.tol_pos, g.tol_vel, g.tol_acc, g.tol_yaw = float(tol_pos), float(tol_vel), float(tol_acc), float(tol_yaw)
+        heur = _alloc(self, cap * 8, alloc)
+        flags = _alloc(self, cap, alloc)
+        canon = _alloc(self, cap * 4, alloc) if want_canon else None
+        _abi.check(self._ctx, _abi.lib().mplx_memset(self._ctx, flags.ptr, 0, cap))
+        o = _abi.Post()
+        o.heur, o.flags, o.canon = heur.ptr, flags.ptr, canon.ptr if canon else None
+        _abi.check(self._ctx, _abi.lib().mplx_post_packed_device(self._ctx, C.byref(ps), int(n_nodes), C.byref(g), C.byref(o)))
+        if not download:
+            return {"heur": heur, "flags": flags, "canon": canon}
+        self.synchronize()
+        total = int(DeviceArrayView(self, ps.offs).download_i64(int(n_nodes)))
+        out = {"heur": heur.download(np.float64, (total,)), "flags": flags.download(np.uint8, (total,)), "total": total}
+        if canon:
+            out["canon"] = canon.download(np.int32, (total,))
             canon.free()
         heur.free()
         flags.free()

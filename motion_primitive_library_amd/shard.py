@@ -125,3 +125,24 @@ def packed_views(packed, n_local, total=None):
     if packed.state is not None:
         rows["state"] = packed.state.view(torch.float64, packed.n_fields * packed.capacity).view(packed.n_fields, packed.capacity)[:, :cap]
     return packed.count.view(torch.int32, max(n_local, 1))[:n_local], packed.offs.view(torch.int64, n_local + 1), rows
+
+
+def packed_struct(count_all, offs_all, rows_all):
+    """The C struct (_abi.PackedLists) of gathered packed lists held in torch tensors (what all_gather_packed returns):
+    lets the engine run on them where they are, e.g. EnvMap.post_packed -- the on-device merge of the whole frontier's
+    successors (heuristic, goal flags, first occurrences) that is the reason to gather at all.  Keep the tensors alive
+    while the struct is in use."""
+    from . import _abi
+
+    total = int(offs_all.shape[0]) and int(rows_all["action"].shape[-1])
+    ps = _abi.PackedLists()
+    ps.count, ps.offs = count_all.data_ptr(), offs_all.data_ptr()
+    ps.action, ps.cost = rows_all["action"].data_ptr(), rows_all["cost"].data_ptr()
+    ps.hash = rows_all["hash"].data_ptr() if rows_all.get("hash") is not None else None
+    st = rows_all.get("state")
+    if st is not None:
+        assert st.is_contiguous() and st.shape[-1] == total
+        ps.state = st.data_ptr()
+    ps.state_stride = total
+    ps.capacity = max(total, 1)
+    return ps

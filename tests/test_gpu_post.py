@@ -87,3 +87,36 @@ def test_post_lists_without_velocity_limit_and_without_identity(engine, oracle_l
     lists.free()
     fr.free()
     env.close()
+
+
+def test_post_on_packed_lists_equals_post_on_the_strided_lists(engine):
+    """mplx_post_packed_device (the consumer of the multi-GPU gather) against mplx_post_lists_device on the same
+    successors: same heuristic and flags entry for entry, and the same first occurrences (canon indices translate
+    through the packing)."""
+    wl = engine.workloads.make("C4", scale=0.25, n_nodes=900)
+    env = engine.EnvMap(wl.dim, 0)
+    wl.apply(env)
+    fr = env.upload_frontier(wl.nodes)
+    lists = env.alloc_lists(wl.n_nodes, want_state=True, want_iters=False)
+    env.expand_lists_resident(fr, lists)
+    env.synchronize()
+    goal = wl.nodes[:, 5].copy()
+    strided = env.post_lists(lists, goal, tol_pos=0.6)
+    host = lists.download()
+    pk = engine.pack_host_lists(host, wl.n_nodes)
+    S = lists.stride
+    src = (np.repeat(np.arange(wl.n_nodes, dtype=np.int64) * S - pk["offs"][:-1], pk["count"]) + np.arange(pk["total"]))
+    packed = env.alloc_packed(wl.n_nodes)
+    env.pack_lists(lists, packed)
+    got = env.post_packed(packed, wl.n_nodes, goal, tol_pos=0.6)
+    assert got["total"] == pk["total"] > 10000
+    assert np.array_equal(got["heur"].view(np.uint64), strided["heur"][src].view(np.uint64))
+    assert np.array_equal(got["flags"], strided["flags"][src])
+    # canon: packed index of the first occurrence == packed position of the strided first occurrence
+    to_packed = np.full(host["action"].size, -1, np.int64)
+    to_packed[src] = np.arange(pk["total"])
+    assert np.array_equal(got["canon"].astype(np.int64), to_packed[strided["canon"][src]])
+    assert 0 < np.count_nonzero(got["flags"] & 4) <= pk["total"]
+    for b in (packed, lists, fr):
+        b.free()
+    env.close()
