@@ -41,6 +41,7 @@ def is_stale():
 
 
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"]
+EXTRA_FLAGS = {}  # per-source extra flags
 
 
 def build_variant(out_path, defines, verbose=False):
@@ -75,7 +76,7 @@ def build(force=False, verbose=False, jobs=None):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         return src, subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
@@ -96,9 +97,9 @@ def build(force=False, verbose=False, jobs=None):
 
 
 if __name__ == "__main__":
-    if "--define" in sys.argv:
-        i = sys.argv.index("--define")
+    if "--define" in sys.argv:  # --define A=1,B=2 (or repeated) --out path
+        defs = [d for i, a in enumerate(sys.argv[:-1]) if a == "--define" for d in sys.argv[i + 1].split(",")]
         out = sys.argv[sys.argv.index("--out") + 1]
-        print(build_variant(os.path.abspath(out), sys.argv[i + 1].split(","), verbose=True))
+        print(build_variant(os.path.abspath(out), defs, verbose=True))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -242,8 +242,23 @@ __device__ __forceinline__ double wrap_angle(double a) {
   return a;
 }
 
+// Resident waves per SIMD the register allocation has to allow (amdgpu_waves_per_eu).  The heading instantiations
+// need 120 - 143 VGPRs when unconstrained: past 128 only 3 waves per SIMD fit, and the kernel is latency bound there.
+#ifndef MPLX_OCC_YAW
+#define MPLX_OCC_YAW 4
+#endif
+#ifndef MPLX_OCC_K3
+#define MPLX_OCC_K3 1
+#endif
+#ifndef MPLX_OCC_PLAIN
+#define MPLX_OCC_PLAIN 1
+#endif
+template <int K, bool YAW>
+constexpr int grid_min_waves() { return YAW ? MPLX_OCC_YAW : (K >= 3 ? MPLX_OCC_K3 : MPLX_OCC_PLAIN); }
+
 template <int D, int K, bool YAW, bool POT>
-__global__ __launch_bounds__(kBT) void expand_grid_kernel(const GridArgs A_kernarg) {
+__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(grid_min_waves<K, YAW>())))
+void expand_grid_kernel(const GridArgs A_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   // The argument block is ~100 SGPRs' worth and the kernel's SGPR budget is 102: preloaded, it alone forces hundreds
   // of v_writelane / v_readlane spills.  So it is read where it lies, through the kernarg segment pointer (scalar
@@ -1168,14 +1183,10 @@ __global__ void build_blocked_bits_kernel(const int8_t *map, const uint32_t *reg
   out[g] = bits;
 }
 
+// the dynamic-LDS ceiling is a per-device attribute of the kernel: set it once per (instantiation, device), not
+// once per process -- a second context on another GPU of the same process needs it too
 template <int D, int K, bool YAW, bool POT>
-hipError_t launch_grid_inst(const GridArgs &a, hipStream_t stream) {
-  if (a.n_nodes == 0) return hipSuccess;
-  const int64_t n_wg = (a.n_nodes + kWPB - 1) / kWPB;
-  const int64_t blocks = n_wg < (int64_t)a.grid_limit ? n_wg : (int64_t)a.grid_limit;
-  const size_t lds = grid_lds_bytes(D, K, a.nU, a.ndp, a.n_max, a.rmax, a.boxcap, YAW ? (a.wyaw > 0 ? 2 : 1) : 0, a.ndy);
-  // the dynamic-LDS ceiling is a per-device attribute of the kernel: set it once per (instantiation, device), not
-  // once per process -- a second context on another GPU of the same process needs it too
+hipError_t grid_inst_attr() {
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
@@ -1185,8 +1196,67 @@ hipError_t launch_grid_inst(const GridArgs &a, hipStream_t stream) {
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
+  return hipSuccess;
+}
+
+template <int D, int K, bool YAW, bool POT>
+hipError_t launch_grid_inst(const GridArgs &a, hipStream_t stream) {
+  if (a.n_nodes == 0) return hipSuccess;
+  const int64_t n_wg = (a.n_nodes + kWPB - 1) / kWPB;
+  const int64_t blocks = n_wg < (int64_t)a.grid_limit ? n_wg : (int64_t)a.grid_limit;
+  const size_t lds = grid_lds_bytes(D, K, a.nU, a.ndp, a.n_max, a.rmax, a.boxcap, YAW ? (a.wyaw > 0 ? 2 : 1) : 0, a.ndy);
+  if (hipError_t e = grid_inst_attr<D, K, YAW, POT>()) return e;
   hipLaunchKernelGGL((expand_grid_kernel<D, K, YAW, POT>), dim3((unsigned)blocks), dim3(kBT), lds, stream, a);
   return hipGetLastError();
+}
+
+// Workgroups of this instantiation one CU keeps resident with `lds` bytes of dynamic LDS each (registers, LDS
+// granules and wave slots as the runtime accounts them); 0 if the runtime cannot tell.
+template <int D, int K, bool YAW, bool POT>
+int resident_inst(size_t lds) {
+  if (grid_inst_attr<D, K, YAW, POT>() != hipSuccess) return 0;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)expand_grid_kernel<D, K, YAW, POT>, kBT, lds) !=
+      hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return nb;
+}
+
+template <int D_, int K_, bool YAW_, bool POT_>
+struct GridInst {
+  static constexpr int D = D_, K = K_;
+  static constexpr bool YAW = YAW_, POT = POT_;
+};
+
+// (dim, control, potential map?) -> instantiation; f(GridInst<...>{}) or `none` when the kernel has none
+template <class R, class F>
+R dispatch_grid(int dim, int control, bool pot, R none, F &&f) {
+#define MPLX_GI(D, K, Y) (pot ? f(GridInst<D, K, Y, true>{}) : f(GridInst<D, K, Y, false>{}))
+  if (dim == 2) {
+    switch (control) {
+      case 0x01: return MPLX_GI(2, 1, false);
+      case 0x03: return MPLX_GI(2, 2, false);
+      case 0x07: return MPLX_GI(2, 3, false);
+      case 0x0f: return pot ? none : f(GridInst<2, 4, false, false>{});
+      case 0x11: return MPLX_GI(2, 1, true);
+      case 0x13: return MPLX_GI(2, 2, true);
+      case 0x17: return MPLX_GI(2, 3, true);
+    }
+  } else if (dim == 3) {
+    switch (control) {
+      case 0x01: return MPLX_GI(3, 1, false);
+      case 0x03: return MPLX_GI(3, 2, false);
+      case 0x07: return MPLX_GI(3, 3, false);
+      case 0x0f: return pot ? none : f(GridInst<3, 4, false, false>{});
+      case 0x11: return MPLX_GI(3, 1, true);
+      case 0x13: return MPLX_GI(3, 2, true);
+      case 0x17: return MPLX_GI(3, 3, true);
+    }
+  }
+#undef MPLX_GI
+  return none;
 }
 
 }  // namespace
@@ -1235,28 +1305,17 @@ hipError_t launch_build_sat(int dim, const uint32_t *blk, const int32_t *mdim, u
 }
 
 hipError_t launch_expand_grid(int dim, int control, const GridArgs &a, hipStream_t s) {
-  if (dim == 2) {
-    switch (control) {
-      case 0x01: return a.pot ? launch_grid_inst<2, 1, false, true>(a, s) : launch_grid_inst<2, 1, false, false>(a, s);
-      case 0x03: return a.pot ? launch_grid_inst<2, 2, false, true>(a, s) : launch_grid_inst<2, 2, false, false>(a, s);
-      case 0x07: return a.pot ? launch_grid_inst<2, 3, false, true>(a, s) : launch_grid_inst<2, 3, false, false>(a, s);
-      case 0x0f: return a.pot ? hipErrorInvalidValue : launch_grid_inst<2, 4, false, false>(a, s);
-      case 0x11: return a.pot ? launch_grid_inst<2, 1, true, true>(a, s) : launch_grid_inst<2, 1, true, false>(a, s);
-      case 0x13: return a.pot ? launch_grid_inst<2, 2, true, true>(a, s) : launch_grid_inst<2, 2, true, false>(a, s);
-      case 0x17: return a.pot ? launch_grid_inst<2, 3, true, true>(a, s) : launch_grid_inst<2, 3, true, false>(a, s);
-    }
-  } else if (dim == 3) {
-    switch (control) {
-      case 0x01: return a.pot ? launch_grid_inst<3, 1, false, true>(a, s) : launch_grid_inst<3, 1, false, false>(a, s);
-      case 0x03: return a.pot ? launch_grid_inst<3, 2, false, true>(a, s) : launch_grid_inst<3, 2, false, false>(a, s);
-      case 0x07: return a.pot ? launch_grid_inst<3, 3, false, true>(a, s) : launch_grid_inst<3, 3, false, false>(a, s);
-      case 0x0f: return a.pot ? hipErrorInvalidValue : launch_grid_inst<3, 4, false, false>(a, s);
-      case 0x11: return a.pot ? launch_grid_inst<3, 1, true, true>(a, s) : launch_grid_inst<3, 1, true, false>(a, s);
-      case 0x13: return a.pot ? launch_grid_inst<3, 2, true, true>(a, s) : launch_grid_inst<3, 2, true, false>(a, s);
-      case 0x17: return a.pot ? launch_grid_inst<3, 3, true, true>(a, s) : launch_grid_inst<3, 3, true, false>(a, s);
-    }
-  }
-  return hipErrorInvalidValue;
+  return dispatch_grid<hipError_t>(dim, control, a.pot != nullptr, hipErrorInvalidValue, [&](auto t) {
+    using T = decltype(t);
+    return launch_grid_inst<T::D, T::K, T::YAW, T::POT>(a, s);
+  });
+}
+
+int grid_resident_blocks(int dim, int control, bool pot, size_t lds) {
+  return dispatch_grid<int>(dim, control, pot, 0, [&](auto t) {
+    using T = decltype(t);
+    return resident_inst<T::D, T::K, T::YAW, T::POT>(lds);
+  });
 }
 
 }  // namespace mplx

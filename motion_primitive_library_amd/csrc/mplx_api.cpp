@@ -483,17 +483,43 @@ GridPlan plan_grid(const mplx_ctx *c) {
   if (c->tune.grid_boxcap > 0) boxcap = c->tune.grid_boxcap;
   if (rmax < 1) rmax = 1;
   while (rmax > 1 && mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rmax, boxcap, ym, ndy) > 80 * 1024) rmax--;
-  const size_t lds = mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rmax, boxcap, ym, ndy);
-  if (lds > 160 * 1024) return g;
-  int per_cu = (int)((160 * 1024) / lds);
   const int wpb = mplx::grid_waves_per_block();
-  // 16 waves per CU is the measured optimum on C4: 20 fit the LDS, but the kernel needs 105 VGPRs (4 waves per
-  // SIMD), and capped to 96 VGPRs with 20 waves resident it is 7-15 % slower (profiles/README.md)
-  {
-    const int cap = c->tune.grid_waves_per_cu > 0 ? c->tune.grid_waves_per_cu : 16;
-    if (per_cu * wpb > cap) per_cu = cap / wpb;
-    if (per_cu < 1) per_cu = 1;
+  // The launch is persistent: every workgroup must be RESIDENT (a workgroup that waits for a slot starts its first,
+  // statically assigned node only after another one has drained the whole queue).  What fits is the runtime's answer
+  // for this instantiation (registers, LDS granules), not LDS bytes alone.
+  auto resident = [&](int rm, size_t *lds_out) -> int {
+    const size_t lds = mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rm, boxcap, ym, ndy);
+    *lds_out = lds;
+    if (lds > 160 * 1024) return 0;
+    int nb = -1;
+    for (const auto &e : c->grid_occ)
+      if (e.control == p.control && e.pot == c->has_pot && e.lds == lds) nb = e.nb;
+    if (nb < 0) {
+      nb = mplx::grid_resident_blocks(c->dim, p.control, c->has_pot, lds);
+      if (c->grid_occ.size() >= 8) c->grid_occ.clear();
+      c->grid_occ.push_back({p.control, c->has_pot, lds, nb});
+      if (getenv("MPLX_GRID_VERBOSE"))
+        fprintf(stderr, "mplx: grid kernel control 0x%x pot %d rows/pass %d: LDS %zu B per workgroup, %d workgroups resident per CU\n",
+                p.control, (int)c->has_pot, rm, lds, nb);
+    }
+    const int by_lds = (int)((160 * 1024) / lds);
+    return (nb > 0 && nb < by_lds) ? nb : by_lds;
+  };
+  // 16 waves per CU (4 per SIMD): what the register allocation of every instantiation allows, and the measured
+  // optimum where more would fit (profiles/README.md)
+  const int cap = c->tune.grid_waves_per_cu > 0 ? c->tune.grid_waves_per_cu : 16;
+  size_t lds = 0;
+  int per_cu = resident(rmax, &lds);
+  if (per_cu < 1) return g;
+  // One row less per pass when that is what lets another workgroup in (the heading-cost tables of ACCxYAW with
+  // wyaw > 0: 45 KB per workgroup = 3 resident, 35 KB = 4; C5 0.108 -> 0.103 ms, a second pass is rare)
+  if (c->tune.grid_rmax <= 0 && rmax == 4 && per_cu * wpb < cap) {
+    size_t lds3 = 0;
+    const int per_cu3 = resident(3, &lds3);
+    if (per_cu3 > per_cu) { rmax = 3; per_cu = per_cu3; lds = lds3; }
   }
+  if (per_cu * wpb > cap) per_cu = cap / wpb;
+  if (per_cu < 1) per_cu = 1;
   g.ok = true;
   g.ndp = ndp;
   g.n_max = n_max;

@@ -106,6 +106,9 @@ struct mplx_ctx {
   int64_t yaw_flagged = 0, yaw_fix_passes = 0;  // statistics (mplx_yaw_pin_stats)
   mplx_detail::DevBuf work_counter;       // dynamic node assignment of the factorised kernel (GridArgs::work)
   int work_parity = 0;                    // which of the two counter sets the next launch uses
+  // workgroups of the factorised kernel resident per CU (grid_resident_blocks), cached per (control, potential, LDS)
+  struct GridOcc { int control; bool pot; size_t lds; int nb; };
+  mutable std::vector<GridOcc> grid_occ;
   // RCCL communicator of this context (comm_api.cpp); the library is loaded on first use
   void *comm = nullptr;
   int comm_rank = 0, comm_world = 1;
