@@ -89,8 +89,10 @@ struct GridLds {
   int total;
   int F, EN, PN, tts, KQ;
   // ym: 0 = no yaw, 1 = yaw, 2 = yaw with the per-sample heading cost (wyaw > 0); ndy = distinct yaw rates
+  // ulex: the control table is the nested-loop enumeration of its per-axis values (GridArgs::ulex): the per-control
+  // entry indices are arithmetic then, no table
   __host__ __device__ GridLds(int D, int K, int waves, int nU, int ndp, int n_max, int rmax, int boxcap, int ym,
-                              int ndy) {
+                              int ndy, int ulex) {
     F = 4 * D + 2;
     EN = D * ndp;
     PN = (D == 3) ? ndp * ndp : ndp;
@@ -98,7 +100,7 @@ struct GridLds {
     KQ = K == 3 ? 4 : K;
     int b = 0;
     o_uval = b; b += EN * 8;
-    o_uidx = b; b += ((nU + 1) & ~1) * 2;  // 4 bits per axis
+    o_uidx = b; b += ulex ? 0 : ((nU + 1) & ~1) * 2;  // 4 bits per axis
     o_tc = b; b += 64;
     // (tried in round 2: the sample-time rows of every n <= n_max resident in shared LDS, to save the per-pass round
     // trip to the global table -- no measurable gain on any configuration, 3.9 KB per workgroup at C4: not kept)
@@ -116,8 +118,8 @@ struct GridLds {
     w = (w + 7) & ~7;
     w_box = w; w += (boxcap * 4 > rmax * tts * 8) ? boxcap * 4 : rmax * tts * 8;  // also the sample times while rows are built
     w = (w + 15) & ~15;
-    w_misc = w; w += 40 * 4;
-    w_rowmap = w; w += 64 * 2;  // per sample count n: offset of its row inside an entry's block this pass (0xffff: not this pass)
+    w_misc = w; w += 37 * 4;  // M_* below
+    w_rowmap = w; w += ((n_max + 2) & ~1) * 2;  // per sample count n <= n_max: offset of its row inside an entry's block this pass (0xffff: not this pass)
     w_list = w; w += ((nU + 1) & ~1) * 2;
     w_cell = w; w += EN * rmax * tts + 8;  // + 8: the sample loop reads up to 7 codes past a row
     w = (w + 15) & ~15;
@@ -277,7 +279,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
   // small control table it is the other way round (|U| = 125: ~700 samples against up to 1 156 rows).
   const bool gather = A.gather != 0;
   const int ndy = YAW ? A.ndy : 0;
-  const GridLds L(D, K, kWPB, nU, ndp, A.n_max, RM, A.boxcap, YAW ? (ycost ? 2 : 1) : 0, ndy);
+  const GridLds L(D, K, kWPB, nU, ndp, A.n_max, RM, A.boxcap, YAW ? (ycost ? 2 : 1) : 0, ndy, A.ulex);
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const double *s_uval = (const double *)(smem + L.o_uval);
@@ -362,7 +364,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
       uv[i] = A.uvals[ax * 16 + j];
     }
     unsigned short *ui = (unsigned short *)(smem + L.o_uidx);
-    for (int i = threadIdx.x; i < nU; i += kBT) {
+    for (int i = threadIdx.x; i < (A.ulex ? 0 : nU); i += kBT) {
       const unsigned int pk = A.uidx[i];  // j0 | j1 << 8 | j2 << 16, each < 16
       ui[i] = (unsigned short)((pk & 15u) | (((pk >> 8) & 15u) << 4) | (((pk >> 16) & 15u) << 8) |
                                (((pk >> 24) & 15u) << 12));  // bits 12..15: the yaw value
@@ -644,6 +646,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
     for (int base = 0; base < nA; base += 64) {
       const int x = base + lane;
       int ci = x;
+      unsigned int lpk = 0;  // what the list holds: the control index, or (ulex) the packed entry indices it follows from
       bool emit = false;
       int n = 0;
       if (x < nA) {
@@ -663,10 +666,12 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
           if (D == 3) j2 = vl_[32 + rb];
           ci = (D == 3) ? (j0 * nd[1] + j1) * nd[2] + j2 : j0 * nd[1] + j1;
           if (YAW) ci = ci * ny_ + jy;
+          lpk = (unsigned)j0 | ((unsigned)j1 << 4) | ((unsigned)j2 << 8) | ((unsigned)jy << 12);
         } else {
           const unsigned int pk = s_uidx[x];
           j0 = pk & 15, j1 = (pk >> 4) & 15, j2 = (pk >> 8) & 15;
           if (YAW) jy = (pk >> 12) & 15;
+          lpk = (unsigned)ci;
         }
         const int px = (D == 3) ? __umul24(j0, ndp) + j1 : j0;
         const int eL = (D - 1) * ndp + ((D == 3) ? j2 : j1);
@@ -683,7 +688,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
       }
       const unsigned long long m = __ballot(emit);
       if (emit) {
-        s_list[E + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)ci;
+        s_list[E + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)lpk;
         if (n) atomicOr((unsigned int *)&s_misc[M_NMASK + (n >> 5)], 1u << (n & 31));
       }
       E += __popcll(m);
@@ -736,7 +741,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
           if (nn == lane) mine_off = (unsigned short)off;
           off += (int)s_tc[nn];
         }
-        s_rowmap[lane] = mine_off;
+        if (lane <= A.n_max) s_rowmap[lane] = mine_off;  // (n_max <= 61)
       }
       if (!safe) {
         // the accumulated sample times of this pass' rows (independent loads: one round trip for all of them)
@@ -873,9 +878,14 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
       for (int e0 = 0; e0 < E; e0 += 64) {
         const int e = e0 + lane;
         const bool act = e < E;
-        const int ci = act ? (int)s_list[e] : 0;
-        const unsigned int pk = s_uidx[ci];
+        const unsigned int le = act ? (unsigned int)s_list[e] : 0u;
+        const unsigned int pk = A.ulex ? le : (unsigned int)s_uidx[le];
         const int j0 = pk & 15, j1 = (pk >> 4) & 15, j2 = (pk >> 8) & 15;
+        int ci = (int)le;
+        if (A.ulex) {
+          ci = (D == 3) ? (int)__umul24(__umul24(j0, nd[1]) + j1, nd[2]) + j2 : (int)__umul24(j0, nd[1]) + j1;
+          if (YAW) ci = (int)__umul24(ci, ndy) + (int)((pk >> 12) & 15);
+        }
         const int en[3] = {j0, ndp + j1, 2 * ndp + j2};
         const int jy = YAW ? (int)((pk >> 12) & 15) : 0;
         const int px = (D == 3) ? __umul24(j0, ndp) + j1 : j0;
@@ -1204,7 +1214,7 @@ hipError_t launch_grid_inst(const GridArgs &a, hipStream_t stream) {
   if (a.n_nodes == 0) return hipSuccess;
   const int64_t n_wg = (a.n_nodes + kWPB - 1) / kWPB;
   const int64_t blocks = n_wg < (int64_t)a.grid_limit ? n_wg : (int64_t)a.grid_limit;
-  const size_t lds = grid_lds_bytes(D, K, a.nU, a.ndp, a.n_max, a.rmax, a.boxcap, YAW ? (a.wyaw > 0 ? 2 : 1) : 0, a.ndy);
+  const size_t lds = grid_lds_bytes(D, K, a.nU, a.ndp, a.n_max, a.rmax, a.boxcap, YAW ? (a.wyaw > 0 ? 2 : 1) : 0, a.ndy, a.ulex);
   if (hipError_t e = grid_inst_attr<D, K, YAW, POT>()) return e;
   hipLaunchKernelGGL((expand_grid_kernel<D, K, YAW, POT>), dim3((unsigned)blocks), dim3(kBT), lds, stream, a);
   return hipGetLastError();
@@ -1272,8 +1282,9 @@ extern "C" int mplx_debug_phase_ticks(unsigned long long *out16, int reset) {
 }
 #endif
 
-size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap, int yaw_mode, int ndy) {
-  return (size_t)GridLds(dim, order, kWPB, nU, ndp, n_max, rmax, boxcap, yaw_mode, ndy).total;
+size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap, int yaw_mode, int ndy,
+                      int ulex) {
+  return (size_t)GridLds(dim, order, kWPB, nU, ndp, n_max, rmax, boxcap, yaw_mode, ndy, ulex).total;
 }
 int grid_waves_per_block() { return kWPB; }
 

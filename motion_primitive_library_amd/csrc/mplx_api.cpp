@@ -482,13 +482,14 @@ GridPlan plan_grid(const mplx_ctx *c) {
   if (c->tune.grid_rmax > 0) rmax = c->tune.grid_rmax;
   if (c->tune.grid_boxcap > 0) boxcap = c->tune.grid_boxcap;
   if (rmax < 1) rmax = 1;
-  while (rmax > 1 && mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rmax, boxcap, ym, ndy) > 80 * 1024) rmax--;
+  const int ulex = (c->u_lex && !c->tune.no_lex) ? 1 : 0;  // = GridArgs::ulex
+  while (rmax > 1 && mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rmax, boxcap, ym, ndy, ulex) > 80 * 1024) rmax--;
   const int wpb = mplx::grid_waves_per_block();
   // The launch is persistent: every workgroup must be RESIDENT (a workgroup that waits for a slot starts its first,
   // statically assigned node only after another one has drained the whole queue).  What fits is the runtime's answer
   // for this instantiation (registers, LDS granules), not LDS bytes alone.
   auto resident = [&](int rm, size_t *lds_out) -> int {
-    const size_t lds = mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rm, boxcap, ym, ndy);
+    const size_t lds = mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rm, boxcap, ym, ndy, ulex);
     *lds_out = lds;
     if (lds > 160 * 1024) return 0;
     int nb = -1;

@@ -178,7 +178,8 @@ struct PackArgs {
 hipError_t launch_pack_rows(const PackArgs &args, int64_t n_nodes, hipStream_t stream);
 // offs[0..n] = exclusive prefix sums of count[0..n) (offs[n] = total); device pointers
 hipError_t launch_scan_counts(const int32_t *count, int64_t n, int64_t *offs, hipStream_t stream);
-size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap, int yaw_mode, int ndy);
+size_t grid_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, int boxcap, int yaw_mode, int ndy,
+                      int ulex);
 int grid_waves_per_block();
 // workgroups of the (dim, control, potential) instantiation resident per CU with `lds` bytes each; 0 = unknown
 int grid_resident_blocks(int dim, int control, bool pot, size_t lds);
