@@ -318,6 +318,11 @@ def main():
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOAD_DESC))
     ap.add_argument("--scale", type=float, default=1.0, help="map edge scale (debug only; invalidates the metric)")
     ap.add_argument("--nodes", type=int, default=None, help="frontier size override (debug only)")
+    ap.add_argument("--spinup-ms", type=float, default=100.0,
+                    help="untimed launches of the same step for at least this long, until their time is steady, BEFORE "
+                         "the W warm-up steps: the workload is generated on the host for seconds while the GPU idles at "
+                         "its lowest clocks, and the first ~25 ms of launches after that run up to 25 %% slower "
+                         "(profiles/micro/c4_ramp.py: 0.60, 0.54, 0.50, 0.48 ms ... steady 0.476); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip e2e / wavefront / other_configs / plan (N = 1 only)")
     ap.add_argument("--frontier", default="random", choices=["random", "wavefront"],
@@ -412,6 +417,23 @@ def main():
         return el, kernel_ms_total / steps
 
     note("workload ready, %d of %d nodes on this rank" % (n_loc, N))
+    spin = {"ms": 0.0, "groups": 0}
+    if args.spinup_ms > 0:
+        # Clocks up from idle (see --spinup-ms): groups of 10 launches until five consecutive groups agree within 1.5 %
+        # (and at least --spinup-ms have passed), at most 3 s.  Not counted as warm-up or timed steps.
+        t_spin = time.perf_counter()
+        recent = []
+        while True:
+            env.timer_begin()
+            for _ in range(10):
+                launch()
+            recent = (recent + [env.timer_end()])[-5:]
+            spin["groups"] += 1
+            el_ms = (time.perf_counter() - t_spin) * 1e3
+            steady = len(recent) == 5 and max(recent) <= 1.015 * min(recent)
+            if (steady and el_ms >= args.spinup_ms) or el_ms >= 3000.0:
+                break
+        spin["ms"] = (time.perf_counter() - t_spin) * 1e3
     for _ in range(args.warmup):
         launch()
     elapsed, kernel_ms = timed(launch, args.steps)
@@ -526,6 +548,7 @@ def main():
                 "sharding": "the frontier block-partitioned by node over the ranks (strong scaling), map replicated per "
                             "rank, no data-path collective; the optional list all-gather is timed separately",
                 "device": dev_name, "compute_units": cus,
+                "clock_spinup_ms": round(spin["ms"], 1),  # untimed launches before the W warm-up steps (see --spinup-ms)
                 "kernel": {"grid": "expand_grid_kernel (per-axis factorised tables in LDS)", "tile": "expand_tile_kernel",
                            "dense": "expand_kernel + compact_lists_kernel", "none": "expand_kernel"}[route],
             },
