@@ -331,7 +331,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
   auto node_of = [&](int64_t it) -> int64_t { return (YAW && A.yaw.node_list) ? (int64_t)A.yaw.node_list[it] : it; };
   const bool dyn = A.work != nullptr;
   const int64_t ck = dyn ? A.work_chunk : 1;
-  int64_t dyn_beg = 0, dyn_len = 0;  // this counter's share of the claimable chunks
+  int64_t dyn_beg = 0, dyn_len = 0, dyn_step = 1;  // this counter's share of the claimable chunks
   unsigned int *ctr = nullptr;
   if (dyn) {
     if (blockIdx.x == 0 && threadIdx.x < kWorkCounters) A.work_zero[threadIdx.x * 32] = 0u;  // for the next launch
@@ -339,15 +339,19 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
     const int nc = gridDim.x < (unsigned)kWorkCounters ? (int)gridDim.x : kWorkCounters;  // counters in use
     const int cx = (int)(blockIdx.x % nc);
     const int64_t base = n_dyn / nc, rem = n_dyn % nc;
-    dyn_beg = wave_stride + cx * base + (cx < rem ? cx : rem);
     dyn_len = base + (cx < rem ? 1 : 0);
+    // Which chunks are this counter's: dealt round-robin (chunk W + j * nc + cx is its j-th).  All counters advance
+    // at about the same pace, so at any moment the whole launch works inside ONE window of the frontier and of every
+    // output row, instead of 64 windows x 17 rows (work_blocked: a contiguous block per counter, the first version).
+    if (A.work_blocked) { dyn_beg = wave_stride + cx * base + (cx < rem ? cx : rem); dyn_step = 1; }
+    else { dyn_beg = wave_stride + cx; dyn_step = nc; }
     ctr = A.work + cx * 32;
   }
   auto claim = [&]() -> int64_t {  // first node of the next chunk of this counter, or past the end
     unsigned int v = 0;
     if (lane == 0) v = atomicAdd(ctr, 1u);
     const int64_t j = (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
-    return j < dyn_len ? (dyn_beg + j) * ck : A.n_nodes;
+    return j < dyn_len ? (dyn_beg + j * dyn_step) * ck : A.n_nodes;
   };
   const int64_t it0 = wave_id * ck;
   int64_t chunk_end = it0 + ck < A.n_nodes ? it0 + ck : A.n_nodes;

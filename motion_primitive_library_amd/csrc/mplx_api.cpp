@@ -121,6 +121,7 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
     c->tune.grid_waves_per_cu = env_int("MPLX_GRID_WAVES_PER_CU");
     c->tune.grid_static = getenv("MPLX_GRID_STATIC") != nullptr;
     c->tune.grid_chunk = env_int("MPLX_GRID_CHUNK");
+    c->tune.grid_blocked = env_int("MPLX_GRID_BLOCKED");
     c->tune.grid_gather = getenv("MPLX_GRID_GATHER") ? env_int("MPLX_GRID_GATHER") : -1;
     c->tune.grid_sat = getenv("MPLX_GRID_SAT") ? env_int("MPLX_GRID_SAT") : -1;
     c->tune.dbg = env_int("MPLX_TILE_DBG");
@@ -557,6 +558,7 @@ int grid_work(mplx_ctx *c, mplx::GridArgs *a) {
   if (ck > 8) ck = 8;
   if (c->tune.grid_chunk > 0) ck = c->tune.grid_chunk;
   a->work_chunk = (int32_t)ck;
+  a->work_blocked = c->tune.grid_blocked ? 1 : 0;
   return MPLX_OK;
 }
 

@@ -59,6 +59,7 @@ struct mplx_ctx {
     int grid_gather = -1, grid_sat = -1;                  // MPLX_GRID_GATHER / MPLX_GRID_SAT: force 0 / 1 (-1 = automatic)
     bool grid_static = false;                             // MPLX_GRID_STATIC: static node striding instead of the work counters
     int grid_chunk = 0;                                   // MPLX_GRID_CHUNK: nodes per claim (0 = automatic)
+    int grid_blocked = 0;                                 // MPLX_GRID_BLOCKED: contiguous shares per counter (A/B)
     int dbg = 0;                                         // MPLX_TILE_DBG ablation bits
     int zero_copy = 1;                                   // MPLX_ZERO_COPY=0: small batches through a device arena instead
     int arena_kb = 0;                                    // MPLX_ARENA_KB: largest batch served by the one-copy path

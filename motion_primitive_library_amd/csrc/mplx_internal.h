@@ -145,6 +145,7 @@ struct GridArgs {
   unsigned int *work;
   unsigned int *work_zero;
   int32_t work_chunk;
+  int32_t work_blocked;  // 1: every counter owns one contiguous block of chunks; 0: the chunks are dealt round-robin
   int32_t dbg;           // timing ablations (env MPLX_TILE_DBG); 0 in production
   int32_t grid_limit;    // persistent workgroups to launch
   const double *ttab;    // tables of launch_make_tables

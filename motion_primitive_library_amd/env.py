@@ -156,10 +156,14 @@ class Slots:
                 b.free()
 
 
+STATE_ROW_PAD = 0  # default padding between the state rows of Lists, in entries (see Lists.state_stride)
+
+
 class Lists:
     """HBM-resident per-node successor lists (mplx_succ_lists)."""
 
-    def __init__(self, env, n_nodes, nU, want_state=True, want_iters=False, want_hash=True, stride=None, alloc=None):
+    def __init__(self, env, n_nodes, nU, want_state=True, want_iters=False, want_hash=True, stride=None, alloc=None,
+                 state_pad=None):
         self.n_nodes, self.nU = int(n_nodes), int(nU)
         # entries reserved per node: a multiple of 32 keeps every node's rows on 128-byte lines (and lets the
         # kernel complete the last line of each list instead of leaving a partial-line store)
@@ -171,7 +175,9 @@ class Lists:
         self.action = _alloc(env, n * 4, alloc)
         self.cost = _alloc(env, n * 8, alloc)
         self.hash = _alloc(env, n * 8, alloc) if want_hash else None
-        self.state = _alloc(env, n * 8 * self.n_fields, alloc) if want_state else None
+        # entries between consecutive state rows (mplx_succ_lists::state_stride): n_slots + state_pad
+        self.state_stride = n + (STATE_ROW_PAD if state_pad is None else int(state_pad))
+        self.state = _alloc(env, self.state_stride * 8 * self.n_fields, alloc) if want_state else None
         self.iters = _alloc(env, n * 4, alloc) if want_iters else None
 
     def c_struct(self):
@@ -179,7 +185,7 @@ class Lists:
         s.count, s.action, s.cost = self.count.ptr, self.action.ptr, self.cost.ptr
         s.hash = self.hash.ptr if self.hash else None
         s.state = self.state.ptr if self.state else None
-        s.state_stride = self.n_slots
+        s.state_stride = self.state_stride
         s.iters = self.iters.ptr if self.iters else None
         s.node_stride = self.stride
         return s
@@ -194,7 +200,8 @@ class Lists:
         if self.hash:
             out["hash"] = self.hash.download(np.uint64, (self.n_slots,))
         if self.state:
-            out["state"] = self.state.download(np.float64, (self.n_fields, self.n_slots))
+            st = self.state.download(np.float64, (self.n_fields, self.state_stride))
+            out["state"] = np.ascontiguousarray(st[:, :self.n_slots]) if self.state_stride != self.n_slots else st
         if self.iters:
             out["iters"] = self.iters.download(np.int32, (self.n_slots,))
         return out
@@ -215,7 +222,7 @@ class Lists:
         if self.state:
             st = np.empty((self.n_fields, n * S), np.float64)
             for r in range(self.n_fields):
-                st[r] = self.state.download(np.float64, (n * S,), (r * self.n_slots + lo * S) * 8)
+                st[r] = self.state.download(np.float64, (n * S,), (r * self.state_stride + lo * S) * 8)
             out["state"] = st
         if self.iters:
             out["iters"] = self.iters.download(np.int32, (n * S,), lo * S * 4)
@@ -517,8 +524,9 @@ class EnvMap:
         _abi.check(self._ctx, _abi.lib().mplx_expand_lists(self._ctx, nodes.ctypes.data, n, n, C.byref(s)))
         return out
 
-    def alloc_lists(self, n_nodes, want_state=True, want_iters=False, want_hash=True, stride=None, alloc=None):
-        return Lists(self, n_nodes, self.nU, want_state, want_iters, want_hash, stride, alloc)
+    def alloc_lists(self, n_nodes, want_state=True, want_iters=False, want_hash=True, stride=None, alloc=None,
+                    state_pad=None):
+        return Lists(self, n_nodes, self.nU, want_state, want_iters, want_hash, stride, alloc, state_pad)
 
     def alloc_packed(self, n_nodes, capacity=None, want_state=True, want_hash=True, alloc=None):
         """Packed lists for n_nodes nodes; the default capacity n_nodes * nU always suffices."""
