@@ -7,7 +7,7 @@ set -u
 TAG=${1:-r2prof}; OUT=$PWD/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 B="python bench.py --no-extras --no-cpu-baseline"
 for W in C4 C2 C3 C5; do
-  rocprofv3 --kernel-trace --stats -f csv -d "$OUT/kt_$W" -o kt -- $B --workload $W --steps 20 --warmup 3 > "$OUT/kt_$W.log" 2>&1
+  rocprofv3 --kernel-trace --stats -f csv -d "$OUT/kt_$W" -o kt -- $B --workload $W --steps 20 --warmup 5 > "$OUT/kt_$W.log" 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES -f csv -d "$OUT/p1_$W" -o p1 -- $B --workload $W --steps 3 --warmup 1 > "$OUT/p1_$W.log" 2>&1
   rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -f csv -d "$OUT/p2_$W" -o p2 -- $B --workload $W --steps 3 --warmup 1 > "$OUT/p2_$W.log" 2>&1
 done
@@ -34,6 +34,16 @@ for W in ("C4", "C2", "C3", "C5"):
                 print("  %-24s %.5g (n=%d)" % (k, sum(v) / len(v), len(v)))
             if meta:
                 print("  ", meta)
+# the timed dispatches alone: bench.py launches spin-up / placement-probe / warm-up steps before them, the stats average
+# covers all of those; the last `steps` dispatches of the kernel are the timed region
+for W in ("C4", "C2", "C3", "C5"):
+    for f in glob.glob(out + "/kt_%s/**/*kernel_trace.csv" % W, recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if "expand_grid" in r["Kernel_Name"] or "expand_tile" in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+        if len(d) >= 20:
+            print("%s kernel trace: %d dispatches, all avg %.1f ns; last 20 (the timed steps) avg %.1f ns, min %d, max %d" % (
+                W, len(d), sum(d) / len(d), sum(d[-20:]) / 20, min(d[-20:]), max(d[-20:])))
 for name in ("fetch", "write"):
     for f in glob.glob(out + "/%s_C4/**/*counter_collection.csv" % name, recursive=True):
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "expand_grid" in r["Kernel_Name"]]
