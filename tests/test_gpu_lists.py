@@ -485,7 +485,8 @@ def test_tiny_and_lopsided_maps(engine, oracle_lib, dims, control):
 
 
 @pytest.mark.parametrize("name,blocks,chunk", [("C2", "8", "1"), ("C2", "8", "3"), ("C2", "5", "8"), ("C5", "16", "2"),
-                                               ("C3", "7", "1"), ("C2", "8", "static")])
+                                               ("C3", "7", "1"), ("C2", "8", "static"), ("C2", "8", "blocked"),
+                                               ("C5", "70", "blocked3")])
 def test_dynamic_node_assignment_small_grids_and_chunks(engine, oracle_lib, monkeypatch, name, blocks, chunk):
     """The factorised kernel's waves claim nodes from counters (GridArgs::work): with few workgroups every wave walks
     many chunks, chunk sizes that do not divide the frontier leave ragged last chunks, and consecutive launches swap
@@ -493,6 +494,9 @@ def test_dynamic_node_assignment_small_grids_and_chunks(engine, oracle_lib, monk
     monkeypatch.setenv("MPLX_GRID_BLOCKS", blocks)
     if chunk == "static":
         monkeypatch.setenv("MPLX_GRID_STATIC", "1")
+    elif chunk.startswith("blocked"):  # one contiguous block of chunks per counter instead of the round-robin deal
+        monkeypatch.setenv("MPLX_GRID_BLOCKED", "1")
+        monkeypatch.setenv("MPLX_GRID_CHUNK", chunk[7:] or "1")
     else:
         monkeypatch.setenv("MPLX_GRID_CHUNK", chunk)
     wl = engine.workloads.make(name, scale=0.25, n_nodes=2311)  # a prime: no chunk size divides it
@@ -516,5 +520,30 @@ def test_dynamic_node_assignment_small_grids_and_chunks(engine, oracle_lib, monk
     sub = {k: (v[:700 * nU] if k != "state" else v[:, :700 * nU]) for k, v in ref.items() if k != "stats"}
     assert_lists_equal(got, sub, 700, nU, cost_rtol=rtol, what="%s shorter frontier" % name)
     lists.free()
+    fr.free()
+    env.close()
+
+
+def test_state_rows_with_padding_between_them(engine, oracle_lib):
+    """mplx_succ_lists::state_stride is the caller's: rows further apart than n_nodes * node_stride (Lists(state_pad))
+    hold the same lists (used by profiles/micro/c4_skew.py)."""
+    wl = engine.workloads.make("C2", scale=0.25, n_nodes=300)
+    nU = wl.U.shape[0]
+    env = engine_env(engine, wl)
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+    fr = env.upload_frontier(wl.nodes)
+    for pad in (0, 32, 2080):
+        for route in ("grid", "tile", "dense"):
+            env.set_lists_route(route)
+            lists = env.alloc_lists(wl.n_nodes, want_state=True, want_iters=True, state_pad=pad)
+            assert lists.c_struct().state_stride == lists.n_slots + pad
+            env.expand_lists_resident(fr, lists)
+            env.synchronize()
+            assert_lists_equal(lists.download(), ref, wl.n_nodes, nU, what="state_pad %d route %s" % (pad, route))
+            half = lists.download_nodes(100, 200)
+            full = lists.download()
+            S = lists.stride
+            assert np.array_equal(half["state"], full["state"][:, 100 * S:200 * S], equal_nan=True)
+            lists.free()
     fr.free()
     env.close()
