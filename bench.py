@@ -442,7 +442,7 @@ def main():
                 break
         spin["ms"] = (time.perf_counter() - t_spin) * 1e3
     placement = {"probe_ms": [], "chosen": 0}
-    if args.placement_trials > 1 and not distributed:  # see --placement-trials
+    if args.placement_trials > 1:  # see --placement-trials (every rank probes its own shard's lists; no collective inside)
         def probe():
             env.timer_begin()
             for _ in range(20):
@@ -452,7 +452,7 @@ def main():
         tried = [slots]
         placement["probe_ms"].append(probe())
         while len(tried) < args.placement_trials and not min(placement["probe_ms"]) <= 0.95 * max(placement["probe_ms"]):
-            slots = env.alloc_lists(n_loc, want_state=True, want_iters=False)  # (the earlier ones stay allocated)
+            slots = env.alloc_lists(n_loc, want_state=True, want_iters=False, alloc=alloc)  # (the earlier ones stay allocated)
             tried.append(slots)
             for _ in range(5):
                 launch()
