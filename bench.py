@@ -452,7 +452,11 @@ def main():
         tried = [slots]
         placement["probe_ms"].append(probe())
         while len(tried) < args.placement_trials and not min(placement["probe_ms"]) <= 0.95 * max(placement["probe_ms"]):
-            slots = env.alloc_lists(n_loc, want_state=True, want_iters=False, alloc=alloc)  # (the earlier ones stay allocated)
+            try:
+                slots = env.alloc_lists(n_loc, want_state=True, want_iters=False, alloc=alloc)  # (the earlier ones stay allocated)
+            except Exception as e:  # noqa: BLE001 -- out of memory for another trial: keep what there is
+                note("placement trial %d not allocated: %s" % (len(tried), e))
+                break
             tried.append(slots)
             for _ in range(5):
                 launch()
