@@ -155,10 +155,14 @@ int mplx_comm_broadcast_map(mplx_ctx *c, int32_t root) {
   if (flags[0]) if (int rc = ensure(c, c->pot, n)) return rc;
   if (flags[1]) if (int rc = ensure(c, c->region_bits, words * 4)) return rc;
   NCCL_TRY(c, rccl().GroupStart());
-  NCCL_TRY(c, rccl().Broadcast(c->map.p, c->map.p, n, ncclInt8, root, comm, c->stream));
-  if (flags[0]) NCCL_TRY(c, rccl().Broadcast(c->pot.p, c->pot.p, n, ncclInt8, root, comm, c->stream));
-  if (flags[1]) NCCL_TRY(c, rccl().Broadcast(c->region_bits.p, c->region_bits.p, words, ncclInt32, root, comm, c->stream));
-  NCCL_TRY(c, rccl().GroupEnd());
+  {  // a call that fails inside the group must not leave it open
+    int e = rccl().Broadcast(c->map.p, c->map.p, n, ncclInt8, root, comm, c->stream);
+    if (e == 0 && flags[0]) e = rccl().Broadcast(c->pot.p, c->pot.p, n, ncclInt8, root, comm, c->stream);
+    if (e == 0 && flags[1]) e = rccl().Broadcast(c->region_bits.p, c->region_bits.p, words, ncclInt32, root, comm, c->stream);
+    const int e_end = rccl().GroupEnd();
+    NCCL_TRY(c, e);
+    NCCL_TRY(c, e_end);
+  }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->has_pot = flags[0] != 0;
   c->has_region = flags[1] != 0;
@@ -220,18 +224,21 @@ int mplx_comm_allgather_lists(mplx_ctx *c, const mplx_packed_lists *loc, int64_t
   }
   if (G > 1) {
     NCCL_TRY(c, rccl().GroupStart());
-    for (int d = 1; d < G; d++) {
+    int e = 0;  // (a call that fails inside the group must not leave it open)
+    for (int d = 1; d < G && e == 0; d++) {
       const int to = (me + d) % G, from = (me - d + G) % G;  // a different peer pair per step on every rank
       const size_t fn = (size_t)meta[(size_t)2 * from], fe = (size_t)meta[(size_t)2 * from + 1];
       for (const RowPair &rw : rows) {
         const size_t sb = (rw.es_n ? my_n : my_e) * (size_t)rw.es;
         const size_t rb = (rw.es_n ? fn : fe) * (size_t)rw.es;
         const size_t at = (size_t)(rw.es_n ? noff[(size_t)from] : eoff[(size_t)from]) * (size_t)rw.es;
-        if (sb) NCCL_TRY(c, rccl().Send(rw.src, sb, ncclInt8, to, comm, c->stream));
-        if (rb) NCCL_TRY(c, rccl().Recv(rw.dst + at, rb, ncclInt8, from, comm, c->stream));
+        if (e == 0 && sb) e = rccl().Send(rw.src, sb, ncclInt8, to, comm, c->stream);
+        if (e == 0 && rb) e = rccl().Recv(rw.dst + at, rb, ncclInt8, from, comm, c->stream);
       }
     }
-    NCCL_TRY(c, rccl().GroupEnd());
+    const int e_end = rccl().GroupEnd();
+    NCCL_TRY(c, e);
+    NCCL_TRY(c, e_end);
   }
   HIP_TRY(c, mplx::launch_scan_counts(all->count, noff[(size_t)G], all->offs, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
