@@ -1,3 +1,5 @@
+"""Launch + synchronise latency of small resident batches by route (factorised / tiled / dense kernel) for small control
+tables; run on the GPU box."""
 import json, sys, time, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import motion_primitive_library_amd as m
