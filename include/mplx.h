@@ -287,6 +287,42 @@ int mplx_comm_broadcast_map(mplx_ctx *ctx, int32_t root);
 int mplx_comm_allgather_lists(mplx_ctx *ctx, const mplx_packed_lists *d_local, int64_t n_local,
                               const mplx_packed_lists *d_all, int64_t *h_node_offs, int64_t *h_entry_offs);
 
+/* The schedule of that exchange as a PURE function (host arithmetic only: no
+ * device, no RCCL, no context) -- what mplx_comm_allgather_lists executes, and
+ * what a host with another transport (MPI, shared memory, a test's in-memory
+ * mailboxes) can execute itself.  `meta` is what the ranks all-gather first,
+ * MPLX_COMM_META int64 words per rank:
+ *   [0] n_local nodes   [1] packed entries   [2] mask of the rows the rank wants
+ *   gathered (MPLX_ROWBIT_*)   [3] capacity of the rank's d_all   [4] status of
+ *   the rank's own argument checks (MPLX_OK or an error code)   [5..7] zero.
+ * Every rank computes the SAME verdict from the same meta, so the ranks fail
+ * together instead of one returning while its peers wait in the group: the call
+ * returns MPLX_ERR_ARG / MPLX_ERR_STATE (and writes no ops) when any rank
+ * reported a status, the row masks differ, or the gathered entries exceed any
+ * rank's capacity.  Otherwise it returns the number of ops of `rank` (also when
+ * ops is NULL or `cap` too small: call again with room) and fills
+ * ops[0 .. min(n, cap)): first the local copies of the rank's own block, then per
+ * step d = 1 .. world-1 and per row one send to (rank + d) % world and one
+ * receive from (rank - d) % world (a different peer pair on every rank in every
+ * step: all xGMI links busy), zero-byte transfers omitted on BOTH sides (a
+ * transport pairs the k-th send of a -> b with the k-th receive of b from a).
+ * node_offs / entry_offs ([world + 1], may be NULL) receive the prefix sums.     */
+#define MPLX_COMM_META 8
+enum { MPLX_ROWBIT_ACTION = 1, MPLX_ROWBIT_COST = 2, MPLX_ROWBIT_HASH = 4, MPLX_ROWBIT_STATE = 8 };
+enum { MPLX_COMM_COPY = 0, MPLX_COMM_SEND = 1, MPLX_COMM_RECV = 2 };
+enum { MPLX_ROW_COUNT = 0, MPLX_ROW_ACTION = 1, MPLX_ROW_COST = 2, MPLX_ROW_HASH = 3, MPLX_ROW_STATE0 = 4 /* + field */ };
+typedef struct {
+  int32_t kind;     /* MPLX_COMM_COPY / _SEND / _RECV                                      */
+  int32_t peer;     /* the other rank (the own rank for a copy)                            */
+  int32_t row;      /* MPLX_ROW_*; a state field f is MPLX_ROW_STATE0 + f                  */
+  int32_t elem;     /* bytes per element of the row (4 or 8)                               */
+  int64_t src_off;  /* bytes into the rank's LOCAL row (send, copy); 0 for a receive       */
+  int64_t dst_off;  /* bytes into the rank's GATHERED row (receive, copy); 0 for a send    */
+  int64_t bytes;
+} mplx_comm_op;
+int64_t mplx_comm_schedule(int32_t world, int32_t rank, const int64_t *meta, int32_t n_fields,
+                           mplx_comm_op *ops, int64_t cap, int64_t *node_offs, int64_t *entry_offs);
+
 /* ---- batched re-validation of stored edges for incremental re-planning
  *       --------------------------------------------------- */
 /* For every edge (parent waypoint, action id): env_base::forward_action

@@ -6,7 +6,7 @@ The compute path is csrc/libmplx.so (hand-written HIP for gfx950).  Importing
 the package does not need a GPU; creating an EnvMap does, and there is no CPU
 fallback of any kind.
 """
-from . import _abi, workloads
+from . import _abi, shard, workloads
 from .env import (ACC, ACCxYAW, JRK, JRKxYAW, SNP, SNPxYAW, VEL, VELxYAW, SLOT_BLOCKED, SLOT_FINITE,
                   SLOT_SKIP_DYN, SLOT_SKIP_SAME, DeviceArray, EnvMap, Lists, PackedLists, Slots, Waypoint, lists_from_dense,
                   pack_host_lists)

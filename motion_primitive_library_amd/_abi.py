@@ -21,7 +21,7 @@ SYMBOLS = [
     "mplx_expand_device", "mplx_expand", "mplx_expand_lists_device", "mplx_expand_lists", "mplx_get_succ",
     "mplx_post_lists_device", "mplx_post_packed_device",
     "mplx_pack_lists_device", "mplx_comm_unique_id", "mplx_comm_init", "mplx_comm_destroy", "mplx_comm_broadcast_map",
-    "mplx_comm_allgather_lists",
+    "mplx_comm_allgather_lists", "mplx_comm_schedule",
     "mplx_check_edges",
     "mplx_device_alloc", "mplx_device_free", "mplx_memcpy_h2d", "mplx_memcpy_d2h", "mplx_memset",
     "mplx_synchronize", "mplx_timer_begin", "mplx_timer_end",
@@ -65,6 +65,15 @@ class PackedLists(C.Structure):
 
 
 COMM_ID_BYTES = 128
+COMM_META = 8
+ROWBIT_ACTION, ROWBIT_COST, ROWBIT_HASH, ROWBIT_STATE = 1, 2, 4, 8
+COMM_COPY, COMM_SEND, COMM_RECV = 0, 1, 2
+ROW_COUNT, ROW_ACTION, ROW_COST, ROW_HASH, ROW_STATE0 = 0, 1, 2, 3, 4
+
+
+class CommOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("peer", C.c_int32), ("row", C.c_int32), ("elem", C.c_int32),
+                ("src_off", C.c_int64), ("dst_off", C.c_int64), ("bytes", C.c_int64)]
 
 
 class GoalSpec(C.Structure):
@@ -149,6 +158,7 @@ def lib():
         "mplx_comm_destroy": (C.c_int, [vp]),
         "mplx_comm_broadcast_map": (C.c_int, [vp, i32]),
         "mplx_comm_allgather_lists": (C.c_int, [vp, C.POINTER(PackedLists), i64, C.POINTER(PackedLists), vp, vp]),
+        "mplx_comm_schedule": (i64, [i32, i32, vp, i32, C.POINTER(CommOp), i64, vp, vp]),
         "mplx_device_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
         "mplx_device_free": (C.c_int, [vp, vp]),
         "mplx_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),

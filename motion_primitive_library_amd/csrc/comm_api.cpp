@@ -20,6 +20,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 using namespace mplx_detail;
 
@@ -170,71 +171,161 @@ int mplx_comm_broadcast_map(mplx_ctx *c, int32_t root) {
   return MPLX_OK;
 }
 
+int64_t mplx_comm_schedule(int32_t world, int32_t rank, const int64_t *meta, int32_t n_fields, mplx_comm_op *ops,
+                           int64_t cap, int64_t *node_offs, int64_t *entry_offs) {
+  if (world < 1 || rank < 0 || rank >= world || !meta || n_fields < 0 || cap < 0) return MPLX_ERR_ARG;
+  const int G = world, me = rank;
+  auto M = [&](int r, int w) { return meta[(size_t)r * MPLX_COMM_META + w]; };
+  // ---- the verdict: a function of `meta` alone, hence the same on every rank
+  int64_t nsum = 0, esum = 0;
+  for (int r = 0; r < G; r++) {
+    if (M(r, 4) != MPLX_OK) return MPLX_ERR_STATE;                   // some rank failed its own argument checks
+    if (M(r, 0) < 0 || M(r, 1) < 0) return MPLX_ERR_ARG;
+    if (M(r, 2) != M(0, 2)) return MPLX_ERR_ARG;                     // the ranks disagree on the rows to gather
+    nsum += M(r, 0);
+    esum += M(r, 1);
+  }
+  for (int r = 0; r < G; r++)
+    if (esum > M(r, 3)) return MPLX_ERR_ARG;                         // some rank's gathered side is too small
+  if (node_offs || entry_offs) {
+    int64_t n = 0, e = 0;
+    for (int r = 0; r <= G; r++) {
+      if (node_offs) node_offs[r] = n;
+      if (entry_offs) entry_offs[r] = e;
+      if (r < G) { n += M(r, 0); e += M(r, 1); }
+    }
+  }
+  // ---- the rows, in the order they are issued
+  struct Row { int32_t row, elem; bool per_node; };
+  Row rows[4 + 64];
+  int nrows = 0;
+  const int64_t mask = M(0, 2);
+  rows[nrows++] = {MPLX_ROW_COUNT, 4, true};
+  if (mask & MPLX_ROWBIT_ACTION) rows[nrows++] = {MPLX_ROW_ACTION, 4, false};
+  if (mask & MPLX_ROWBIT_COST) rows[nrows++] = {MPLX_ROW_COST, 8, false};
+  if (mask & MPLX_ROWBIT_HASH) rows[nrows++] = {MPLX_ROW_HASH, 8, false};
+  if (mask & MPLX_ROWBIT_STATE)
+    for (int f = 0; f < n_fields && f < 64; f++) rows[nrows++] = {MPLX_ROW_STATE0 + f, 8, false};
+  std::vector<int64_t> noff((size_t)G + 1, 0), eoff((size_t)G + 1, 0);
+  for (int r = 0; r < G; r++) {
+    noff[(size_t)r + 1] = noff[(size_t)r] + M(r, 0);
+    eoff[(size_t)r + 1] = eoff[(size_t)r] + M(r, 1);
+  }
+  int64_t n_ops = 0;
+  auto put = [&](int32_t kind, int32_t peer, const Row &rw, int64_t src, int64_t dst, int64_t bytes) {
+    if (ops && n_ops < cap) ops[n_ops] = mplx_comm_op{kind, peer, rw.row, rw.elem, src, dst, bytes};
+    n_ops++;
+  };
+  auto units = [&](int r, const Row &rw) { return rw.per_node ? M(r, 0) : M(r, 1); };
+  auto start = [&](int r, const Row &rw) { return rw.per_node ? noff[(size_t)r] : eoff[(size_t)r]; };
+  for (int i = 0; i < nrows; i++)  // the rank's own block: a local copy into its place
+    if (units(me, rows[i])) put(MPLX_COMM_COPY, me, rows[i], 0, start(me, rows[i]) * rows[i].elem, units(me, rows[i]) * rows[i].elem);
+  for (int d = 1; d < G; d++) {
+    const int to = (me + d) % G, from = (me - d + G) % G;
+    for (int i = 0; i < nrows; i++) {
+      const Row &rw = rows[i];
+      if (units(me, rw)) put(MPLX_COMM_SEND, to, rw, 0, 0, units(me, rw) * rw.elem);
+      if (units(from, rw)) put(MPLX_COMM_RECV, from, rw, 0, start(from, rw) * rw.elem, units(from, rw) * rw.elem);
+    }
+  }
+  return n_ops;
+}
+
 int mplx_comm_allgather_lists(mplx_ctx *c, const mplx_packed_lists *loc, int64_t n_local, const mplx_packed_lists *all,
                               int64_t *h_node_offs, int64_t *h_entry_offs) {
   if (!c) return MPLX_ERR_ARG;
   if (!c->comm) return fail(c, MPLX_ERR_STATE, "mplx_comm_allgather_lists: mplx_comm_init first");
-  if (!loc || !all || n_local < 0 || !loc->offs || !loc->count || !all->offs || !all->count)
-    return fail(c, MPLX_ERR_ARG, "mplx_comm_allgather_lists: both sides need count and offs");
-  if ((all->action && !loc->action) || (all->cost && !loc->cost) || (all->hash && !loc->hash) || (all->state && !loc->state))
-    return fail(c, MPLX_ERR_ARG, "mplx_comm_allgather_lists: a gathered row is requested that the local side lacks");
   MPLX_GUARD_BEGIN
   if (int rc = bind_device(c)) return rc;
   if (int rc = resolve_pending(c)) return rc;
   ncclComm_t comm = (ncclComm_t)c->comm;
   const int G = c->comm_world, me = c->comm_rank, F = 4 * c->dim + 2;
-  // ---- (n_local, total) of every rank
-  if (int rc = ensure(c, c->comm_meta, (size_t)(G + 1) * 16)) return rc;
-  int64_t *d_meta = (int64_t *)c->comm_meta.p;  // [G][2], then one scratch pair
-  int64_t *d_mine = d_meta + 2 * G;
-  HIP_TRY(c, hipMemcpyAsync(d_mine, &n_local, 8, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(d_mine + 1, loc->offs + n_local, 8, hipMemcpyDeviceToDevice, c->stream));
-  NCCL_TRY(c, rccl().AllGather(d_mine, d_meta, 2, ncclInt64, comm, c->stream));
-  std::vector<int64_t> meta((size_t)2 * G);
-  HIP_TRY(c, hipMemcpyAsync(meta.data(), d_meta, (size_t)G * 16, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  std::vector<int64_t> noff((size_t)G + 1, 0), eoff((size_t)G + 1, 0);
-  for (int r = 0; r < G; r++) {
-    noff[(size_t)r + 1] = noff[(size_t)r] + meta[(size_t)2 * r];
-    eoff[(size_t)r + 1] = eoff[(size_t)r] + meta[(size_t)2 * r + 1];
+  // ---- this rank's own argument checks do NOT return yet: a rank that left here alone would leave its peers waiting
+  // in the collectives below.  Their verdict travels in the meta all-gather and every rank bails out together.
+  int my_status = MPLX_OK;
+  const char *my_msg = "";
+  if (!loc || !all || n_local < 0 || !loc->offs || !loc->count || !all->offs || !all->count) {
+    my_status = MPLX_ERR_ARG;
+    my_msg = "both sides need count and offs";
+  } else if ((all->action && !loc->action) || (all->cost && !loc->cost) || (all->hash && !loc->hash) || (all->state && !loc->state)) {
+    my_status = MPLX_ERR_ARG;
+    my_msg = "a gathered row is requested that the local side lacks";
+  } else if (all->state && all->state_stride < all->capacity) {
+    my_status = MPLX_ERR_ARG;
+    my_msg = "state_stride < capacity";
   }
-  if (meta[(size_t)2 * me] != n_local) return fail(c, MPLX_ERR_STATE, "mplx_comm_allgather_lists: rank order mismatch");
-  if (eoff[(size_t)G] > all->capacity)
-    return fail(c, MPLX_ERR_ARG, "mplx_comm_allgather_lists: %lld gathered entries exceed the capacity %lld",
-                (long long)eoff[(size_t)G], (long long)all->capacity);
-  if (all->state && all->state_stride < all->capacity)
-    return fail(c, MPLX_ERR_ARG, "mplx_comm_allgather_lists: state_stride < capacity");
+  const bool ok = my_status == MPLX_OK;
+  // ---- meta of every rank: (n_local, entries, row mask, capacity, status)
+  if (int rc = ensure(c, c->comm_meta, (size_t)(G + 1) * MPLX_COMM_META * 8)) return rc;
+  int64_t *d_meta = (int64_t *)c->comm_meta.p;  // [G][META], then this rank's own record
+  int64_t *d_mine = d_meta + (size_t)MPLX_COMM_META * G;
+  int64_t mine[MPLX_COMM_META] = {0};
+  mine[0] = ok ? n_local : 0;
+  mine[2] = ok ? (all->action ? MPLX_ROWBIT_ACTION : 0) | (all->cost ? MPLX_ROWBIT_COST : 0) | (all->hash ? MPLX_ROWBIT_HASH : 0) |
+                     (all->state ? MPLX_ROWBIT_STATE : 0) : 0;
+  mine[3] = ok ? all->capacity : 0;
+  mine[4] = my_status;
+  HIP_TRY(c, hipMemcpyAsync(d_mine, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+  if (ok) HIP_TRY(c, hipMemcpyAsync(d_mine + 1, loc->offs + n_local, 8, hipMemcpyDeviceToDevice, c->stream));
+  NCCL_TRY(c, rccl().AllGather(d_mine, d_meta, MPLX_COMM_META, ncclInt64, comm, c->stream));
+  std::vector<int64_t> meta((size_t)MPLX_COMM_META * G);
+  HIP_TRY(c, hipMemcpyAsync(meta.data(), d_meta, meta.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!ok) return fail(c, my_status, "mplx_comm_allgather_lists: %s", my_msg);
+  std::vector<int64_t> noff((size_t)G + 1, 0), eoff((size_t)G + 1, 0);
+  const int64_t n_ops = mplx_comm_schedule(G, me, meta.data(), F, nullptr, 0, noff.data(), eoff.data());
+  if (n_ops < 0) {  // the same verdict on every rank (a function of the gathered meta alone)
+    for (int r = 0; r < G; r++)
+      if (meta[(size_t)r * MPLX_COMM_META + 4] != MPLX_OK)
+        return fail(c, (int)n_ops, "mplx_comm_allgather_lists: rank %d failed its argument checks (code %lld)", r,
+                    (long long)meta[(size_t)r * MPLX_COMM_META + 4]);
+    for (int r = 0; r < G; r++)
+      if (meta[(size_t)r * MPLX_COMM_META + 2] != meta[2])
+        return fail(c, (int)n_ops, "mplx_comm_allgather_lists: rank %d gathers rows 0x%llx, rank 0 rows 0x%llx", r,
+                    (unsigned long long)meta[(size_t)r * MPLX_COMM_META + 2], (unsigned long long)meta[2]);
+    int64_t esum = 0;
+    for (int r = 0; r < G; r++) esum += meta[(size_t)r * MPLX_COMM_META + 1];
+    for (int r = 0; r < G; r++)
+      if (esum > meta[(size_t)r * MPLX_COMM_META + 3])
+        return fail(c, (int)n_ops, "mplx_comm_allgather_lists: %lld gathered entries exceed the capacity %lld of rank %d",
+                    (long long)esum, (long long)meta[(size_t)r * MPLX_COMM_META + 3], r);
+    return fail(c, (int)n_ops, "mplx_comm_allgather_lists: inconsistent sizes across the ranks");
+  }
+  if (meta[(size_t)me * MPLX_COMM_META] != n_local) return fail(c, MPLX_ERR_STATE, "mplx_comm_allgather_lists: rank order mismatch");
   if (h_node_offs) std::memcpy(h_node_offs, noff.data(), (size_t)(G + 1) * 8);
   if (h_entry_offs) std::memcpy(h_entry_offs, eoff.data(), (size_t)(G + 1) * 8);
-  // ---- all-pairs exchange: my rows to every peer, every peer's rows into their final place, one group
-  struct RowPair { const void *src; char *dst; int es_n; /* 0: per-entry row, 1: the per-node count row */ int es; };
-  std::vector<RowPair> rows;
-  rows.push_back({loc->count, (char *)all->count, 1, 4});
-  if (all->action) rows.push_back({loc->action, (char *)all->action, 0, 4});
-  if (all->cost) rows.push_back({loc->cost, (char *)all->cost, 0, 8});
-  if (all->hash) rows.push_back({loc->hash, (char *)all->hash, 0, 8});
-  if (all->state)
-    for (int f = 0; f < F; f++)
-      rows.push_back({loc->state + (size_t)f * loc->state_stride, (char *)(all->state + (size_t)f * all->state_stride), 0, 8});
-  const size_t my_n = (size_t)meta[(size_t)2 * me], my_e = (size_t)meta[(size_t)2 * me + 1];
-  for (const RowPair &rw : rows) {  // my own block: a device copy
-    const size_t bytes = (rw.es_n ? my_n : my_e) * (size_t)rw.es;
-    const size_t at = (size_t)(rw.es_n ? noff[(size_t)me] : eoff[(size_t)me]) * (size_t)rw.es;
-    if (bytes) HIP_TRY(c, hipMemcpyAsync(rw.dst + at, rw.src, bytes, hipMemcpyDeviceToDevice, c->stream));
-  }
-  if (G > 1) {
+  std::vector<mplx_comm_op> ops((size_t)n_ops);
+  (void)mplx_comm_schedule(G, me, meta.data(), F, ops.data(), n_ops, nullptr, nullptr);
+  // ---- execute: local copies, then every send / receive of the all-pairs exchange inside ONE group
+  auto src_of = [&](const mplx_comm_op &o) -> const char * {
+    switch (o.row) {
+      case MPLX_ROW_COUNT: return (const char *)loc->count;
+      case MPLX_ROW_ACTION: return (const char *)loc->action;
+      case MPLX_ROW_COST: return (const char *)loc->cost;
+      case MPLX_ROW_HASH: return (const char *)loc->hash;
+      default: return (const char *)(loc->state + (size_t)(o.row - MPLX_ROW_STATE0) * loc->state_stride);
+    }
+  };
+  auto dst_of = [&](const mplx_comm_op &o) -> char * {
+    switch (o.row) {
+      case MPLX_ROW_COUNT: return (char *)all->count;
+      case MPLX_ROW_ACTION: return (char *)all->action;
+      case MPLX_ROW_COST: return (char *)all->cost;
+      case MPLX_ROW_HASH: return (char *)all->hash;
+      default: return (char *)(all->state + (size_t)(o.row - MPLX_ROW_STATE0) * all->state_stride);
+    }
+  };
+  size_t k = 0;
+  for (; k < ops.size() && ops[k].kind == MPLX_COMM_COPY; k++)
+    HIP_TRY(c, hipMemcpyAsync(dst_of(ops[k]) + ops[k].dst_off, src_of(ops[k]) + ops[k].src_off, (size_t)ops[k].bytes,
+                              hipMemcpyDeviceToDevice, c->stream));
+  if (k < ops.size()) {
     NCCL_TRY(c, rccl().GroupStart());
     int e = 0;  // (a call that fails inside the group must not leave it open)
-    for (int d = 1; d < G && e == 0; d++) {
-      const int to = (me + d) % G, from = (me - d + G) % G;  // a different peer pair per step on every rank
-      const size_t fn = (size_t)meta[(size_t)2 * from], fe = (size_t)meta[(size_t)2 * from + 1];
-      for (const RowPair &rw : rows) {
-        const size_t sb = (rw.es_n ? my_n : my_e) * (size_t)rw.es;
-        const size_t rb = (rw.es_n ? fn : fe) * (size_t)rw.es;
-        const size_t at = (size_t)(rw.es_n ? noff[(size_t)from] : eoff[(size_t)from]) * (size_t)rw.es;
-        if (e == 0 && sb) e = rccl().Send(rw.src, sb, ncclInt8, to, comm, c->stream);
-        if (e == 0 && rb) e = rccl().Recv(rw.dst + at, rb, ncclInt8, from, comm, c->stream);
-      }
+    for (; k < ops.size() && e == 0; k++) {
+      const mplx_comm_op &o = ops[k];
+      if (o.kind == MPLX_COMM_SEND) e = rccl().Send(src_of(o) + o.src_off, (size_t)o.bytes, ncclInt8, o.peer, comm, c->stream);
+      else e = rccl().Recv(dst_of(o) + o.dst_off, (size_t)o.bytes, ncclInt8, o.peer, comm, c->stream);
     }
     const int e_end = rccl().GroupEnd();
     NCCL_TRY(c, e);

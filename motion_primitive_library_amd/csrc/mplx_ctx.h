@@ -113,7 +113,7 @@ struct mplx_ctx {
   // RCCL communicator of this context (comm_api.cpp); the library is loaded on first use
   void *comm = nullptr;
   int comm_rank = 0, comm_world = 1;
-  mplx_detail::DevBuf comm_meta;  // [world][2] int64: (n_local nodes, total entries) of every rank
+  mplx_detail::DevBuf comm_meta;  // [world + 1][MPLX_COMM_META] int64: the meta record of every rank, then the own one
   std::vector<uint8_t> h_status;
   std::vector<double> h_cost, h_state;
 };

@@ -146,3 +146,27 @@ def packed_struct(count_all, offs_all, rows_all):
     ps.state_stride = total
     ps.capacity = max(total, 1)
     return ps
+
+
+def comm_schedule(world, rank, meta, n_fields):
+    """mplx_comm_schedule (include/mplx.h): the all-pairs exchange mplx_comm_allgather_lists executes, as data.
+
+    meta : int64 [world][_abi.COMM_META] -- what the ranks all-gather first.
+    Returns (ops, node_offs, entry_offs); ops is a list of dicts (kind, peer, row, elem, src_off, dst_off, bytes).
+    Raises _abi.MplxError with the collective verdict when the meta is inconsistent (every rank raises the same).
+    Pure host arithmetic inside libmplx.so: needs neither a GPU nor RCCL."""
+    import ctypes as C
+
+    from . import _abi
+
+    L = _abi.lib()
+    meta = np.ascontiguousarray(meta, dtype=np.int64).reshape(world, _abi.COMM_META)
+    noff = np.zeros(world + 1, np.int64)
+    eoff = np.zeros(world + 1, np.int64)
+    n = L.mplx_comm_schedule(world, rank, meta.ctypes.data, n_fields, None, 0, noff.ctypes.data, eoff.ctypes.data)
+    if n < 0:
+        raise _abi.MplxError(int(n), "mplx_comm_schedule: the ranks' meta records are inconsistent")
+    ops = (_abi.CommOp * max(int(n), 1))()
+    n2 = L.mplx_comm_schedule(world, rank, meta.ctypes.data, n_fields, ops, int(n), None, None)
+    assert n2 == n
+    return ([{f: getattr(ops[i], f) for f, _ in _abi.CommOp._fields_} for i in range(int(n))], noff, eoff)

@@ -154,3 +154,93 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(tmp_path):
     g = d["allgather"]
     assert "error" not in g, g
     assert g["edges"]["entries"] == g["full"]["entries"] == d["roofline"]["emitted_all_ranks"] > 0
+
+
+def test_c_abi_allgather_refuses_a_short_gathered_side_collectively(engine):
+    """The capacity check is part of the collective verdict (mplx_comm_schedule on the gathered meta): with a world of
+    one it is simply the error; with more ranks every rank returns it instead of one leaving the others in the group."""
+    wl = engine.workloads.make("C4", scale=0.25, n_nodes=200)
+    env = engine_env(engine, wl)
+    env.comm_init(engine.EnvMap.comm_unique_id(), 0, 1)
+    fr, lists = _expand(engine, env, wl)
+    want = engine.pack_host_lists(lists.download(), wl.n_nodes)
+    packed = env.alloc_packed(wl.n_nodes)
+    env.pack_lists(lists, packed)
+    short = env.alloc_packed(wl.n_nodes, capacity=want["total"] - 1)
+    with pytest.raises(engine._abi.MplxError) as e:
+        env.comm_allgather_lists(packed, wl.n_nodes, short)
+    assert e.value.code == engine._abi.ERR_ARG and "capacity" in str(e.value)
+    lean_local = env.alloc_packed(wl.n_nodes, want_state=False)
+    env.pack_lists(lists, lean_local)
+    full = env.alloc_packed(wl.n_nodes, capacity=want["total"])
+    with pytest.raises(engine._abi.MplxError):  # a gathered row the local side lacks
+        env.comm_allgather_lists(lean_local, wl.n_nodes, full)
+    noff, eoff = env.comm_allgather_lists(packed, wl.n_nodes, full)  # the communicator is still usable
+    assert eoff[1] == want["total"]
+    _assert_packed_equal(full.download(), want)
+    env.comm_destroy()
+    for b in (packed, short, lean_local, full, lists, fr):
+        b.free()
+    env.close()
+
+
+def _two_gpu_rank(rank, world, id_q, out_q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch  # noqa: F401 -- one RCCL per process: torch's
+    import motion_primitive_library_amd as m
+    from motion_primitive_library_amd.shard import partition
+
+    wl = m.workloads.make("C4", scale=0.25, n_nodes=1001)  # not divisible by the world size
+    lo, hi = partition(wl.n_nodes, world, rank)
+    env = m.EnvMap(wl.dim, rank)
+    wl.apply(env)
+    if rank == 0:
+        uid = m.EnvMap.comm_unique_id()
+        for _ in range(world - 1):
+            id_q.put(uid)
+    else:
+        uid = id_q.get(timeout=120)
+    env.comm_init(uid, rank, world)
+    env.comm_broadcast_map(0)
+    fr = env.upload_frontier(np.ascontiguousarray(wl.nodes[:, lo:hi]))
+    lists = env.alloc_lists(hi - lo, want_state=True, want_iters=False)
+    env.expand_lists_resident(fr, lists)
+    packed = env.alloc_packed(hi - lo)
+    env.pack_lists(lists, packed)
+    gathered = env.alloc_packed(wl.n_nodes, capacity=wl.n_nodes * env.nU)
+    noff, eoff = env.comm_allgather_lists(packed, hi - lo, gathered)
+    got = gathered.download(wl.n_nodes)
+    env.comm_destroy()
+    env.close()
+    out_q.put((rank, noff[:world + 1].tolist(), eoff[:world + 1].tolist(), got))
+
+
+def test_c_abi_all_pairs_exchange_on_two_gpus(engine):
+    """The G > 1 branch of mplx_comm_allgather_lists (all-pairs ncclSend / ncclRecv in one group) on real devices:
+    one process per GPU, every rank must end up with the lists of the whole frontier.  Skipped on one-GPU boxes, where
+    tests/test_comm_schedule.py executes the same schedule against a host-memory transport."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (%d visible); the schedule itself is executed by tests/test_comm_schedule.py" % torch.cuda.device_count())
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    id_q, out_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_two_gpu_rank, args=(r, world, id_q, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out_q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    wl = engine.workloads.make("C4", scale=0.25, n_nodes=1001)
+    env = engine_env(engine, wl)
+    fr, lists = _expand(engine, env, wl)
+    want = engine.pack_host_lists(lists.download(), wl.n_nodes)
+    env.close()
+    for rank, noff, eoff, got in res:
+        assert noff == [0, 501, 1001] and eoff[-1] == want["total"]
+        _assert_packed_equal(got, want)
