@@ -228,11 +228,21 @@ def device_potential_fn(device=0, stats=None):
     return fn
 
 
-def make(name, scale=1.0, n_nodes=None, potential_fn=None):
+def make(name, scale=1.0, n_nodes=None, potential_fn=None, shell=False):
     """Build configuration `name` in {"C2","C3","C4","C5"}.  `scale` < 1
     shrinks the map edge (tests); n_nodes overrides the frontier size.
     potential_fn(grid, origin, res, radius) -> int8 map builds C5's potential map (device_potential_fn: on the
-    GPU); the default is the numpy restatement potential_field (33 s at 256^3: the checker of the device path)."""
+    GPU); the default is the numpy restatement potential_field (33 s at 256^3: the checker of the device path).
+    shell=True: geometry, controls and parameters only -- an all-free map and an all-zero frontier of the right
+    shapes -- for the ranks of a multi-GPU run that receive map and frontier from rank 0."""
+    if shell:
+        spec = {"C2": (2, 1024, 32, 4096), "C3": (3, 256, 16, 16384), "C4": (3, 512, 16, 65536), "C5": (3, 256, 16, 32768)}[name]
+        dim, edge = spec[0], max(spec[2], int(spec[1] * scale))
+        real = make(name, scale=16.0 / spec[1] if dim == 3 else 32.0 / spec[1], n_nodes=1,
+                    potential_fn=(lambda g, o, r, rad: np.zeros_like(g)) if name == "C5" else None)
+        grid = np.zeros((edge,) * dim, dtype=np.int8)
+        nodes = np.zeros((4 * dim + 2, n_nodes or spec[3]), dtype=np.float64)
+        return Workload(name, dim, real.control, grid, real.origin, real.res, real.U, nodes, real.params)
     if name == "C2":
         edge = max(32, int(1024 * scale))
         grid = box_map([edge, edge], 0.1, 0.20, 1002)

@@ -126,7 +126,8 @@ def test_torch_distributed_gather_of_engine_buffers_world_of_one(engine):
         dist.destroy_process_group()
 
 
-def test_bench_two_ranks_share_the_gpu_over_gloo(tmp_path):
+@pytest.mark.parametrize("launcher", ["self", "external"])
+def test_bench_two_ranks_share_the_gpu_over_gloo(tmp_path, launcher):
     """The whole `bench.py --gpus 2` flow (one process per rank under torch.distributed.run) rehearsed on the one GPU of
     the box: MPLX_BENCH_BACKEND=gloo lets both ranks use device 0 (RCCL refuses two ranks on one device).  THE frontier
     is partitioned, both legs run, the packed lists of both ranks are gathered on both, the timed lists pass the
@@ -141,13 +142,18 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(tmp_path):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, MPLX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--workload", "C4", "--scale", "0.25", "--nodes", "6001"]
-    proc = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+            "--workload", "C4", "--scale", "0.25", "--nodes", "6001"]
+    launchers = {"external": [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port)],
+                 "self": [sys.executable]}  # plain `python bench.py --gpus 2`: bench.py becomes the launcher itself
+    proc = subprocess.run(launchers[launcher] + tail, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
     line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
+    assert "rank 0's map broadcast" in d["config"]["map"] and d["ms_per_step_wall"] >= d["ms_per_step"] > 0
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["parity_sample_ok"] is True
     assert d["config"]["frontier_nodes"] == 6001 and d["config"]["frontier_nodes_per_gpu"] == 3001  # rank 0's block
     assert d["weak"]["frontier_nodes_per_gpu"] == 6001
