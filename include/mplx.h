@@ -354,6 +354,12 @@ int mplx_check_edges(mplx_ctx *ctx, const double *h_parents, const int32_t *h_ac
 
 /* ---- device memory + stream helpers (so any host language can keep the
  *      frontier and the successor slots resident in HBM) ------------------- */
+/* Ordering rule for buffers a launch READ (the frontier): writes through this API
+ * (mplx_memcpy_h2d, mplx_memset) are ordered after every earlier launch on the
+ * context, including the deferred heading-limit re-check of yaw controls, which
+ * re-reads the flagged nodes.  Writes the library cannot see (another stream,
+ * another library writing into memory handed over as pointers) must be preceded
+ * by mplx_synchronize -- as they must anyway not to race with the launch itself. */
 int mplx_device_alloc(mplx_ctx *ctx, size_t bytes, void **dptr);
 int mplx_device_free(mplx_ctx *ctx, void *dptr);
 int mplx_memcpy_h2d(mplx_ctx *ctx, void *dst, const void *src, size_t bytes);

@@ -177,12 +177,11 @@ int64_t mplx_comm_schedule(int32_t world, int32_t rank, const int64_t *meta, int
   const int G = world, me = rank;
   auto M = [&](int r, int w) { return meta[(size_t)r * MPLX_COMM_META + w]; };
   // ---- the verdict: a function of `meta` alone, hence the same on every rank
-  int64_t nsum = 0, esum = 0;
+  int64_t esum = 0;
   for (int r = 0; r < G; r++) {
     if (M(r, 4) != MPLX_OK) return MPLX_ERR_STATE;                   // some rank failed its own argument checks
     if (M(r, 0) < 0 || M(r, 1) < 0) return MPLX_ERR_ARG;
     if (M(r, 2) != M(0, 2)) return MPLX_ERR_ARG;                     // the ranks disagree on the rows to gather
-    nsum += M(r, 0);
     esum += M(r, 1);
   }
   for (int r = 0; r < G; r++)

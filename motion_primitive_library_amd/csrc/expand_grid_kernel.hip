@@ -420,7 +420,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
         const double sn = sqrt(vx0 * vx0 + vy0 * vy0);
         const double d = vx0 / sn * c0 + vy0 / sn * s0;
         dead = d < cos_lim;
-        yaw_amb = near_limit(d, cos_lim, A.yaw.margin, vy0, y0, A.yaw_max);
+        yaw_amb = near_limit(d, cos_lim, A.yaw.margin, vy0, y0, A.yaw.tie_yaw);
       }
       if (dead) {  // uniform
         if (lane == 0 && A.l_count) A.l_count[node] = 0;
@@ -569,7 +569,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
             const double sn = sqrt(vx0 * vx0 + vy0 * vy0);
             const double d = vx0 / sn * c0 + vy0 / sn * s0;
             if (d < cos_lim) mask = 0;
-            yaw_amb = yaw_amb || near_limit(d, cos_lim, A.yaw.margin, vy0, y0, A.yaw_max);
+            yaw_amb = yaw_amb || near_limit(d, cos_lim, A.yaw.margin, vy0, y0, A.yaw.tie_yaw);
           }
           const double vxT = qx.template vel<true>(T), vyT = qy.template vel<true>(T);
           if (vxT != 0 || vyT != 0) {
@@ -578,7 +578,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
             for (int jy = 0; jy < ndy; jy++) {
               const double d = nx * s_ycs[jy * 2] + ny * s_ycs[jy * 2 + 1];
               if (d < cos_lim) mask &= ~(1u << jy);
-              yaw_amb = yaw_amb || near_limit(d, cos_lim, A.yaw.margin, vyT, s_yawT[jy], A.yaw_max);
+              yaw_amb = yaw_amb || near_limit(d, cos_lim, A.yaw.margin, vyT, s_yawT[jy], A.yaw.tie_yaw);
             }
           }
         }

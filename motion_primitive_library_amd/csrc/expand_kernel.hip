@@ -209,12 +209,12 @@ struct Axis {
 // primitive.h:504-525, one end of the primitive.  cs: the host libm's {cos(yaw), sin(yaw)} in the override pass of
 // the yaw pinning (YawPin, mplx_internal.h), else null; *amb: the decision is within `margin` of the threshold.
 __device__ __forceinline__ bool heading_ok(double vx, double vy, double yaw, double cos_lim, const double *cs,
-                                           double margin, double yaw_max, bool *amb) {
+                                           double margin, double tie_yaw, bool *amb) {
   if (vx != 0 || vy != 0) {
     const double s = sqrt(vx * vx + vy * vy);
     const double c = cs ? cs[0] : cos(yaw), sn = cs ? cs[1] : sin(yaw);
     const double d = vx / s * c + vy / s * sn;
-    *amb = *amb || mplx::dev::near_limit(d, cos_lim, margin, vy, yaw, yaw_max);
+    *amb = *amb || mplx::dev::near_limit(d, cos_lim, margin, vy, yaw, tie_yaw);
     if (d < cos_lim) return false;
   }
   return true;
@@ -285,9 +285,9 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs A) {
     const double y0 = wrap_angle((0.0 + uyaw * 0.0) + cyaw);
     bool amb = false;
     const bool ok0 = heading_ok(ax[0].template vel<true>(0.0), ax[1].template vel<true>(0.0), y0, cos_lim,
-                                tab ? tab : nullptr, A.yaw.margin, A.yaw_max, &amb);
+                                tab ? tab : nullptr, A.yaw.margin, A.yaw.tie_yaw, &amb);
     const bool okT = heading_ok(nvel[0], nvel[1], nyaw, cos_lim, tab ? tab + 2 + 2 * ci : nullptr, A.yaw.margin,
-                                A.yaw_max, &amb);
+                                A.yaw.tie_yaw, &amb);
     valid = ok0 && okT;
     if (amb && A.yaw.amb) mplx::dev::flag_node(A.yaw.amb, A.yaw.amb_cap, node, A.yaw.any_host);
   }

@@ -588,6 +588,8 @@ bool yaw_pin_active(const mplx_ctx *c) {
   return c->tune.yaw_pin && (c->prm.control & 0x10) && c->prm.yaw_max > 0;
 }
 
+void host_sincos(double x, double *s, double *c);
+
 // The detection block of the next launch: a slot of the ring (older launches are resolved first when it is full).
 int yaw_slot(mplx_ctx *c, mplx::YawPin *y) {
   *y = mplx::YawPin{};
@@ -607,6 +609,13 @@ int yaw_slot(mplx_ctx *c, mplx::YawPin *y) {
   y->amb = (int32_t *)c->yaw_ring.p + c->yaw_pending.size() * (size_t)(1 + kAmbCap);
   y->amb_cap = kAmbCap;
   y->margin = c->tune.yaw_margin > 0 ? c->tune.yaw_margin : kYawMargin;
+  {  // is the x-aligned tie exact under THIS host's libm (near_limit, mplx_device_common.h)?
+    double sp, cp, sm, cm;
+    host_sincos(c->prm.yaw_max, &sp, &cp);
+    host_sincos(-c->prm.yaw_max, &sm, &cm);
+    const double lim = std::cos(c->prm.yaw_max);
+    y->tie_yaw = (cp == lim && cm == lim) ? c->prm.yaw_max : std::nan("");
+  }
   return MPLX_OK;
 }
 
@@ -864,9 +873,27 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
 }  // namespace
 
 namespace mplx_detail {
+namespace {
+// A failure after the pending list was swapped out: the ring still holds the counts and ids of launches that are no
+// longer pending, and the next launches would start on those slots -- ids beyond their own n_nodes.  Leave no trace.
+int resolve_failed(mplx_ctx *c, int rc) {
+  c->yaw_pending.clear();
+  if (c->yaw_any_host) *c->yaw_any_host = 0;
+  if (c->yaw_ring.p) {
+    (void)hipStreamSynchronize(c->stream);
+    if (hipMemsetAsync(c->yaw_ring.p, 0, c->yaw_ring.cap, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+      release(c->yaw_ring);  // re-allocated (and zeroed) by the next yaw_slot
+  }
+  return rc;
+}
+}  // namespace
+
 int resolve_pending(mplx_ctx *c) {
   if (c->yaw_pending.empty()) return MPLX_OK;
   MPLX_GUARD_BEGIN
+  // several contexts of one process may sit on different GPUs: the fix pass allocates (yaw_ids, yaw_tab) and launches,
+  // so the context's device must be the current one whatever entry point came through here
+  if (int rc = bind_device(c)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->yaw_any_host && *(volatile int32_t *)c->yaw_any_host == 0) {
     // nothing was flagged by any launch since the last resolve (the common case: the kernels set this pinned word
@@ -901,10 +928,11 @@ int resolve_pending(mplx_ctx *c) {
     const int64_t chunk = 16384;
     for (int64_t k0 = 0; k0 < (int64_t)ids.size(); k0 += chunk) {
       const int64_t nk = std::min<int64_t>(chunk, (int64_t)ids.size() - k0);
-      if (int rc = yaw_fix_pass(c, p, ids.data() + k0, nk)) return rc;
+      if (int rc = yaw_fix_pass(c, p, ids.data() + k0, nk)) return resolve_failed(c, rc);
     }
   }
-  if (any) HIP_TRY(c, hipMemsetAsync(c->yaw_ring.p, 0, np * slot * 4, c->stream));
+  if (any && hipMemsetAsync(c->yaw_ring.p, 0, np * slot * 4, c->stream) != hipSuccess)
+    return resolve_failed(c, fail(c, MPLX_ERR_HIP, "resolve_pending: clearing the detection ring failed"));
   return MPLX_OK;
   MPLX_GUARD_END(c)
 }
@@ -1084,6 +1112,8 @@ int mplx_device_free(mplx_ctx *c, void *dptr) {
 int mplx_memcpy_h2d(mplx_ctx *c, void *dst, const void *src, size_t bytes) {
   if (!c) return MPLX_ERR_ARG;
   if (int rc = bind_device(c)) return rc;
+  // the write may land in a frontier a pending launch read: its yaw fix pass re-reads the nodes, so it runs first
+  if (int rc = resolve_pending(c)) return rc;
   HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return MPLX_OK;
@@ -1101,6 +1131,7 @@ int mplx_memcpy_d2h(mplx_ctx *c, void *dst, const void *src, size_t bytes) {
 int mplx_memset(mplx_ctx *c, void *dst, int value, size_t bytes) {
   if (!c) return MPLX_ERR_ARG;
   if (int rc = bind_device(c)) return rc;
+  if (int rc = resolve_pending(c)) return rc;  // as mplx_memcpy_h2d
   HIP_TRY(c, hipMemsetAsync(dst, value, bytes, c->stream));
   return MPLX_OK;
 }

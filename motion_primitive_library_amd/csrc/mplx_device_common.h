@@ -63,10 +63,14 @@ __device__ __forceinline__ int wave_reduce_minmax(int v) {
 // ANY libm with an even cosine: velocity along x (vy == 0: the y term is an exact zero and vx / |v| is exactly +-1)
 // with |yaw| == yaw_max gives d = +-cos(yaw) against cos(yaw_max) = cos(|yaw|) -- equal, or 2 cos(yaw_max) apart.
 // Lattice searches hit that tie all the time (yaw_max and the yaw steps are the same multiples of 0.5), so it must
-// not count as ambiguous; it is decided identically by the device and by the host.
+// not count as ambiguous; it is decided identically by the device and by the host -- PROVIDED the host's cosine of
+// the pair sincos(+-yaw_max) (what GCC makes of primitive.h:519-520) is bit-equal to its stand-alone cos(yaw_max)
+// (primitive.h:521).  The host checks exactly that once per launch set-up (yaw_slot, mplx_api.cpp) and passes
+// tie_yaw = yaw_max when it holds, NaN when it does not: then nothing compares equal and the tie goes through the
+// host-pinned pass like every other decision inside the band.
 __device__ __forceinline__ bool near_limit(double d, double cos_lim, double margin, double vy, double yaw,
-                                           double yaw_max) {
-  if (vy == 0 && fabs(yaw) == yaw_max) return false;
+                                           double tie_yaw) {
+  if (vy == 0 && fabs(yaw) == tie_yaw) return false;
   return fabs(d - cos_lim) <= margin;
 }
 __device__ __forceinline__ void flag_node(int32_t *amb, int cap, int64_t node, int32_t *any_host) {

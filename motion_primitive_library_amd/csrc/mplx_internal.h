@@ -24,6 +24,8 @@ struct YawPin {
                               // that the host learns "nothing flagged" from its own memory, without a copy
   int32_t amb_cap;
   double margin;
+  double tie_yaw;             // detection: yaw_max when the "velocity along x, |yaw| == yaw_max" tie is exact under the host's
+                              // libm too (mplx_device_common.h near_limit), NaN when it is not (then no decision is exempt)
   const int32_t *node_list;   // override pass: the nodes to re-expand (kernel node k -> node_list[k]); null = all
   const double *tab;          // override pass: per listed node the host's trig values (layout per kernel); null = off
   int32_t tab_stride;         // doubles per listed node

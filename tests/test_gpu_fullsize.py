@@ -8,9 +8,11 @@ full-size launch are compared with the reference chunk by chunk --
   count, action order, lattice hash, cost, iteration count and the complete
   successor state (bit for bit, sign of zero included) of all 47.8 M pairs of
   C4 / 2 M of C3 / 102 k of C2 / 2.65 M of C5 and of C5 with a tunnel region
-(reference include/mpl_planner/env/env_map.h:147-172).  Where oracle/_ref is not
-built the restatement (oracle/libmpl_oracle.so) stands in, itself pinned to the
-reference by tests/test_oracle_vs_ref.py.  Size-independent properties on top:
+(reference include/mpl_planner/env/env_map.h:147-172) -- for the factorised kernel
+on every configuration and for the two general routes on the configurations they
+serve at full size (the workgroup-per-node kernel on C4, lane-per-pair + compaction
+on C3).  A box without oracle/_ref FAILS these tests (helpers.require_reference_build)
+instead of comparing with the restatement.  Size-independent properties on top:
   * the dense lane-per-pair kernel agrees with the lists on every pair;
   * expansion is a pure per-node function: permuting the frontier permutes the
     lists, expanding a node twice gives the same list (idempotence);
@@ -20,7 +22,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_lists_equal, engine_env, oracle_env
+from helpers import assert_lists_equal, engine_env, oracle_env, require_reference_build
 
 pytestmark = pytest.mark.gpu
 
@@ -54,20 +56,23 @@ def full_size_workload(engine, name):
     return wl
 
 
-@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5", "C5-tunnel"])
-def test_full_size_every_pair_against_the_reference(engine, oracle_lib, name):
+@pytest.mark.parametrize("name,route", [("C2", "grid"), ("C3", "grid"), ("C4", "grid"), ("C5", "grid"), ("C5-tunnel", "grid"),
+                                        ("C4", "tile"), ("C3", "dense")])
+def test_full_size_every_pair_against_the_reference(engine, oracle_lib, name, route):
+    use_ref = require_reference_build()
     wl = full_size_workload(engine, name)
     nU, N = wl.U.shape[0], wl.n_nodes
-    use_ref = os.path.exists(oracle_lib.REF_SO)
     threads = os.cpu_count() or 1
     oenv = oracle_env(wl)
     env = engine_env(engine, wl)
+    if route != "grid":
+        env.set_lists_route(route)
     # ONE full-size launch; the lists stay in HBM and are walked chunk by chunk
     fr = env.upload_frontier(wl.nodes)
     lists = env.alloc_lists(N, want_state=True, want_iters=True)
     env.expand_lists_resident(fr, lists)
     env.synchronize()
-    assert env.last_lists_route() == "grid"
+    assert env.last_lists_route() == route
     chunk = max(1, min(N, (6 << 20) // nU))  # ~6 M pairs (0.8 GB of reference output) at a time
     n_emit = n_fin = n_dyn = 0
     for lo in range(0, N, chunk):
@@ -76,15 +81,15 @@ def test_full_size_every_pair_against_the_reference(engine, oracle_lib, name):
         got = lists.download_nodes(lo, hi)
         # xYAW: the per-sample heading COST uses cos / sin (glibc there, OCML here): north_star's 1e-6 relative
         assert_lists_equal(got, ref, hi - lo, nU, cost_rtol=1e-6 if wl.control & 0x10 else 0.0,
-                           what="%s nodes [%d, %d) vs %s" % (name, lo, hi, "the reference build" if use_ref else "the oracle"))
+                           what="%s (%s route) nodes [%d, %d) vs %s" % (name, route, lo, hi, "the reference build" if use_ref else "the oracle"))
         st = ref["status"]
         n_emit += int(np.count_nonzero((st == 1) | (st == 2)))
         n_fin += int(np.count_nonzero(st == 1))
         n_dyn += int(np.count_nonzero(st == 3))
     total = lists.count.download(np.int32, (N,))
     assert int(total.sum(dtype=np.int64)) == n_emit
-    print("%s full size: all %d pairs vs %s: %d emitted, %d finite" % (
-        name, N * nU, "oracle/_ref (the reference's own headers)" if use_ref else "the oracle", n_emit, n_fin))
+    print("%s full size, %s route: all %d pairs vs %s: %d emitted, %d finite" % (
+        name, route, N * nU, "oracle/_ref (the reference's own headers)" if use_ref else "the oracle", n_emit, n_fin))
     assert n_fin > 0 and n_emit > n_fin and n_dyn > 0  # every outcome occurs
     lists.free()
     fr.free()

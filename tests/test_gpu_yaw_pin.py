@@ -6,12 +6,13 @@ glibc's; the device's cos / sin (OCML) differ from glibc's in the last place on 
 decision within rounding noise of the threshold could go either way.  The engine flags such nodes and re-expands
 them with trig values computed by the host (YawPin, csrc/mplx_internal.h).  Here the frontier is built ON the
 threshold -- headings a few 2^-55 rad either side of yaw_max away from the velocity direction, at t = 0 and at
-t = T -- and the successor SET must still be the oracle's (= the reference's: tests/test_oracle_vs_ref.py), for
-the lists kernel, the dense kernel and the dense -> lists route."""
+t = T -- and the successor SET must still be the reference build's (oracle/_ref: the reference's own headers compiled
+by GCC, so its cos / sin pair is the fused glibc sincos), for the lists kernel, the dense kernel and the
+dense -> lists route."""
 import numpy as np
 import pytest
 
-from helpers import assert_lists_equal, assert_slots_equal
+from helpers import assert_lists_equal, assert_slots_equal, require_reference_build
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -67,7 +68,10 @@ def oracle_of(wd):
 def test_decisions_on_the_threshold_are_the_host_libms(engine, monkeypatch):
     wd = threshold_world(engine)
     n, nU = wd["nodes"].shape[1], wd["U"].shape[0]
-    ref = O.expand(oracle_of(wd), wd["nodes"], threads=8)
+    # against the REFERENCE BUILD (its headers as GCC compiles them: cos(w.yaw), sin(w.yaw) of primitive.h:519-520 fused
+    # into one glibc sincos()) -- exactly the arithmetic the pinning reproduces; the restatement is not good enough here
+    use_ref = require_reference_build()
+    ref = O.expand(oracle_of(wd), wd["nodes"], threads=8, ref=use_ref)
     # the premise: the reference itself splits these nodes both ways
     st = ref["status"].reshape(n, nU)
     dead0 = np.all(st[: n // 2] != 1, axis=1)
