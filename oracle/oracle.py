@@ -271,25 +271,28 @@ def ref_plan(env, start_row, goal_row, use_gpu=False, epsilon=1.0, reps=1):
 SCENARIOS = {"distance": 0, "distance_yaw": 1, "distance_iterative": 2, "yaw": 3, "prior_traj": 4}
 
 
-def ref_scenario(env, start_row, goal_row, scenario, use_gpu=False):
+def ref_scenario(env, start_row, goal_row, scenario, use_gpu=False, via_base=False):
     """The scenarios of the reference's own test programs end to end, on the reference's MapPlanner:
     "distance" (test_distance_map_planner_2d.cpp), "distance_yaw" (..._with_yaw.cpp), "distance_iterative"
     (..._iterative.cpp), "yaw" (test_planner_2d_with_yaw.cpp; one stage), "prior_traj"
     (test_planner_2d_with_prior_traj.cpp).  env.U must be the {-0.5, 0, 0.5}^2 table.  use_gpu: MPL::GpuMapPlanner
     instead of MPL::MapPlanner in every stage (> 1: speculative batch size).  Returns the two stages' summaries."""
     lib = _LIBS.setdefault("ref_planner", C.CDLL(REF_PLANNER_SO))
-    lib.mpl_ref_scenario.restype = C.c_int
-    lib.mpl_ref_scenario.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                          C.POINTER(RefPlanOut), C.POINTER(C.c_double), C.POINTER(C.c_int64),
-                                          C.POINTER(C.c_int64)]
+    for fn in (lib.mpl_ref_scenario, lib.mpl_ref_scenario_via_base):
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(RefPlanOut),
+                       C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     s = np.ascontiguousarray(start_row, dtype=np.float64)
     g = np.ascontiguousarray(goal_row, dtype=np.float64)
     out = (RefPlanOut * 2)()
     chk = (C.c_double * 2)()
     region, pot = C.c_int64(0), C.c_int64(0)
     ce = env._c()
-    rc = lib.mpl_ref_scenario(C.byref(ce), s.ctypes.data, g.ctypes.data, int(use_gpu), SCENARIOS[scenario], out, chk,
-                                   C.byref(region), C.byref(pot))
+    # via_base: the drop-in (MPL::GpuMapPlanner) held through a MapPlanner<Dim> pointer -- the reference's non-virtual
+    # plan / setSearchRegion / updatePotentialMap / iterativePlan run, only get_succ is the device's
+    fn = lib.mpl_ref_scenario_via_base if via_base else lib.mpl_ref_scenario
+    rc = fn(C.byref(ce), s.ctypes.data, g.ctypes.data, int(use_gpu), SCENARIOS[scenario], out, chk,
+            C.byref(region), C.byref(pot))
     if rc != 0:
         raise RuntimeError("mpl_ref_scenario failed: %d" % rc)
     res = []

@@ -119,6 +119,9 @@ template <int D> int planner_launches(MPL::MapPlanner<D> &);
 template <int D> int planner_launches(MPL::GpuMapPlanner<D> &);
 template <int D> void set_batch(MPL::MapPlanner<D> &, int);
 template <int D> void set_batch(MPL::GpuMapPlanner<D> &, int);
+template <int D> struct ViaBase;
+template <int D> int planner_launches(ViaBase<D> &);
+template <int D> void set_batch(ViaBase<D> &, int);
 
 template <int D>
 void fill_out(MPL::MapPlanner<D> &pl, bool ok, double ms, int launches, mpl_ref_plan_out *o, double *checksum) {
@@ -277,6 +280,44 @@ int run_scenario(const mpl_oracle_env *e, const double *start_row, const double 
   *potential_sum = ps;
   return 0;
 }
+
+/* The drop-in held the way an application that only swaps the constructor holds it: through a MapPlanner<D>
+ * pointer.  plan / setSearchRegion / updatePotentialMap / iterativePlan are NOT virtual in the reference
+ * (map_planner.h, planner_base.h), so through this pointer the BASE versions run -- host preprocessing, then the
+ * virtual / fingerprinted hand-over to the device env (env_map_hip::set_potential_map, is_free, region fingerprint)
+ * -- and only get_succ is the device's.  INTEGRATION.md states which calls need the derived type; this type makes
+ * the run_scenario template exercise exactly the base-pointer route. */
+template <int D>
+struct ViaBase {
+  std::unique_ptr<MPL::MapPlanner<D>> p;
+  explicit ViaBase(bool verbose) : p(new MPL::GpuMapPlanner<D>(verbose, 0, 1)) {}
+  operator MPL::MapPlanner<D> &() { return *p; }
+  void setMapUtil(const std::shared_ptr<MPL::MapUtil<D>> &mu) { p->setMapUtil(mu); }  // virtual: installs env_map_hip
+  void setVmax(decimal_t v) { p->setVmax(v); }
+  void setAmax(decimal_t v) { p->setAmax(v); }
+  void setDt(decimal_t v) { p->setDt(v); }
+  void setW(decimal_t v) { p->setW(v); }
+  void setEpsilon(decimal_t v) { p->setEpsilon(v); }
+  void setYawmax(decimal_t v) { p->setYawmax(v); }
+  void setTol(decimal_t v) { p->setTol(v); }
+  void setU(const vec_E<VecDf> &u) { p->setU(u); }
+  void setPriorTrajectory(const Trajectory<D> &t) { p->setPriorTrajectory(t); }
+  void setSearchRadius(const Vecf<D> &r) { p->setSearchRadius(r); }
+  void setSearchRegion(const vec_Vecf<D> &path) { p->setSearchRegion(path); }   // BASE version (host ray trace)
+  void setPotentialRadius(const Vecf<D> &r) { p->setPotentialRadius(r); }
+  void setPotentialWeight(decimal_t w) { p->setPotentialWeight(w); }
+  void setGradientWeight(decimal_t w) { p->setGradientWeight(w); }
+  void updatePotentialMap(const Vecf<D> &pos) { p->updatePotentialMap(pos); }   // BASE version (host scatter)
+  bool plan(const Waypoint<D> &s, const Waypoint<D> &g) { return p->plan(s, g); }  // BASE version (no device check)
+  bool iterativePlan(const Waypoint<D> &s, const Waypoint<D> &g, const Trajectory<D> &t, int n) {
+    return p->iterativePlan(s, g, t, n);
+  }
+  Trajectory<D> getTraj() const { return p->getTraj(); }
+  vec_Vecf<D> getSearchRegion() const { return p->getSearchRegion(); }
+  MPL::GpuMapPlanner<D> &derived() { return *static_cast<MPL::GpuMapPlanner<D> *>(p.get()); }
+};
+template <int D> int planner_launches(ViaBase<D> &p) { return p.derived().deviceLaunches(); }
+template <int D> void set_batch(ViaBase<D> &p, int b) { p.derived().setBatch(b > 1 ? b : 1); }
 
 template <int D>
 int planner_launches(MPL::MapPlanner<D> &) { return 0; }
@@ -546,6 +587,14 @@ extern "C" int mpl_ref_lpastar(const mpl_oracle_env *env, const double *start, c
   return -1;
 }
 
+/* the same scenarios with the drop-in held through a MapPlanner<D> base pointer (ViaBase above) */
+extern "C" int mpl_ref_scenario_via_base(const mpl_oracle_env *env, const double *start, const double *goal, int batch,
+                                         int mode, mpl_ref_plan_out *out2, double *checksum2, int64_t *region_cells,
+                                         int64_t *potential_sum) {
+  if (!env || !start || !goal || !out2 || env->dim != 2 || mode < 0 || mode > 4) return -1;
+  return run_scenario<2, ViaBase<2>>(env, start, goal, mode, batch, out2, checksum2, region_cells, potential_sum);
+}
+
 /* ---- adapter robustness: a device failure must be distinguishable from "no trajectory" ---- */
 extern "C" int mpl_gpu_plan_on_device(const mpl_oracle_env *e, const double *start_row, const double *goal_row,
                                       int device, int32_t *plan_ok, int32_t *device_ok, char *err, int err_cap) {
@@ -574,5 +623,38 @@ extern "C" int mpl_gpu_plan_on_device(const mpl_oracle_env *e, const double *sta
   *plan_ok = pl.plan(s, g) ? 1 : 0;
   *device_ok = pl.deviceOk() ? 1 : 0;
   if (err && err_cap > 0) snprintf(err, (size_t)err_cap, "%s", pl.deviceError().c_str());
+  return 0;
+}
+
+/* the same through a MapPlanner<2> pointer: the base plan() cannot check the device (it returns "no trajectory"),
+ * the latch is still there for an application that asks the derived type afterwards */
+extern "C" int mpl_gpu_plan_on_device_via_base(const mpl_oracle_env *e, const double *start_row, const double *goal_row,
+                                               int device, int32_t *plan_ok, int32_t *device_ok, char *err, int err_cap) {
+  if (!e || e->dim != 2 || !plan_ok || !device_ok) return -1;
+  constexpr int D = 2;
+  std::shared_ptr<MPL::MapUtil<D>> mu = std::make_shared<MPL::MapUtil<D>>();
+  Vecf<D> ori;
+  Veci<D> dim;
+  size_t n = 1;
+  for (int i = 0; i < D; i++) { ori(i) = e->origin[i]; dim(i) = e->map_dim[i]; n *= (size_t)e->map_dim[i]; }
+  mu->setMap(ori, dim, MPL::Tmap(e->map, e->map + n), e->res);
+  std::unique_ptr<MPL::MapPlanner<D>> pl(new MPL::GpuMapPlanner<D>(false, device, 1));
+  pl->setMapUtil(mu);
+  pl->setVmax(e->v_max);
+  pl->setAmax(e->a_max);
+  pl->setDt(e->dt);
+  vec_E<VecDf> U;
+  for (int i = 0; i < e->nU; i++) {
+    VecDf u(e->udim);
+    for (int k = 0; k < e->udim; k++) u(k) = e->U[(size_t)i * e->udim + k];
+    U.push_back(u);
+  }
+  pl->setU(U);
+  Waypoint<D> s((Control::Control)e->control), g((Control::Control)e->control);
+  for (int i = 0; i < D; i++) { s.pos(i) = start_row[i]; g.pos(i) = goal_row[i]; }
+  *plan_ok = pl->plan(s, g) ? 1 : 0;  // PlannerBase::plan
+  MPL::GpuMapPlanner<D> *gp = static_cast<MPL::GpuMapPlanner<D> *>(pl.get());
+  *device_ok = gp->deviceOk() ? 1 : 0;
+  if (err && err_cap > 0) snprintf(err, (size_t)err_cap, "%s", gp->deviceError().c_str());
   return 0;
 }

@@ -114,6 +114,37 @@ def test_reference_test_scenarios_with_dropin_adapter(engine, scenario):
         assert gpu[1]["region_cells"] == cpu[1]["region_cells"] and gpu[1]["potential_sum"] == cpu[1]["potential_sum"]
 
 
+@pytest.mark.parametrize("scenario", ["distance", "distance_yaw", "prior_traj"])
+def test_dropin_adapter_through_a_base_class_pointer(engine, scenario):
+    """INTEGRATION.md's caveat, exercised: an application that only swaps the constructor holds the drop-in as
+    MapPlanner<Dim>*.  plan / setSearchRegion / updatePotentialMap / iterativePlan are not virtual in the reference,
+    so the BASE versions run (host ray trace, host potential scatter, no device check in plan) and hand their results
+    to the device env through what IS virtual or fingerprinted (set_potential_map, is_free, the region fingerprint);
+    get_succ is the device's.  Every stage must still be the reference's search, and the device must really have
+    served it (launches > 0)."""
+    import os
+    from oracle import oracle as O
+    if not os.path.exists(O.REF_PLANNER_SO):
+        pytest.skip("oracle/_ref/libmpl_ref_planner.so not built")
+    c = corridor()
+    U = engine.workloads.grid_controls([-0.5, 0.0, 0.5], 2)
+    oenv = O.Env(2, O.ACC, U, c["cells"], c["dim"], c["origin"], c["res"], v_max=1.0, a_max=1.0, dt=1.0)
+    start = engine.Waypoint(2, engine.ACC, pos=c["start"]).to_row()
+    goal = engine.Waypoint(2, engine.ACC, pos=c["goal"]).to_row()
+    cpu = O.ref_scenario(oenv, start, goal, scenario)
+    yaw_stage = {"distance_yaw": (1,)}.get(scenario, ())
+    for batch in (1, 64):
+        gpu = O.ref_scenario(oenv, start, goal, scenario, use_gpu=batch, via_base=True)
+        for stage in (0, 1):
+            assert gpu[stage]["device_launches"] > 0
+            for k in ("ok", "closed", "opened", "expansions", "segments", "total_time", "J"):
+                assert gpu[stage][k] == cpu[stage][k], (batch, stage, k, gpu[stage][k], cpu[stage][k])
+            tol = 1e-9 if stage in yaw_stage else 0.0
+            assert abs(gpu[stage]["cost"] - cpu[stage]["cost"]) <= tol * abs(cpu[stage]["cost"])
+            assert abs(gpu[stage]["traj_checksum"] - cpu[stage]["traj_checksum"]) <= tol * abs(cpu[stage]["traj_checksum"])
+        assert gpu[1]["region_cells"] == cpu[1]["region_cells"] and gpu[1]["potential_sum"] == cpu[1]["potential_sum"]
+
+
 _REF_PINS = {  # the reference's MapPlanner on the CPU (tests/test_plan_known_answer.py pins the same numbers)
     "distance": dict(closed=2732, cost=647.0999999999999, T=36.0, J=[40.08333333333333, 7.0]),
     "distance_iterative": dict(closed=3419, cost=617.45, T=37.0, J=[42.833333333333336, 7.75]),

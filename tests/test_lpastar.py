@@ -98,3 +98,22 @@ def test_gpu_adapter_reports_a_device_failure_instead_of_no_path(engine):
                                           err, 512) == 0
         assert bool(ok.value) == want_ok and bool(dev_ok.value) == want_ok
         assert (err.value == b"") == want_ok, err.value
+
+
+def test_device_failure_through_a_base_class_pointer_is_still_latched(engine):
+    """The drop-in held as MapPlanner<2>*: PlannerBase::plan (not virtual) runs, so a device failure comes back as
+    "no trajectory" -- but the latch is set and an application that asks the derived type learns why
+    (hold the planner as GpuMapPlanner, or check deviceOk() after plan())."""
+    oenv, s, g = corridor_problem(engine)
+    lib = C.CDLL(O.REF_PLANNER_SO)
+    lib.mpl_gpu_plan_on_device_via_base.restype = C.c_int
+    lib.mpl_gpu_plan_on_device_via_base.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32),
+                                                    C.POINTER(C.c_int32), C.c_char_p, C.c_int]
+    ce = oenv._c()
+    for device, want_ok in ((0, True), (4096, False)):
+        ok, dev_ok = C.c_int32(-1), C.c_int32(-1)
+        err = C.create_string_buffer(512)
+        assert lib.mpl_gpu_plan_on_device_via_base(C.byref(ce), s.ctypes.data, g.ctypes.data, device, C.byref(ok),
+                                                   C.byref(dev_ok), err, 512) == 0
+        assert bool(ok.value) == want_ok and bool(dev_ok.value) == want_ok
+        assert (err.value == b"") == want_ok, err.value
