@@ -100,6 +100,8 @@ def test_gpu_adapter_reports_a_device_failure_instead_of_no_path(engine):
         assert (err.value == b"") == want_ok, err.value
 
 
+@pytest.mark.gpu
+@needs_ref
 def test_device_failure_through_a_base_class_pointer_is_still_latched(engine):
     """The drop-in held as MapPlanner<2>*: PlannerBase::plan (not virtual) runs, so a device failure comes back as
     "no trajectory" -- but the latch is set and an application that asks the derived type learns why
