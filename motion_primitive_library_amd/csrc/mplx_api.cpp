@@ -143,7 +143,7 @@ void mplx_destroy(mplx_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->map, &c->pot, &c->region_bits, &c->region_bytes, &c->U, &c->s_nodes, &c->s_status,
                     &c->s_cost, &c->s_hash, &c->s_state, &c->s_iters, &c->s_count, &c->s_action, &c->tables,
-                    &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx, &c->blk, &c->sat, &c->prep_lut, &c->prep_a, &c->prep_b, &c->post_keys, &c->e_parents, &c->e_action, &c->e_free, &c->e_cost, &c->e_cells, &c->e_count})
+                    &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx, &c->blk, &c->sat, &c->prep_lut, &c->prep_a, &c->prep_b, &c->post_keys, &c->post_ws, &c->e_parents, &c->e_action, &c->e_free, &c->e_cost, &c->e_cells, &c->e_count})
     release(*b);
   (void)mplx_comm_destroy(c);
   release(c->comm_meta);

@@ -46,6 +46,7 @@ struct mplx_ctx {
   bool sat_ok = false;   // summed-area table of blk is current
   mplx_detail::DevBuf e_parents, e_action, e_free, e_cost, e_cells, e_count;  // edge re-validation staging
   mplx_detail::DevBuf post_keys;                 // node-identity table (post_api.cpp)
+  mplx_detail::DevBuf post_ws;                   // workspace of the partitioned identity pass (identity_kernel.hip)
   mplx_detail::DevBuf prep_lut, prep_a, prep_b;  // map preprocessing scratch (map_prep_api.cpp)
   bool blk_ok = false;   // blocked-bit map matches the current map + region
   bool u_factored = false;

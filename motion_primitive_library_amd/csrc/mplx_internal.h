@@ -230,9 +230,31 @@ struct PostArgs {
   int32_t *canon;
   struct Slot { uint64_t key; uint32_t val; uint32_t pad; };
   Slot *keys;              // identity table: cap + 1 slots, cap a power of two; key = ~0 empty, val = smallest index
-  uint64_t cap;
+  uint64_t cap;            // (keys == null and canon != null: canon was filled by launch_identity before this launch)
 };
 hipError_t launch_post_lists(int dim, const PostArgs &args, hipStream_t s);
+
+// Node identity by radix partition + per-bucket LDS tables (identity_kernel.hip): canon[g] = smallest list index with
+// the same lattice hash, for every emitted successor g.  The lists are the strided form (packed lists: n_nodes = 1,
+// nstride = capacity, count = &total).
+struct IdentityArgs {
+  const int32_t *count;
+  const uint64_t *hash;
+  int64_t n_nodes, nstride;
+  int32_t *canon;
+  uint64_t *hk[2];   // workspace: (hash, list index) pairs after partition level 1 / 2, n_slots each
+  uint32_t *gi[2];
+  uint32_t *cnt[2];  // per level: (digit, tile) counters -> exclusive prefix sums inside 4096-blocks
+  uint32_t *tot[2];  // per level: scanned block totals, [blocks + 1]
+  uint32_t *seg;     // level-1 buckets as segments of level 2: start[nb1 + 1], tile prefix[nb1 + 1]
+  int64_t n_slots, tiles1, tiles2_cap;
+  int b1, b2;        // digit bits of the two levels (b2 = 0: one level)
+  int fill;          // distinct keys one round of a bucket's LDS table takes (identity_default_fill(); tests lower it)
+};
+int identity_default_fill();
+void identity_plan(int64_t n_slots, int *b1, int *b2);
+void identity_sizes(int64_t n_slots, int b1, int b2, int64_t *tiles1, int64_t *tiles2_cap, int64_t *ctr1, int64_t *ctr2);
+hipError_t launch_identity(const IdentityArgs &a, int64_t ctr1, int64_t ctr2, hipStream_t s);
 
 // Map preprocessing (map_prep_kernel.hip).  d, c1, c2: 3 entries (unused axes 1 / [0,1)).
 hipError_t launch_potential_passes(const int8_t *map, const int32_t *d, const int32_t *c1, const int32_t *c2, int rn,

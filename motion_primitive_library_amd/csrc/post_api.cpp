@@ -4,6 +4,8 @@
 #include "mplx_ctx.h"
 #include "host_planner.hpp"
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 using namespace mplx_detail;
@@ -42,7 +44,45 @@ static int post_lists_impl(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t 
   a.heur = d_out->heur;
   a.flags = d_out->flags;
   a.canon = d_out->canon;
-  if (d_out->canon) {
+  // node identity: batches above ~256 k slots go through the radix partition + LDS tables (identity_kernel.hip), small
+  // ones through the table in HBM (two launches).  MPLX_POST_PARTITION_MIN moves the switch (tests: 0 = always).
+  const char *e_min = getenv("MPLX_POST_PARTITION_MIN"), *e_fill = getenv("MPLX_POST_FILL"), *e_bits = getenv("MPLX_POST_BITS");
+  const int64_t partition_min = e_min ? (int64_t)atoll(e_min) : (int64_t)1 << 18;
+  if (d_out->canon && n >= partition_min) {
+    mplx::IdentityArgs ia{};
+    ia.count = d_lists->count;
+    ia.hash = d_lists->hash;
+    ia.n_nodes = n_nodes;
+    ia.nstride = S;
+    ia.canon = d_out->canon;
+    ia.n_slots = n;
+    mplx::identity_plan(n, &ia.b1, &ia.b2);
+    if (e_bits) {  // diagnostic: "b1,b2" (b1 <= 6 with two levels, <= 8 with one; b2 <= 8)
+      int x = 0, y = 0;
+      if (sscanf(e_bits, "%d,%d", &x, &y) == 2 && x >= 0 && y >= 0 && y <= 8 && x <= (y ? 6 : 8)) { ia.b1 = x; ia.b2 = y; }
+    }
+    ia.fill = mplx::identity_default_fill();
+    if (e_fill && atoi(e_fill) >= 1 && atoi(e_fill) < ia.fill) ia.fill = atoi(e_fill);
+    int64_t ctr1 = 0, ctr2 = 0;
+    mplx::identity_sizes(n, ia.b1, ia.b2, &ia.tiles1, &ia.tiles2_cap, &ctr1, &ctr2);
+    const int levels = ia.b2 ? 2 : 1;
+    // one allocation: pairs of both levels, counters, block totals, segments
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t sz_h = up((size_t)n * 8), sz_g = up((size_t)n * 4);
+    const size_t sz_c1 = up((size_t)ctr1 * 4), sz_c2 = up((size_t)ctr2 * 4);
+    const size_t sz_t1 = up((size_t)(ctr1 / 4096 + 1) * 4), sz_t2 = up((size_t)(ctr2 / 4096 + 1) * 4);
+    const size_t total = levels * (sz_h + sz_g) + sz_c1 + sz_c2 + sz_t1 + sz_t2 + 1024;
+    if (int rc = ensure(c, c->post_ws, total)) return rc;
+    char *w = (char *)c->post_ws.p;
+    for (int l = 0; l < levels; l++) { ia.hk[l] = (uint64_t *)w; w += sz_h; }
+    for (int l = 0; l < levels; l++) { ia.gi[l] = (uint32_t *)w; w += sz_g; }
+    ia.cnt[0] = (uint32_t *)w; w += sz_c1;
+    ia.cnt[1] = (uint32_t *)w; w += sz_c2;
+    ia.tot[0] = (uint32_t *)w; w += sz_t1;
+    ia.tot[1] = (uint32_t *)w; w += sz_t2;
+    ia.seg = (uint32_t *)w;
+    HIP_TRY(c, mplx::launch_identity(ia, ctr1, ctr2, c->stream));
+  } else if (d_out->canon) {
     uint64_t cap = 1024;
     while (cap < max_entries) cap <<= 1;  // >= the emitted successors whatever the frontier
     if (cap < 2 * max_entries && cap < (1ull << 27)) cap <<= 1;

@@ -15,9 +15,11 @@
 //                   host creates each new state once and only transfers the rest
 //                   as edges.  Deterministic: the canonical duplicate is the one
 //                   with the smallest list index.
-// The identity pass is an open-addressing table in HBM keyed by the 64-bit lattice
-// hash (linear probing, 64-bit CAS for the key, 32-bit atomicMin for the index;
-// key and index share one 16-byte slot, so each successor touches one line per pass).
+// The identity pass of SMALL batches (below ~256 k list slots: the batches of a search) is an open-addressing table
+// in HBM keyed by the 64-bit lattice hash (linear probing, 64-bit CAS for the key, 32-bit atomicMin for the index;
+// key and index share one 16-byte slot, so each successor touches one line per pass): two launches, latency bound.
+// Large batches (a whole frontier's lists, the gathered lists of all GPUs) take identity_kernel.hip: radix
+// partition + per-bucket tables in LDS, the same canon[] at memory bandwidth.
 #include "mplx_internal.h"
 
 namespace mplx {
@@ -69,7 +71,10 @@ __global__ __launch_bounds__(256) void post_lists_kernel(const PostArgs A) {
       goaled = ma <= A.tol_acc;
     }
     if (goaled && A.tol_yaw >= 0) goaled = fabs(A.state[(int64_t)(4 * D) * A.sstride + g] - A.goal[4 * D]) <= A.tol_yaw;
-    A.flags[g] = (uint8_t)((goaled ? 1 : 0) | (is_goal_state ? 2 : 0));
+    // bit 2 (first occurrence of the lattice state in the batch): from canon[] when the partitioned identity pass
+    // (identity_kernel.hip) ran before this launch; the table route sets it in post_canon_kernel
+    const bool first = !A.keys && A.canon && A.canon[g] == (int32_t)g;
+    A.flags[g] = (uint8_t)((goaled ? 1 : 0) | (is_goal_state ? 2 : 0) | (first ? 4 : 0));
   }
   if (A.keys) {
     if (h == kEmpty) {  // the one hash the key field cannot hold: a dedicated slot past the table

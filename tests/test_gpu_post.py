@@ -120,3 +120,81 @@ def test_post_on_packed_lists_equals_post_on_the_strided_lists(engine):
     for b in (packed, lists, fr):
         b.free()
     env.close()
+
+
+def _want_canon(h, idx):
+    order = np.lexsort((idx, h))
+    hs, ids = h[order], idx[order]
+    first = np.concatenate([[True], hs[1:] != hs[:-1]])
+    canon_sorted = np.maximum.accumulate(np.where(first, np.arange(ids.size), 0))
+    want = np.empty(idx.size, np.int64)
+    want[order] = ids[canon_sorted]
+    return want
+
+
+@pytest.mark.parametrize("knobs", [
+    {},                                                        # automatic: two partition levels at this size
+    {"MPLX_POST_BITS": "3,0"},                                 # one level, 8 buckets of ~50 k successors: many rounds per bucket
+    {"MPLX_POST_BITS": "6,8", "MPLX_POST_FILL": "40"},         # finest partition, tiny tables: rounds in most buckets
+    {"MPLX_POST_BITS": "0,0", "MPLX_POST_FILL": "900"},        # ONE bucket for everything
+    {"MPLX_POST_PARTITION_MIN": "1000000000"},                 # the table in HBM (the small-batch route) on the same input
+])
+def test_partitioned_identity_equals_first_occurrence(engine, monkeypatch, knobs):
+    """identity_kernel.hip (radix partition + LDS tables) against the definition: canon[g] = smallest list index with
+    the same lattice hash, bit 2 of the flags = first occurrence -- on a frontier with heavy duplication (repeated
+    nodes, a lattice start region) so that buckets hold far more successors than distinct keys, for partitions finer
+    and coarser than the automatic one and for tables that overflow into further rounds."""
+    monkeypatch.setenv("MPLX_POST_PARTITION_MIN", "0")
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    wl = engine.workloads.make("C4", scale=0.25, n_nodes=3000)
+    rng = np.random.default_rng(9)
+    wl.nodes[:, 1000:2000] = wl.nodes[:, rng.integers(0, 1000, size=1000)]   # every third node a repeat
+    wl.nodes[:3, 2000:2300] = np.round(wl.nodes[:3, 2000:2001], 1)           # 300 nodes on one lattice position
+    env = engine_env(engine, wl)
+    fr = env.upload_frontier(wl.nodes)
+    lists = env.alloc_lists(wl.n_nodes, want_state=True, want_iters=False)
+    env.expand_lists_resident(fr, lists)
+    env.synchronize()
+    L = lists.download()
+    idx = _emitted_indices(L)
+    assert idx.size > 400000
+    goal = wl.nodes[:, 7].copy()
+    got = env.post_lists(lists, goal, tol_pos=0.6)
+    want = _want_canon(L["hash"][idx], idx)
+    assert np.array_equal(got["canon"][idx].astype(np.int64), want)
+    assert np.array_equal((got["flags"][idx] & 4) != 0, want == idx)
+    assert (want != idx).sum() > 100000
+    # the packed form (one long list; what the multi-GPU merge runs on)
+    packed = env.alloc_packed(wl.n_nodes)
+    env.pack_lists(lists, packed)
+    gp = env.post_packed(packed, wl.n_nodes, goal, tol_pos=0.6)
+    hp = packed.download()["hash"]
+    wantp = _want_canon(hp, np.arange(hp.size, dtype=np.int64))
+    assert np.array_equal(gp["canon"].astype(np.int64), wantp)
+    assert np.array_equal((gp["flags"] & 4) != 0, wantp == np.arange(hp.size))
+    for b in (packed, lists, fr):
+        b.free()
+    env.close()
+
+
+def test_partitioned_identity_full_size_c4(engine):
+    """C4's whole frontier (20.4 M successors in 48 M list slots): the partitioned pass against numpy."""
+    wl = engine.workloads.make("C4")
+    env = engine_env(engine, wl)
+    fr = env.upload_frontier(wl.nodes)
+    lists = env.alloc_lists(wl.n_nodes, want_state=True, want_iters=False)
+    env.expand_lists_resident(fr, lists)
+    env.synchronize()
+    got = env.post_lists(lists, wl.nodes[:, 0].copy())
+    h = lists.hash.download(np.uint64, (lists.n_slots,))
+    cnt = lists.count.download(np.int32, (wl.n_nodes,))
+    S = lists.stride
+    valid = (np.arange(S)[None, :] < cnt[:, None]).ravel()
+    idx = np.nonzero(valid)[0].astype(np.int64)
+    want = _want_canon(h[idx], idx)
+    assert np.array_equal(got["canon"][idx].astype(np.int64), want)
+    assert np.array_equal((got["flags"][idx] & 4) != 0, want == idx)
+    lists.free()
+    fr.free()
+    env.close()
