@@ -30,8 +30,10 @@ constexpr uint64_t kEmpty = ~0ull;
 constexpr int kTile = 4096;   // pairs (or list slots) per workgroup and pass
 constexpr int kBT = 256;
 constexpr int kPer = kTile / kBT;
-constexpr int kSlots = 4096;  // LDS table of one fine bucket
-constexpr int kFill = 3400;   // distinct keys a round may hold before the bucket is split further (IdentityArgs::fill)
+constexpr int kSlots = 2048;  // LDS table of one fine bucket: 24 KB, six workgroups per CU
+constexpr int kFill = 1500;   // distinct keys a round may hold before the bucket is split further (IdentityArgs::fill)
+constexpr int kMaxProbe = 192; // longest probe sequence of an insert before the round is declared overflowed
+constexpr int kChunk = 2048;  // pairs a workgroup has in flight at once in the table kernel (8 per thread)
 
 __device__ __forceinline__ uint64_t mix(uint64_t h) {  // bucket / slot selection only; never leaves the device
   h ^= h >> 33;
@@ -100,26 +102,43 @@ struct TileSrc {
   int64_t ctr_stride;  // ... and the distance between consecutive digits
   int shift, nb;       // digit = (mix(h) >> shift) & (nb - 1)
   bool ok;
+  uint32_t node0, r0;  // level 1: node of the tile's first slot and that slot's offset inside the node
+  float inv;           // level 1: 1 / nstride
 };
+
+// Workgroup -> tile, XCD-aware: the hardware deals workgroups round-robin over the 8 XCDs, each with its own L2.
+// Tiles that follow each other write ADJACENT runs of every bucket (a run is ~100 - 200 bytes: a partial 128-byte line
+// at both ends), so consecutive tiles must meet in the same L2 for those lines to be completed there instead of
+// leaving eight L2s as partial-line writes: XCD x takes the x-th contiguous eighth of the tiles.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t n_tiles) {
+  const uint32_t per = (n_tiles + 7u) >> 3;
+  return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);  // >= n_tiles for the surplus workgroups of the rounded-up grid
+}
 
 template <int LEVEL>
 __device__ __forceinline__ TileSrc tile_of(const IdentityArgs &A, const uint32_t *s_seg) {
   TileSrc t{};
   if (LEVEL == 1) {
-    t.lo = (int64_t)blockIdx.x * kTile;
+    const uint32_t tile = xcd_tile((uint32_t)A.tiles1);
+    if (tile >= (uint32_t)A.tiles1 || (blockIdx.x >> 3) >= (((uint32_t)A.tiles1 + 7u) >> 3)) { t.ok = false; return t; }
+    t.lo = (int64_t)tile * kTile;
     t.hi = t.lo + kTile < A.n_slots ? t.lo + kTile : A.n_slots;
-    t.ctr0 = blockIdx.x;
+    t.ctr0 = tile;
     t.ctr_stride = A.tiles1;
     t.shift = 64 - A.b1;
     t.nb = 1 << A.b1;
     t.ok = true;
+    t.node0 = (uint32_t)(t.lo / A.nstride);  // (uniform: one scalar division per workgroup)
+    t.r0 = (uint32_t)(t.lo - (int64_t)t.node0 * A.nstride);
+    t.inv = 1.0f / (float)A.nstride;
   } else {
     const int nb1 = 1 << A.b1;
     const uint32_t *start = s_seg, *tpre = s_seg + nb1 + 1;
-    t.ok = blockIdx.x < tpre[nb1];
+    const uint32_t n_tiles = tpre[nb1], tile = xcd_tile(n_tiles);
+    t.ok = tile < n_tiles && (blockIdx.x >> 3) < ((n_tiles + 7u) >> 3);
     int c = 0;
-    for (int k = 0; k < nb1; k++) c = (t.ok && blockIdx.x >= tpre[k]) ? k : c;  // tpre is non-decreasing: the last k with tpre[k] <= block
-    const int tl = (int)(blockIdx.x - tpre[c]);
+    for (int k = 0; k < nb1; k++) c = (t.ok && tile >= tpre[k]) ? k : c;  // tpre is non-decreasing: the last k with tpre[k] <= tile
+    const int tl = (int)(tile - tpre[c]);
     t.lo = (int64_t)start[c] + (int64_t)tl * kTile;
     t.hi = t.lo + kTile < (int64_t)start[c + 1] ? t.lo + kTile : (int64_t)start[c + 1];
     t.nb = 1 << A.b2;
@@ -130,25 +149,48 @@ __device__ __forceinline__ TileSrc tile_of(const IdentityArgs &A, const uint32_t
   return t;
 }
 
-// pair `i` of the tile: hash, list index, valid?
+// The tile's pairs, kPer per thread, ALL loads in flight together: two dependent batches at level 1 (the counts of the
+// slots' nodes, then the hashes of the slots that carry a successor), one at level 2.  Every load is unconditional on a
+// clamped address so that the compiler issues the whole batch before the first use (a conditional load per slot -- the
+// first version -- compiled to kPer serial round trips).  h[i] is only meaningful where ok bit i is set.
 template <int LEVEL>
-__device__ __forceinline__ bool load_pair(const IdentityArgs &A, int64_t s, int64_t hi, uint64_t *h, uint32_t *g) {
-  if (s >= hi) return false;
+__device__ __forceinline__ uint32_t load_tile(const IdentityArgs &A, const TileSrc &t, uint64_t (&h)[kPer]) {
+  uint32_t ok = 0;
   if (LEVEL == 1) {
-    if (A.n_nodes == 1) {
-      if (s >= (int64_t)A.count[0]) return false;
+    if (A.n_nodes == 1) {  // packed lists: one long list
+      const int64_t total = (int64_t)A.count[0];
+#pragma unroll
+      for (int i = 0; i < kPer; i++) ok |= ((t.lo + i * kBT + (int64_t)threadIdx.x) < (t.hi < total ? t.hi : total) ? 1u : 0u) << i;
     } else {
-      const uint32_t node = (uint32_t)s / (uint32_t)A.nstride;  // n_slots < 2^31 (checked by the host)
-      const uint32_t j = (uint32_t)s - node * (uint32_t)A.nstride;
-      if ((int)j >= A.count[node]) return false;
+      int cn[kPer];
+      uint32_t jj[kPer];
+#pragma unroll
+      for (int i = 0; i < kPer; i++) {
+        // node = slot / nstride without a division per slot: x = (offset of the tile inside its first node) + (slot
+        // inside the tile) < nstride + 4096 < 2^24 is exact in f32, so the f32 quotient is off by at most one
+        const uint32_t x = t.r0 + (uint32_t)(i * kBT + threadIdx.x);
+        uint32_t q = (uint32_t)((float)x * t.inv);
+        if (q * (uint32_t)A.nstride > x) q--;
+        else if ((q + 1) * (uint32_t)A.nstride <= x) q++;
+        jj[i] = x - q * (uint32_t)A.nstride;
+        const int64_t node = (int64_t)t.node0 + q;
+        cn[i] = A.count[node < A.n_nodes ? node : A.n_nodes - 1];
+      }
+#pragma unroll
+      for (int i = 0; i < kPer; i++)
+        ok |= ((t.lo + i * kBT + (int64_t)threadIdx.x < t.hi && (int)jj[i] < cn[i]) ? 1u : 0u) << i;
     }
-    *h = A.hash[s];
-    *g = (uint32_t)s;
+#pragma unroll
+    for (int i = 0; i < kPer; i++) h[i] = A.hash[((ok >> i) & 1u) ? t.lo + i * kBT + threadIdx.x : t.lo];
   } else {
-    *h = A.hk[0][s];
-    *g = A.gi[0][s];
+#pragma unroll
+    for (int i = 0; i < kPer; i++) {
+      const int64_t p = t.lo + i * kBT + threadIdx.x;
+      ok |= (p < t.hi ? 1u : 0u) << i;
+      h[i] = A.hk[0][p < t.hi ? p : t.lo];
+    }
   }
-  return true;
+  return ok;
 }
 
 __device__ __forceinline__ void load_seg(const IdentityArgs &A, uint32_t *s_seg) {
@@ -166,62 +208,84 @@ __global__ __launch_bounds__(kBT) void id_hist_kernel(const IdentityArgs A) {
   if (!t.ok) return;  // (uniform)
   hist[threadIdx.x] = 0;
   __syncthreads();
+  uint64_t h[kPer];
+  const uint32_t ok = load_tile<LEVEL>(A, t, h);
 #pragma unroll
   for (int i = 0; i < kPer; i++) {
-    uint64_t h;
-    uint32_t g;
-    if (load_pair<LEVEL>(A, t.lo + i * kBT + threadIdx.x, t.hi, &h, &g))
-      atomicAdd(&hist[(mix(h) >> t.shift) & (t.nb - 1)], 1u);
+    if ((ok >> i) & 1u) {
+      atomicAdd(&hist[(mix(h[i]) >> t.shift) & (t.nb - 1)], 1u);
+      // every successor starts as its own first occurrence (coalesced, in list order); the table kernel then only
+      // writes the duplicates -- on a frontier without revisits that is next to nothing instead of one scattered
+      // 4-byte write per successor
+      if (LEVEL == 1) A.canon[t.lo + i * kBT + threadIdx.x] = (int32_t)(t.lo + i * kBT + threadIdx.x);
+    }
   }
   __syncthreads();
   if ((int)threadIdx.x < t.nb) A.cnt[LEVEL - 1][t.ctr0 + threadIdx.x * t.ctr_stride] = hist[threadIdx.x];
 }
 
+// Scatter of one tile.  Staged through LDS so that consecutive lanes write consecutive addresses inside a digit's run.
+// Level 1 (sparse tiles: ~40 % of the slots of padded lists carry a successor) stages only the pair's POSITION in the
+// tile (2 bytes) and reads hash and index again on the way out: 8 KB of LDS instead of 48, eight resident workgroups per
+// CU instead of three to overlap the kernel's dependent round trips (counts, hashes, bases, stores): 266 -> 154 us on
+// C4.  Level 2 (dense tiles, 16 gathers per thread on the way out) stages the pairs themselves: 167 us against 309.
 template <int LEVEL>
 __global__ __launch_bounds__(kBT) void id_scatter_kernel(const IdentityArgs A) {
   __shared__ uint32_t s_seg[2 * 65 + 2];
-  __shared__ uint32_t hist[256], lbase[256], gbase[256];
-  __shared__ uint64_t st_h[kTile];
-  __shared__ uint32_t st_g[kTile];
+  __shared__ uint32_t hist[256], lbase[256], gbase[256], wtot[4];
+  constexpr bool kStagePairs = LEVEL == 2;
+  __shared__ unsigned short st_i[kStagePairs ? 1 : kTile];
+  __shared__ uint64_t st_h[kStagePairs ? kTile : 1];
+  __shared__ uint32_t st_g[kStagePairs ? kTile : 1];
   if (LEVEL == 2) load_seg(A, s_seg);
   const TileSrc t = tile_of<LEVEL>(A, s_seg);
   if (!t.ok) return;
   hist[threadIdx.x] = 0;
   __syncthreads();
+  uint32_t rk[kPer];  // rank inside the tile's share of the digit | digit << 16
   uint64_t h[kPer];
-  uint32_t g[kPer], rk[kPer];  // rk: rank inside the tile's share of the digit | digit << 16; ~0 = no pair
+  uint32_t g[kPer];
+  const uint32_t ok = load_tile<LEVEL>(A, t, h);
+  if (kStagePairs) {
+#pragma unroll
+    for (int i = 0; i < kPer; i++) {
+      const int64_t p = t.lo + i * kBT + threadIdx.x;
+      g[i] = A.gi[0][p < t.hi ? p : t.lo];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < kPer; i++) {
-    rk[i] = 0xffffffffu;
-    if (load_pair<LEVEL>(A, t.lo + i * kBT + threadIdx.x, t.hi, &h[i], &g[i])) {
+    rk[i] = 0;
+    if ((ok >> i) & 1u) {
       const uint32_t d = (uint32_t)((mix(h[i]) >> t.shift) & (uint64_t)(t.nb - 1));
       rk[i] = atomicAdd(&hist[d], 1u) | (d << 16);
     }
   }
   __syncthreads();
-  {  // exclusive scan of the 256 digit counts; where the tile's share of every digit starts in the output
+  {  // exclusive scan of the 256 digit counts (one per thread): inside each wave by shuffles, the four wave totals
+     // through LDS; where the tile's share of every digit starts in the output
     const uint32_t v = hist[threadIdx.x];
-    lbase[threadIdx.x] = v;
-    __syncthreads();
-    for (int d = 1; d < kBT; d <<= 1) {
-      const uint32_t o = threadIdx.x >= (unsigned)d ? lbase[threadIdx.x - d] : 0u;
-      __syncthreads();
-      lbase[threadIdx.x] += o;
-      __syncthreads();
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+      if ((int)(threadIdx.x & 63) >= d) inc += o;
     }
-    const uint32_t excl = lbase[threadIdx.x] - v;
+    if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
     __syncthreads();
-    lbase[threadIdx.x] = excl;
+    uint32_t before = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) before += wtot[w];
+    lbase[threadIdx.x] = before + inc - v;
     if ((int)threadIdx.x < t.nb)
       gbase[threadIdx.x] = scanned(A.cnt[LEVEL - 1], A.tot[LEVEL - 1], t.ctr0 + threadIdx.x * t.ctr_stride);
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < kPer; i++) {
-    if (rk[i] != 0xffffffffu) {
+    if ((ok >> i) & 1u) {
       const uint32_t p = lbase[rk[i] >> 16] + (rk[i] & 0xffffu);
-      st_h[p] = h[i];
-      st_g[p] = g[i];
+      if (kStagePairs) { st_h[p] = h[i]; st_g[p] = g[i]; }
+      else st_i[p] = (unsigned short)(i * kBT + threadIdx.x);
     }
   }
   __syncthreads();
@@ -229,11 +293,20 @@ __global__ __launch_bounds__(kBT) void id_scatter_kernel(const IdentityArgs A) {
   uint64_t *oh = A.hk[LEVEL == 1 ? 0 : 1];
   uint32_t *og = A.gi[LEVEL == 1 ? 0 : 1];
   for (uint32_t p = threadIdx.x; p < total; p += kBT) {  // consecutive lanes -> consecutive addresses inside a digit's run
-    const uint64_t hh = st_h[p];
+    uint64_t hh;
+    uint32_t gg;
+    if (kStagePairs) {
+      hh = st_h[p];
+      gg = st_g[p];
+    } else {
+      const int64_t src = t.lo + st_i[p];
+      hh = A.hash[src];
+      gg = (uint32_t)src;
+    }
     const uint32_t d = (uint32_t)((mix(hh) >> t.shift) & (uint64_t)(t.nb - 1));
     const uint32_t o = gbase[d] + (p - lbase[d]);
     oh[o] = hh;
-    og[o] = st_g[p];
+    og[o] = gg;
   }
 }
 
@@ -257,82 +330,146 @@ __global__ __launch_bounds__(128) void id_segments_kernel(const IdentityArgs A) 
   if (c <= nb1) A.seg[c] = start[c];
 }
 
+// where every fine bucket starts in the partitioned pairs: range[b], b = 0 .. buckets (one thread per bucket), so that a
+// table workgroup starts with ONE load instead of segment table + two scanned counters
+__global__ __launch_bounds__(kBT) void id_ranges_kernel(const IdentityArgs A, uint32_t n_buckets) {
+  const uint32_t b = blockIdx.x * kBT + threadIdx.x;
+  if (b > n_buckets) return;
+  uint32_t v;
+  if (A.b2 > 0) {
+    const int nb1 = 1 << A.b1, nb2 = 1 << A.b2;
+    const uint32_t *tpre = A.seg + nb1 + 1;
+    if (b == n_buckets) {
+      v = scanned(A.cnt[1], A.tot[1], (int64_t)tpre[nb1] * nb2);  // one past the last counter in use (zeroed padding): the total
+    } else {
+      const int c = (int)(b >> A.b2), d = (int)(b & (uint32_t)(nb2 - 1));
+      v = scanned(A.cnt[1], A.tot[1], (int64_t)tpre[c] * nb2 + (int64_t)d * (int64_t)(tpre[c + 1] - tpre[c]));
+    }
+  } else {
+    v = scanned(A.cnt[0], A.tot[0], (int64_t)b * A.tiles1);
+  }
+  A.range[b] = v;
+}
+
 // ---- one workgroup per fine bucket: identity table in LDS
 __global__ __launch_bounds__(kBT) void id_tables_kernel(const IdentityArgs A) {
   __shared__ unsigned long long keys[kSlots];
   __shared__ uint32_t vals[kSlots];
-  __shared__ uint32_t nuniq, ovf, special;
-  __shared__ uint32_t s_seg[2 * 65 + 2];
-  int64_t lo, hi;
-  const uint64_t *hk;
-  const uint32_t *gi;
-  if (A.b2 > 0) {
-    load_seg(A, s_seg);
-    const int nb2 = 1 << A.b2;
-    const int c = blockIdx.x >> A.b2, d = blockIdx.x & (nb2 - 1);
-    const uint32_t *tpre = s_seg + (1 << A.b1) + 1;
-    const int64_t ntile = (int64_t)(tpre[c + 1] - tpre[c]);
-    const int64_t i0 = (int64_t)tpre[c] * nb2 + d * ntile;
-    lo = scanned(A.cnt[1], A.tot[1], i0);
-    hi = scanned(A.cnt[1], A.tot[1], i0 + ntile);  // the next bucket's first counter (zeroed padding after the last)
-    hk = A.hk[1];
-    gi = A.gi[1];
-  } else {
-    lo = scanned(A.cnt[0], A.tot[0], (int64_t)blockIdx.x * A.tiles1);
-    hi = scanned(A.cnt[0], A.tot[0], (int64_t)(blockIdx.x + 1) * A.tiles1);
-    hk = A.hk[0];
-    gi = A.gi[0];
-  }
+  __shared__ uint32_t nuniq, nseen, ovf, special;
+  const int64_t lo = A.range[blockIdx.x], hi = A.range[blockIdx.x + 1];
   if (hi <= lo) return;
-  // rounds over further hash bits when the bucket holds more distinct keys than the table takes
+  const uint64_t *hk = A.hk[A.b2 > 0 ? 1 : 0];
+  const uint32_t *gi = A.gi[A.b2 > 0 ? 1 : 0];
+  // Every sweep over the bucket has kChunk pairs (8 per thread) in flight at once, and the typical bucket IS one such
+  // chunk: it is loaded once and both sweeps (insert, look-up) run from registers.  Rounds over further hash bits when
+  // the bucket holds more distinct keys than the table takes.
+  constexpr int kPT = kChunk / kBT;
+  const bool single = hi - lo <= kChunk;
+  uint64_t h[kPT];
+  uint32_t g[kPT];
+  uint32_t have = 0;  // bit i: pair i of the chunk exists
+#define MPLX_ID_LOAD(base_)                                         \
+  do {                                                              \
+    have = 0;                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < kPT; i_++) {            \
+      const int64_t p_ = (base_) + i_ * kBT + threadIdx.x;          \
+      have |= (p_ < hi ? 1u : 0u) << i_;                            \
+      h[i_] = hk[p_ < hi ? p_ : lo];                                \
+      g[i_] = gi[p_ < hi ? p_ : lo];                                \
+    }                                                               \
+  } while (0)
+  if (single) MPLX_ID_LOAD(lo);
   for (uint32_t R = 1;; R <<= 1) {
     bool split = false;
     for (uint32_t r = 0; r < R; r++) {
       for (int i = threadIdx.x; i < kSlots; i += kBT) { keys[i] = kEmpty; vals[i] = 0xffffffffu; }
-      if (threadIdx.x == 0) { nuniq = 0; ovf = 0; special = 0xffffffffu; }
+      if (threadIdx.x == 0) { nuniq = 0; nseen = 0; ovf = 0; special = 0xffffffffu; }
       __syncthreads();
-      for (int64_t p = lo + threadIdx.x; p < hi; p += kBT) {
-        const uint64_t h = hk[p];
-        const uint64_t m = mix(h);
-        if (((uint32_t)(m >> 12) & (R - 1u)) != r) continue;
-        const uint32_t g = gi[p];
-        if (h == kEmpty) { atomicMin(&special, g); continue; }  // the one hash the key field cannot hold
-        uint32_t s = (uint32_t)m & (kSlots - 1);
-        for (int probes = 0;; probes++) {
-          const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)kEmpty, (unsigned long long)h);
-          if (old == kEmpty || old == h) {
-            atomicMin(&vals[s], g);
-            if (old == kEmpty && atomicAdd(&nuniq, 1u) >= (uint32_t)A.fill) ovf = 1;
-            break;
+      for (int64_t base = lo; base < hi; base += kChunk) {
+        if (ovf) break;  // (not uniform, no barrier inside this loop: the round is void anyway)
+        if (!single) MPLX_ID_LOAD(base);
+        uint32_t fresh = 0;  // keys this thread put into the table | pairs it looked at << 16 (counted per wave below: one LDS atomic each per wave and chunk)
+#pragma unroll
+        for (int i = 0; i < kPT; i++) {
+          const uint64_t m = mix(h[i]);
+          const bool mine = ((have >> i) & 1u) && ((uint32_t)(m >> 12) & (R - 1u)) == r;
+          fresh += mine ? 0x10000u : 0u;
+          if (mine && h[i] == kEmpty) atomicMin(&special, g[i]);  // the one hash the key field cannot hold
+#ifdef MPLX_ID_NO_INSERT
+          if (false) {
+#else
+          if (mine && h[i] != kEmpty) {
+#endif
+            uint32_t s = (uint32_t)m & (kSlots - 1);
+            for (int probes = 0;; probes++) {
+              // plain reads first: LDS atomics are processed lane by lane, reads at full rate.  A key that is already
+              // in the table (every duplicate after the first) costs no CAS, and -- the partition keeps list order
+              // up to a tile's run -- its index is rarely smaller than the one recorded, so usually no atomicMin either.
+              unsigned long long k = keys[s];
+              if (k == kEmpty) {
+                k = atomicCAS(&keys[s], (unsigned long long)kEmpty, (unsigned long long)h[i]);
+                if (k == kEmpty) { fresh++; k = h[i]; }
+              }
+              if (k == h[i]) {
+                if (vals[s] > g[i]) atomicMin(&vals[s], g[i]);
+                break;
+              }
+              // a probe sequence this long means the table is (nearly) full: more distinct keys than `fill` are on
+              // their way in; give up at once (the round is repeated with the bucket split further) instead of
+              // walking a full table for every remaining pair
+              if (probes >= kMaxProbe) { ovf = 1; break; }
+              s = (s + 1) & (kSlots - 1);
+            }
           }
-          if (probes >= 1024) { ovf = 1; break; }
-          s = (s + 1) & (kSlots - 1);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) fresh += (uint32_t)__shfl_xor((int)fresh, d, 64);
+        if ((threadIdx.x & 63) == 0 && fresh) {  // (8 pairs per lane x 64 lanes: both halves stay below 2^16)
+          if ((fresh & 0xffffu) && atomicAdd(&nuniq, fresh & 0xffffu) + (fresh & 0xffffu) > (uint32_t)A.fill) ovf = 1;
+          atomicAdd(&nseen, fresh >> 16);
         }
       }
       __syncthreads();
       const bool over = ovf != 0 && R < (1u << 20);  // (uniform)
-      __syncthreads();                              // everyone has read `ovf` before the next round clears it
+      // as many keys as pairs: every pair of the round is the only one with its hash, and canon[g] = g is what the
+      // level-1 pass wrote -- nothing to look up (a frontier without revisits: practically every bucket)
+      const bool all_first = nuniq == nseen && special == 0xffffffffu;
+      __syncthreads();                              // everyone has read the counters before the next round clears them
       if (over) { split = true; break; }            // split further and start the bucket over; canon writes are idempotent
-      for (int64_t p = lo + threadIdx.x; p < hi; p += kBT) {
-        const uint64_t h = hk[p];
-        const uint64_t m = mix(h);
-        if (((uint32_t)(m >> 12) & (R - 1u)) != r) continue;
-        const uint32_t g = gi[p];
-        uint32_t c;
-        if (h == kEmpty) {
-          c = special;
-        } else {
-          uint32_t s = (uint32_t)m & (kSlots - 1);
-          int probes = 0;
-          while (keys[s] != h && probes++ <= 1024) s = (s + 1) & (kSlots - 1);
-          c = keys[s] == h ? vals[s] : g;  // (a key that was not inserted: only past the 2^20-round limit)
+      if (all_first) continue;
+      for (int64_t base = lo; base < hi; base += kChunk) {
+        if (!single) MPLX_ID_LOAD(base);
+#pragma unroll
+        for (int i = 0; i < kPT; i++) {
+          const uint64_t m = mix(h[i]);
+          const bool mine = ((have >> i) & 1u) && ((uint32_t)(m >> 12) & (R - 1u)) == r;
+#ifdef MPLX_ID_NO_LOOKUP
+          if (false) {
+#else
+          if (mine) {
+#endif
+            uint32_t c;
+            if (h[i] == kEmpty) {
+              c = special;
+            } else {
+              uint32_t s = (uint32_t)m & (kSlots - 1);
+              int probes = 0;
+              while (keys[s] != h[i] && probes++ <= kMaxProbe) s = (s + 1) & (kSlots - 1);
+              c = keys[s] == h[i] ? vals[s] : g[i];  // (a key that was not inserted: only past the 2^20-round limit)
+            }
+#ifndef MPLX_ID_NO_STORE
+            if (c != g[i]) A.canon[g[i]] = (int32_t)c;  // (first occurrences were written by the level-1 histogram pass)
+#else
+            if (c == 0x12345u) A.canon[g[i]] = (int32_t)c;
+#endif
+          }
         }
-        A.canon[g] = (int32_t)c;
       }
       __syncthreads();
     }
     if (!split) break;
   }
+#undef MPLX_ID_LOAD
 }
 
 }  // namespace
@@ -359,21 +496,23 @@ int identity_default_fill() { return kFill; }
 hipError_t launch_identity(const IdentityArgs &a, int64_t ctr1, int64_t ctr2, hipStream_t s) {
   if (a.n_slots <= 0) return hipSuccess;
   hipError_t e;
+  auto up8 = [](int64_t tiles) { return (unsigned)(((tiles + 7) / 8) * 8); };  // whole rounds over the 8 XCDs (xcd_tile)
   if ((e = hipMemsetAsync(a.cnt[0], 0, (size_t)ctr1 * 4, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(id_hist_kernel<1>, dim3((unsigned)a.tiles1), dim3(kBT), 0, s, a);
+  hipLaunchKernelGGL(id_hist_kernel<1>, dim3(up8(a.tiles1)), dim3(kBT), 0, s, a);
   hipLaunchKernelGGL(id_scan_blocks_kernel, dim3((unsigned)(ctr1 / kTile)), dim3(kBT), 0, s, a.cnt[0], a.tot[0]);
   hipLaunchKernelGGL(id_scan_totals_kernel, dim3(1), dim3(1024), 0, s, a.tot[0], (int)(ctr1 / kTile));
-  hipLaunchKernelGGL(id_scatter_kernel<1>, dim3((unsigned)a.tiles1), dim3(kBT), 0, s, a);
+  hipLaunchKernelGGL(id_scatter_kernel<1>, dim3(up8(a.tiles1)), dim3(kBT), 0, s, a);
   unsigned buckets = 1u << a.b1;
   if (a.b2 > 0) {
     if ((e = hipMemsetAsync(a.cnt[1], 0, (size_t)ctr2 * 4, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(id_segments_kernel, dim3(1), dim3(128), 0, s, a);
-    hipLaunchKernelGGL(id_hist_kernel<2>, dim3((unsigned)a.tiles2_cap), dim3(kBT), 0, s, a);
+    hipLaunchKernelGGL(id_hist_kernel<2>, dim3(up8(a.tiles2_cap)), dim3(kBT), 0, s, a);
     hipLaunchKernelGGL(id_scan_blocks_kernel, dim3((unsigned)(ctr2 / kTile)), dim3(kBT), 0, s, a.cnt[1], a.tot[1]);
     hipLaunchKernelGGL(id_scan_totals_kernel, dim3(1), dim3(1024), 0, s, a.tot[1], (int)(ctr2 / kTile));
-    hipLaunchKernelGGL(id_scatter_kernel<2>, dim3((unsigned)a.tiles2_cap), dim3(kBT), 0, s, a);
+    hipLaunchKernelGGL(id_scatter_kernel<2>, dim3(up8(a.tiles2_cap)), dim3(kBT), 0, s, a);
     buckets <<= a.b2;
   }
+  hipLaunchKernelGGL(id_ranges_kernel, dim3(buckets / kBT + 1), dim3(kBT), 0, s, a, buckets);
   hipLaunchKernelGGL(id_tables_kernel, dim3(buckets), dim3(kBT), 0, s, a);
   return hipGetLastError();
 }

@@ -247,6 +247,7 @@ struct IdentityArgs {
   uint32_t *cnt[2];  // per level: (digit, tile) counters -> exclusive prefix sums inside 4096-blocks
   uint32_t *tot[2];  // per level: scanned block totals, [blocks + 1]
   uint32_t *seg;     // level-1 buckets as segments of level 2: start[nb1 + 1], tile prefix[nb1 + 1]
+  uint32_t *range;   // [buckets + 1]: where every fine bucket starts in the partitioned pairs
   int64_t n_slots, tiles1, tiles2_cap;
   int b1, b2;        // digit bits of the two levels (b2 = 0: one level)
   int fill;          // distinct keys one round of a bucket's LDS table takes (identity_default_fill(); tests lower it)

@@ -48,7 +48,7 @@ static int post_lists_impl(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t 
   // ones through the table in HBM (two launches).  MPLX_POST_PARTITION_MIN moves the switch (tests: 0 = always).
   const char *e_min = getenv("MPLX_POST_PARTITION_MIN"), *e_fill = getenv("MPLX_POST_FILL"), *e_bits = getenv("MPLX_POST_BITS");
   const int64_t partition_min = e_min ? (int64_t)atoll(e_min) : (int64_t)1 << 18;
-  if (d_out->canon && n >= partition_min) {
+  if (d_out->canon && n >= partition_min && (n_nodes == 1 || S + 4096 < (1 << 24))) {  // (the slot -> node arithmetic of the partition is f32-exact below 2^24)
     mplx::IdentityArgs ia{};
     ia.count = d_lists->count;
     ia.hash = d_lists->hash;
@@ -71,7 +71,8 @@ static int post_lists_impl(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t 
     const size_t sz_h = up((size_t)n * 8), sz_g = up((size_t)n * 4);
     const size_t sz_c1 = up((size_t)ctr1 * 4), sz_c2 = up((size_t)ctr2 * 4);
     const size_t sz_t1 = up((size_t)(ctr1 / 4096 + 1) * 4), sz_t2 = up((size_t)(ctr2 / 4096 + 1) * 4);
-    const size_t total = levels * (sz_h + sz_g) + sz_c1 + sz_c2 + sz_t1 + sz_t2 + 1024;
+    const size_t sz_r = up(((size_t)1 << (ia.b1 + ia.b2)) * 4 + 4);
+    const size_t total = levels * (sz_h + sz_g) + sz_c1 + sz_c2 + sz_t1 + sz_t2 + sz_r + 1024;
     if (int rc = ensure(c, c->post_ws, total)) return rc;
     char *w = (char *)c->post_ws.p;
     for (int l = 0; l < levels; l++) { ia.hk[l] = (uint64_t *)w; w += sz_h; }
@@ -80,6 +81,7 @@ static int post_lists_impl(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t 
     ia.cnt[1] = (uint32_t *)w; w += sz_c2;
     ia.tot[0] = (uint32_t *)w; w += sz_t1;
     ia.tot[1] = (uint32_t *)w; w += sz_t2;
+    ia.range = (uint32_t *)w; w += sz_r;
     ia.seg = (uint32_t *)w;
     HIP_TRY(c, mplx::launch_identity(ia, ctr1, ctr2, c->stream));
   } else if (d_out->canon) {
