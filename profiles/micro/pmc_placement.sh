@@ -2,7 +2,7 @@
 # TCC -> memory counters of the C4 kernel per allocation (slow against fast placement): c4_stride.py cycles allocations
 # (50 dispatches each), rocprofv3 records the counters per dispatch; the summary groups them by allocation.
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/pmc_place; rm -rf $OUT; mkdir -p $OUT
+OUT=$PWD/gpurun_out/${PMC_TAG:-pmc_place}; rm -rf $OUT; mkdir -p $OUT
 # at most two TCC counters per pass: more "exceeds the capabilities of the hardware", rocprofv3 aborts and then hangs in its
 # signal handler (cost 15 GPU-minutes once) -- hence the hard timeout
 CNT="${1:-TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_WRITE_GMI_32B_sum}"
