@@ -118,7 +118,7 @@ struct GridLds {
     w = (w + 7) & ~7;
     w_box = w; w += (boxcap * 4 > rmax * tts * 8) ? boxcap * 4 : rmax * tts * 8;  // also the sample times while rows are built
     w = (w + 15) & ~15;
-    w_misc = w; w += 37 * 4;  // M_* below
+    w_misc = w; w += 49 * 4;  // M_* below (M_WORDS)
     w_rowmap = w; w += ((n_max + 2) & ~1) * 2;  // per sample count n <= n_max: offset of its row inside an entry's block this pass (0xffff: not this pass)
     w_list = w; w += ((nU + 1) & ~1) * 2;
     w_cell = w; w += EN * rmax * tts + 8;  // + 8: the sample loop reads up to 7 codes past a row
@@ -235,7 +235,7 @@ __device__ __forceinline__ int pair_flags(const int *s_eflag, int ndp, int j0, i
 }
 
 // misc words of a wave
-enum { M_BASE = 0, M_NMASK = 4, M_NV = 6, M_NODEQ = 12, M_VL = 24, M_YQ = 36 };  // NV: valid entries per axis; NODEQ: [D][4]; VL: [D][16] bytes; YQ: the node's yaw integer
+enum { M_BASE = 0, M_NV = 6, M_NODEQ = 12, M_VL = 24, M_YQ = 36, M_VLC = 37, M_WORDS = 49 };  // NV: valid entries per axis; NODEQ: [D][4]; VL: [D][16] bytes; YQ: the node's yaw integer; VLC: [D][16] bytes, the entries whose row the current sample count needs
 
 // reference include/mpl_basis/math.h:15-19
 __device__ __forceinline__ double wrap_angle(double a) {
@@ -328,14 +328,19 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
   const int64_t wave_id = (int64_t)blockIdx.x * kWPB + wv;
   const int64_t wave_stride = (int64_t)gridDim.x * kWPB;
   // the override pass of the yaw pinning walks a list of nodes; everything else the whole frontier in order
-  auto node_of = [&](int64_t it) -> int64_t { return (YAW && A.yaw.node_list) ? (int64_t)A.yaw.node_list[it] : it; };
+  // (or, after a pre-screen launch, the list of nodes whose own heading passed validate_yaw at t = 0)
+  const bool screened = YAW && A.live != nullptr;
+  const int64_t NN = screened ? (int64_t)*A.live_n : A.n_nodes;
+  auto node_of = [&](int64_t it) -> int64_t {
+    return screened ? (int64_t)A.live[it] : ((YAW && A.yaw.node_list) ? (int64_t)A.yaw.node_list[it] : it);
+  };
   const bool dyn = A.work != nullptr;
   const int64_t ck = dyn ? A.work_chunk : 1;
   int64_t dyn_beg = 0, dyn_len = 0, dyn_step = 1;  // this counter's share of the claimable chunks
   unsigned int *ctr = nullptr;
   if (dyn) {
     if (blockIdx.x == 0 && threadIdx.x < kWorkCounters) A.work_zero[threadIdx.x * 32] = 0u;  // for the next launch
-    const int64_t n_chunks = (A.n_nodes + ck - 1) / ck, n_dyn = n_chunks > wave_stride ? n_chunks - wave_stride : 0;
+    const int64_t n_chunks = (NN + ck - 1) / ck, n_dyn = n_chunks > wave_stride ? n_chunks - wave_stride : 0;
     const int nc = gridDim.x < (unsigned)kWorkCounters ? (int)gridDim.x : kWorkCounters;  // counters in use
     const int cx = (int)(blockIdx.x % nc);
     const int64_t base = n_dyn / nc, rem = n_dyn % nc;
@@ -351,14 +356,14 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
     unsigned int v = 0;
     if (lane == 0) v = atomicAdd(ctr, 1u);
     const int64_t j = (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
-    return j < dyn_len ? (dyn_beg + j * dyn_step) * ck : A.n_nodes;
+    return j < dyn_len ? (dyn_beg + j * dyn_step) * ck : NN;
   };
   const int64_t it0 = wave_id * ck;
-  int64_t chunk_end = it0 + ck < A.n_nodes ? it0 + ck : A.n_nodes;
+  int64_t chunk_end = it0 + ck < NN ? it0 + ck : NN;
   double nxt = 0.0;  // lanes < F: one field of the next node (prefetched)
-  if (it0 < A.n_nodes && lane < F) nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(it0)];
-  int64_t next_chunk = A.n_nodes;  // (dynamic) first node of the chunk claimed ahead
-  if (dyn && it0 < A.n_nodes) next_chunk = claim();
+  if (it0 < NN && lane < F) nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(it0)];
+  int64_t next_chunk = NN;  // (dynamic) first node of the chunk claimed ahead
+  if (dyn && it0 < NN) next_chunk = claim();
 
   // ---- once per (persistent) workgroup: shared read-only tables
   {
@@ -384,7 +389,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
   int64_t it_next = 0;
 
   PT_DECL;
-  for (int64_t it = it0; it < A.n_nodes; it = it_next) {
+  for (int64_t it = it0; it < NN; it = it_next) {
     PT(9);  // (loop overhead / tail of the previous node)
     asm volatile("" : "+s"(Ak));  // see the top of the kernel
     if (!dyn) {
@@ -393,8 +398,8 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
       it_next = it + 1;
     } else {  // last node of the chunk: move on to the chunk claimed ahead and claim the one after it
       it_next = next_chunk;
-      chunk_end = it_next + ck < A.n_nodes ? it_next + ck : A.n_nodes;
-      next_chunk = it_next < A.n_nodes ? claim() : A.n_nodes;
+      chunk_end = it_next + ck < NN ? it_next + ck : NN;
+      next_chunk = it_next < NN ? claim() : NN;
     }
     const int64_t node = node_of(it);
     const double *ytab = pinned ? A.yaw.tab + it * A.yaw.tab_stride : nullptr;  // [c0, s0, cT[16], sT[16]]
@@ -403,14 +408,14 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
     wave_prio(0);
     wave_sync();
     if (lane < F) s_node[lane] = nxt;
-    if (it_next < A.n_nodes && lane < F)
+    if (it_next < NN && lane < F)
       nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(it_next)];
-    if (lane < 2) s_misc[M_NMASK + lane] = 0;
     wave_sync();
 
-    if (YAW && K >= 2 && A.yaw_max > 0) {
+    if (YAW && K >= 2 && A.yaw_max > 0 && !screened) {
       // validate_yaw at t = 0 (primitive.h:509-523) does not depend on the control when the state carries a
       // velocity: evaluate(0).vel = 0.0 + v and yaw(0) = wrap(yaw).  A node that fails it has no successor at all.
+      // (Large frontiers: grid_prescreen_kernel has done this test lane-per-node and only the survivors are here.)
       const double vx0 = 0.0 + s_node[1 * D], vy0 = 0.0 + s_node[1 * D + 1];
       bool dead = false;
       if (vx0 != 0 || vy0 != 0) {
@@ -640,6 +645,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
     // reference test builds U with, test/test_planner_2d.cpp:52-53), only the combinations of entries that pass
     // the limits are enumerated, in the same ascending control order: 43 % of C4's pairs instead of all of them.
     int E = 0;  // emitted successors of the node (uniform)
+    unsigned int nm_lo = 0, nm_hi = 0;  // this lane's share of the set of sample counts in use (OR-reduced after the loop)
     const int ny_ = YAW ? ndy : 1;
     const int nv0 = __builtin_amdgcn_readfirstlane(s_misc[M_NV + 0]), nv1 = __builtin_amdgcn_readfirstlane(s_misc[M_NV + 1]);
     const int nv2 = (D == 3) ? __builtin_amdgcn_readfirstlane(s_misc[M_NV + 2]) : 1;
@@ -693,14 +699,15 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
       const unsigned long long m = __ballot(emit);
       if (emit) {
         s_list[E + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)lpk;
-        if (n) atomicOr((unsigned int *)&s_misc[M_NMASK + (n >> 5)], 1u << (n & 31));
+        // (an LDS atomicOr per emitting lane here -- the first version -- is processed lane by lane: five 64-lane
+        // atomics per C4 node; the set is OR-ed in registers and reduced once per node instead)
+        if (n) { if (n < 32) nm_lo |= 1u << n; else nm_hi |= 1u << (n - 32); }
       }
       E += __popcll(m);
     }
     wave_sync();
     if (lane == 0 && A.l_count) A.l_count[node] = E;
-    unsigned long long nm = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(s_misc[M_NMASK]) |
-                            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(s_misc[M_NMASK + 1]) << 32);
+    unsigned long long nm = (unsigned long long)wave_reduce_or(nm_lo) | ((unsigned long long)wave_reduce_or(nm_hi) << 32);
     if (A.dbg & 1) nm = 0;  // timing ablation: no sampling
     // The next node's state (issued at the top of this node) has certainly arrived by now; pin that here,
     // where only loads are in flight, so that the wait does not end up at the top of the next node behind
@@ -770,6 +777,18 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
           const int cn = (int)s_tc[nn];
           const float inv_cn = 1.0f / (float)cn;
           const double *trow = s_trow + row;
+          // The row of (entry, count nn) is only ever read by a pair whose count max(n_axis) IS nn, i.e. by entries
+          // with n_entry <= nn: the small counts of a node need the rows of few entries (a JRK node uses 4 - 8 counts
+          // between 5 and 31; building every entry's row for every count was ~40 % of C3's instructions).  Per count:
+          // the entries to build, per axis, in value order (lanes = entries, as in T1).
+          const unsigned long long fm = __ballot(lane < EN && (flag & 1) && (flag >> 8) <= nn);
+          wave_sync();  // (the previous count's list has been read)
+          if (lane < EN && ((fm >> lane) & 1ull)) {
+            const int ax_ = lane / ndp;
+            const unsigned long long am = (((1ull << ndp) - 1ull) << (ax_ * ndp)) & fm;
+            ((unsigned char *)(s_misc + M_VLC))[ax_ * 16 + __popcll(am & ((1ull << lane) - 1ull))] = (unsigned char)(lane - ax_ * ndp);
+          }
+          wave_sync();
 #pragma unroll
           for (int ax = 0; ax < D; ax++) {
             const double p0 = s_node[0 * D + ax];
@@ -777,8 +796,8 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
             const double a0 = (K >= 3) ? s_node[2 * D + ax] : 0.0;
             const double j0 = (K >= 4) ? s_node[3 * D + ax] : 0.0;
             const int shift = half - base_c[ax];
-            const int nv = __builtin_amdgcn_readfirstlane(s_misc[M_NV + ax]);
-            const unsigned char *vl = (const unsigned char *)(s_misc + M_VL) + ax * 16;
+            const int nv = __popcll(fm & (((1ull << ndp) - 1ull) << (ax * ndp)));
+            const unsigned char *vl = (const unsigned char *)(s_misc + M_VLC) + ax * 16;
             for (int x = lane; x < nv * cn; x += 64) {
               const int vi = (int)(((float)x + 0.5f) * inv_cn);  // exact: x < 2^12
               const int k = x - __umul24(vi, cn);
@@ -1124,6 +1143,55 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
 #undef A
 }
 
+// Pre-screen of yaw controls, lane per node.  validate_yaw at t = 0 (primitive.h:509-523) depends on the node alone
+// when the state carries a velocity (evaluate(0).vel = 0.0 + v, yaw(0) = wrap(yaw)): a node whose own heading is off
+// its velocity direction by more than yaw_max has no successor at all.  On a synthetic frontier with random headings
+// that is most nodes (C5: 84 %), and in the main kernel each of them costs a WAVE a sincos, a square root, two
+// divisions and a trip round the node loop; here 64 nodes share those instructions.  The survivors are appended to
+// `live` in frontier order within a workgroup (ballot + prefix; workgroups append in arrival order -- the output of a
+// node does not depend on where it sits in the list), the dead get their empty list here.  Same expressions as the
+// main kernel's own test (and -ffp-contract=off), so the decision is the same bit for bit; decisions within rounding
+// noise of the threshold are flagged for the host-libm pass exactly as there.
+template <int D, int K>
+__global__ __launch_bounds__(256) void grid_prescreen_kernel(const double *nodes, int64_t n_nodes, int64_t node_stride,
+                                                             double yaw_max, YawPin yaw, int32_t *l_count, int32_t *live,
+                                                             uint32_t *live_n) {
+  __shared__ uint32_t s_wave[4], s_base;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  bool alive = false;
+  if (i < n_nodes) {
+    alive = true;
+    const double vx0 = 0.0 + nodes[(int64_t)(1 * D) * node_stride + i], vy0 = 0.0 + nodes[(int64_t)(1 * D + 1) * node_stride + i];
+    if (vx0 != 0 || vy0 != 0) {
+      const double cos_lim = cos(yaw_max);
+      double c0, s0;
+      const double y0 = wrap_angle((0.0 + 0.0) + nodes[(int64_t)(4 * D) * node_stride + i]);
+      sincos(y0, &s0, &c0);
+      const double sn = sqrt(vx0 * vx0 + vy0 * vy0);
+      const double d = vx0 / sn * c0 + vy0 / sn * s0;
+      if (d < cos_lim) {
+        alive = false;
+        if (l_count) l_count[i] = 0;
+        if (yaw.amb && near_limit(d, cos_lim, yaw.margin, vy0, y0, yaw.tie_yaw)) flag_node(yaw.amb, yaw.amb_cap, i, yaw.any_host);
+      }
+    }
+  }
+  const unsigned long long m = __ballot(alive);
+  if (lane == 0) s_wave[wv] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = t ? atomicAdd(live_n, t) : 0u;
+  }
+  __syncthreads();
+  if (alive) {
+    uint32_t pos = s_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wv; w++) pos += s_wave[w];
+    live[pos] = (int32_t)i;
+  }
+}
+
 // Summed-area table of the blocked-bit map: sat[z][y][x] (sizes d+1, zero border at index 0) = number of
 // blocked cells with coordinates < (x, y, z).  Built once per map / region change.
 __global__ void sat_seed_kernel(const uint32_t *blk, int d0, int d1, int d2, uint32_t *sat) {
@@ -1324,6 +1392,22 @@ hipError_t launch_expand_grid(int dim, int control, const GridArgs &a, hipStream
     using T = decltype(t);
     return launch_grid_inst<T::D, T::K, T::YAW, T::POT>(a, s);
   });
+}
+
+hipError_t launch_grid_prescreen(int dim, int control, const GridArgs &a, int32_t *live, uint32_t *live_n, hipStream_t s) {
+  if (a.n_nodes == 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(live_n, 0, 4, s);
+  if (e != hipSuccess) return e;
+  const unsigned blocks = (unsigned)((a.n_nodes + 255) / 256);
+#define MPLX_PS(D, K) hipLaunchKernelGGL((grid_prescreen_kernel<D, K>), dim3(blocks), dim3(256), 0, s, a.nodes, a.n_nodes, \
+                                         a.node_stride, a.yaw_max, a.yaw, a.l_count, live, live_n)
+  if (dim == 2 && control == 0x13) MPLX_PS(2, 2);
+  else if (dim == 2 && control == 0x17) MPLX_PS(2, 3);
+  else if (dim == 3 && control == 0x13) MPLX_PS(3, 2);
+  else if (dim == 3 && control == 0x17) MPLX_PS(3, 3);
+  else return hipErrorInvalidValue;
+#undef MPLX_PS
+  return hipGetLastError();
 }
 
 int grid_resident_blocks(int dim, int control, bool pot, size_t lds) {

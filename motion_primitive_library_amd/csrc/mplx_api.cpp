@@ -130,6 +130,7 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
     c->tune.no_sat = getenv("MPLX_GRID_NOSAT") != nullptr;
     c->tune.no_lex = getenv("MPLX_GRID_NOLEX") != nullptr;
     c->tune.no_line_pad = getenv("MPLX_NO_LINE_PAD") != nullptr;
+    c->tune.prescreen_min = env_int("MPLX_GRID_PRESCREEN_MIN");
     c->tune.yaw_pin = !(getenv("MPLX_YAW_PIN") && atoi(getenv("MPLX_YAW_PIN")) == 0);
     c->tune.yaw_margin = getenv("MPLX_YAW_MARGIN") ? atof(getenv("MPLX_YAW_MARGIN")) : 0.0;
   }
@@ -143,7 +144,7 @@ void mplx_destroy(mplx_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->map, &c->pot, &c->region_bits, &c->region_bytes, &c->U, &c->s_nodes, &c->s_status,
                     &c->s_cost, &c->s_hash, &c->s_state, &c->s_iters, &c->s_count, &c->s_action, &c->tables,
-                    &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx, &c->blk, &c->sat, &c->prep_lut, &c->prep_a, &c->prep_b, &c->post_keys, &c->post_ws, &c->e_parents, &c->e_action, &c->e_free, &c->e_cost, &c->e_cells, &c->e_count})
+                    &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx, &c->blk, &c->sat, &c->prep_lut, &c->prep_a, &c->prep_b, &c->post_keys, &c->post_ws, &c->live_list, &c->e_parents, &c->e_action, &c->e_free, &c->e_cost, &c->e_cells, &c->e_count})
     release(*b);
   (void)mplx_comm_destroy(c);
   release(c->comm_meta);
@@ -787,11 +788,25 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.l_nstride = o->node_stride ? o->node_stride : c->nU;
     a.l_pad = (a.l_nstride % 32 == 0 && !c->tune.no_line_pad) ? 1 : 0;  // see expand_grid_kernel.hip
     if (int rc = yaw_slot(c, &a.yaw)) return rc;
+    // Yaw controls with a heading limit on a frontier of several nodes per wave: validate_yaw(t = 0) of every node
+    // first, lane per node, and the main kernel walks the survivors only (grid_prescreen_kernel).  Small batches (a
+    // search's) skip it: one more launch costs them more than the dead nodes do.
+    const int64_t ps_min = c->tune.prescreen_min > 0 ? c->tune.prescreen_min : (int64_t)4 * gp.grid * mplx::grid_waves_per_block();
+    if (yaw && gp.order >= 2 && c->prm.yaw_max > 0 && c->tune.prescreen_min >= 0 && n_nodes >= ps_min && n_nodes < 0x7fffffffLL) {
+      if (int rc = ensure(c, c->live_list, ((size_t)n_nodes + 1) * 4)) return rc;
+      int32_t *live = (int32_t *)c->live_list.p;
+      uint32_t *live_n = (uint32_t *)c->live_list.p + n_nodes;
+      HIP_TRY(c, mplx::launch_grid_prescreen(c->dim, c->prm.control, a, live, live_n, c->stream));
+      a.live = live;
+      a.live_n = live_n;
+    }
     if (int rc = launch_grid(c, &a)) return rc;
     if (a.yaw.amb) {
       mplx_ctx::YawPending p;
       p.kind = 0;
       p.g = a;
+      p.g.live = nullptr;  // the fix pass walks its own node list
+      p.g.live_n = nullptr;
       c->yaw_pending.push_back(p);
     }
     c->last_route = MPLX_ROUTE_GRID;

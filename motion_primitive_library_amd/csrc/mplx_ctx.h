@@ -65,6 +65,7 @@ struct mplx_ctx {
     int zero_copy = 1;                                   // MPLX_ZERO_COPY=0: small batches through a device arena instead
     int arena_kb = 0;                                    // MPLX_ARENA_KB: largest batch served by the one-copy path
     bool no_sat = false, no_lex = false, no_line_pad = false;  // MPLX_GRID_NOSAT / MPLX_GRID_NOLEX / MPLX_NO_LINE_PAD
+    int prescreen_min = 0;     // MPLX_GRID_PRESCREEN_MIN: smallest frontier that gets the lane-per-node pre-screen (0 = automatic, -1 = never)
     bool yaw_pin = true;       // MPLX_YAW_PIN=0: raw device trig decisions (to measure what the pinning is for)
     double yaw_margin = 0;     // MPLX_YAW_MARGIN: detection band (tests widen it to drive many nodes through the fix pass)
   } tune;
@@ -106,6 +107,7 @@ struct mplx_ctx {
   std::vector<double> h_U;          // host copy of the control table (the fix pass needs the yaw rates)
   double h_uyaw[16] = {0};          // ... and of its distinct yaw rates, in the factorisation's order
   int64_t yaw_flagged = 0, yaw_fix_passes = 0;  // statistics (mplx_yaw_pin_stats)
+  mplx_detail::DevBuf live_list;          // pre-screen of yaw controls: surviving nodes (int32 each) + their number (last word)
   mplx_detail::DevBuf work_counter;       // dynamic node assignment of the factorised kernel (GridArgs::work)
   int work_parity = 0;                    // which of the two counter sets the next launch uses
   // workgroups of the factorised kernel resident per CU (grid_resident_blocks), cached per (control, potential, LDS)

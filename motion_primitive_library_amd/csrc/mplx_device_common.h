@@ -58,6 +58,19 @@ __device__ __forceinline__ int wave_reduce_minmax(int v) {
   return __builtin_amdgcn_readlane(x, 63);
 }
 
+// wave-wide OR of an unsigned over all 64 lanes (all lanes active), result uniform: the same seven DPP moves
+__device__ __forceinline__ unsigned int wave_reduce_or(unsigned int v) {
+  int x = (int)v;
+  x |= __builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x |= __builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x |= __builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false);  // row_shr:3
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xe, false);       // row_shr:4
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xc, false);       // row_shr:8: lane 15 of a row = the row
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);       // row_bcast:15 into rows 1, 3
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);       // row_bcast:31 into rows 2, 3: lane 63 = the wave
+  return (unsigned int)__builtin_amdgcn_readlane(x, 63);
+}
+
 // ---- yaw pinning (YawPin, mplx_internal.h): is the heading-limit decision `d < cos_lim` of validate_yaw
 // (primitive.h:504-525) within rounding noise of its threshold?  One case is exempt because it is an exact tie under
 // ANY libm with an even cosine: velocity along x (vy == 0: the y term is an exact zero and vx / |v| is exactly +-1)

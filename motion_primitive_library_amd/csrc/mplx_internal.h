@@ -163,8 +163,15 @@ struct GridArgs {
   int64_t l_nstride;  // entries reserved per node (>= nU)
   int32_t l_pad;      // 1: complete the last 128-byte line of every list row (node stride is a multiple of 32)
   YawPin yaw;         // heading-limit decisions pinned to the host libm (see YawPin); tab row: [c0, s0, cT[16], sT[16]]
+  // Pre-screen of yaw controls (grid_prescreen_kernel): the nodes whose own heading passes validate_yaw at t = 0, in
+  // frontier order, and their number (device memory, written by the pre-screen launch that precedes this one on the
+  // stream).  Null: the kernel walks [0, n_nodes) and tests every node itself.
+  const int32_t *live;
+  const uint32_t *live_n;
 };
 constexpr int kWorkCounters = 64;
+// lane-per-node validate_yaw(t = 0) over a whole frontier (expand_grid_kernel.hip); fills live / live_n of `a`'s launch
+hipError_t launch_grid_prescreen(int dim, int control, const GridArgs &a, int32_t *live, uint32_t *live_n, hipStream_t s);
 // Packing of the used list prefixes for the copy back to the host (pack_kernel.hip).
 constexpr int kPackRows = 24;
 struct PackArgs {
