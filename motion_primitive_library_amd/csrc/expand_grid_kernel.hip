@@ -961,7 +961,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
           int ptr[3] = {0, 0, 0};
 #pragma unroll
           for (int i = 0; i < D; i++) ptr[i] = __umul24(en[i], rowcap) + r;
-          bool done = !smp || safe;  // a node whose whole reach box is free has nothing to look up
+          bool done = !smp || safe || (A.dbg & 32);  // a node whose whole reach box is free has nothing to look up (dbg 32: timing ablation, rows built but no sample loop)
           const double sdt = (smp && (POT || ycost)) ? T / n : 0.0;  // env_map.h:96
           // env_map.h:121-129: heading cost of sample k (after the potential term of the same sample)
           const int pyr = YAW ? __umul24(jy, rowcap) + r : 0;

@@ -21,6 +21,9 @@ def load(name, lib):
     mod = importlib.util.module_from_spec(spec)
     sys.modules[name] = mod
     spec.loader.exec_module(mod)
+    import ctypes
+    probe = ctypes.CDLL(os.path.abspath(lib))
+    mod._abi.SYMBOLS = [n for n in mod._abi.SYMBOLS if hasattr(probe, n)]  # an older build lacks the newer entry points
     mod._abi.lib()
     return mod
 
