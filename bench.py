@@ -103,10 +103,13 @@ def time_lists(env, frontier, lists, steps, warmup):
     return env.timer_end() / steps
 
 
-def run_config(m, wl, steps, warmup, device=0):
-    """Resident-lists kernel rate of one workload (used for the configurations next to the headline)."""
+def run_config(m, wl, steps, warmup, device=0, route=None):
+    """Resident-lists kernel rate of one workload (used for the configurations next to the headline).  route: force
+    "tile" / "dense" (the general kernels behind the factorised one) instead of the automatic choice."""
     env = m.EnvMap(wl.dim, device)
     wl.apply(env)
+    if route:
+        env.set_lists_route(route)
     fr = env.upload_frontier(wl.nodes)
     lists = env.alloc_lists(wl.n_nodes, want_state=True, want_iters=False)
     n_emit, n_fin, n_samples = count_work(env, fr, wl.n_nodes)
@@ -226,7 +229,8 @@ def extra_plan(m):
     U = W.grid_controls([-0.5, 0.0, 0.5], 2)
     start, goal = m.Waypoint(2, m.ACC, pos=c["start"]), m.Waypoint(2, m.ACC, pos=c["goal"])
     c1 = {"problem": "C1: test_planner_2d on data/corridor.yaml, ACC, |U| = 9"}
-    c1["engine_host_search"] = engine_plan(m, 2, c["origin"], c["dim"], c["cells"], c["res"], U, start, goal, 1.0, 1.0, 64)
+    c1["engine_host_search"] = engine_plan(m, 2, c["origin"], c["dim"], c["cells"], c["res"], U, start, goal, 1.0, 1.0, 16)
+    c1["engine_host_search"]["batch"] = 16  # a 5 535-pair problem: a small speculative batch (64: ~30 % slower)
     if have_ref:
         oenv = O.Env(2, O.ACC, U, c["cells"], c["dim"], c["origin"], c["res"], v_max=1.0, a_max=1.0, dt=1.0)
         cpu = min((O.ref_plan(oenv, start.to_row(), goal.to_row(), use_gpu=False) for _ in range(3)), key=lambda r: r["wall_ms"])
@@ -236,36 +240,47 @@ def extra_plan(m):
                                                "expansions": ad["expansions"], "launches": ad["device_launches"]}
         c1["agree"] = bool(cpu["cost"] == ad["cost"] == c1["engine_host_search"]["cost"] and cpu["closed"] == 615)
     out["C1"] = c1
-    # ---- 3D, |U| = 729: large enough for batching to matter
-    edge, res = 120, 0.1
-    grid = W.box_map([edge] * 3, res, 0.08, 4242, side_m=(0.5, 2.5))
-    flat = grid.ravel()
-    U3 = W.grid_controls(np.linspace(-2.0, 2.0, 9), 3)
+    # ---- 3D, |U| = 729: large enough for batching to matter; 120^3 (3.3 k expansions) and 160^3 (64 k expansions)
+    def problem_3d(edge, with_adapter, engine_batch, reps):
+        res = 0.1
+        grid = W.box_map([edge] * 3, res, 0.08, 4242, side_m=(0.5, 2.5))
+        flat = grid.ravel()
+        U3 = W.grid_controls(np.linspace(-2.0, 2.0, 9), 3)
 
-    def free_near(p):
-        cc = np.array([int(x / res) for x in p])
-        for r in range(0, 30):
-            for d in np.ndindex(2 * r + 1, 2 * r + 1, 2 * r + 1):
-                q = cc + np.array(d) - r
-                if np.all(q >= 0) and np.all(q < edge) and flat[q[0] + edge * (q[1] + edge * q[2])] == 0:
-                    return [(q[i] + 0.5) * res for i in range(3)]
-        raise RuntimeError("no free cell")
+        def free_near(p):
+            cc = np.array([int(x / res) for x in p])
+            for r in range(0, 30):
+                for d in np.ndindex(2 * r + 1, 2 * r + 1, 2 * r + 1):
+                    q = cc + np.array(d) - r
+                    if np.all(q >= 0) and np.all(q < edge) and flat[q[0] + edge * (q[1] + edge * q[2])] == 0:
+                        return [(q[i] + 0.5) * res for i in range(3)]
+            raise RuntimeError("no free cell")
 
-    s3 = m.Waypoint(3, m.ACC, pos=free_near([1.0, 1.0, 1.0]))
-    g3 = m.Waypoint(3, m.ACC, pos=free_near([edge * res - 1.0, edge * res - 1.2, edge * res - 1.5]))
-    p3 = {"problem": "3D %d^3 voxels, ACC, |U| = 729, v_max 2" % edge}
-    p3["engine_host_search"] = engine_plan(m, 3, [0.0] * 3, [edge] * 3, flat, res, U3, s3, g3, 2.0, 2.0, 64, reps=2)
-    if have_ref:
-        oenv = O.Env(3, O.ACC, U3, flat, [edge] * 3, [0.0] * 3, res, v_max=2.0, a_max=2.0, dt=1.0)
-        cpu = O.ref_plan(oenv, s3.to_row(), g3.to_row(), use_gpu=False)
-        ad = O.ref_plan(oenv, s3.to_row(), g3.to_row(), use_gpu=64)
-        p3["reference_cpu"] = {k: cpu[k] for k in ("wall_ms", "ok", "cost", "expansions")}
-        p3["reference_planner_gpu_adapter"] = {"wall_ms": ad["wall_ms"], "ok": ad["ok"], "cost": ad["cost"],
-                                               "expansions": ad["expansions"], "launches": ad["device_launches"]}
-        p3["agree"] = bool(cpu["cost"] == ad["cost"] == p3["engine_host_search"]["cost"])
-        p3["speedup_engine_vs_reference_cpu"] = cpu["wall_ms"] / p3["engine_host_search"]["wall_ms"]
-        p3["speedup_adapter_vs_reference_cpu"] = cpu["wall_ms"] / ad["wall_ms"]
-    out["3D"] = p3
+        s3 = m.Waypoint(3, m.ACC, pos=free_near([1.0, 1.0, 1.0]))
+        g3 = m.Waypoint(3, m.ACC, pos=free_near([edge * res - 1.0, edge * res - 1.2, edge * res - 1.5]))
+        p3 = {"problem": "3D %d^3 voxels, ACC, |U| = 729, v_max 2" % edge}
+        p3["engine_host_search"] = engine_plan(m, 3, [0.0] * 3, [edge] * 3, flat, res, U3, s3, g3, 2.0, 2.0, engine_batch, reps=reps)
+        p3["engine_host_search"]["batch"] = engine_batch
+        if have_ref:
+            oenv = O.Env(3, O.ACC, U3, flat, [edge] * 3, [0.0] * 3, res, v_max=2.0, a_max=2.0, dt=1.0)
+            cpu = O.ref_plan(oenv, s3.to_row(), g3.to_row(), use_gpu=False)
+            p3["reference_cpu"] = {k: cpu[k] for k in ("wall_ms", "ok", "cost", "expansions")}
+            agree = cpu["cost"] == p3["engine_host_search"]["cost"] and cpu["expansions"] == p3["engine_host_search"]["expansions"]
+            if with_adapter:
+                ad = O.ref_plan(oenv, s3.to_row(), g3.to_row(), use_gpu=64)
+                p3["reference_planner_gpu_adapter"] = {"wall_ms": ad["wall_ms"], "ok": ad["ok"], "cost": ad["cost"],
+                                                       "expansions": ad["expansions"], "launches": ad["device_launches"]}
+                agree = agree and cpu["cost"] == ad["cost"]
+                p3["speedup_adapter_vs_reference_cpu"] = cpu["wall_ms"] / ad["wall_ms"]
+            p3["agree"] = bool(agree)
+            p3["speedup_engine_vs_reference_cpu"] = cpu["wall_ms"] / p3["engine_host_search"]["wall_ms"]
+        return p3
+
+    out["3D"] = problem_3d(120, True, 64, 2)
+    # the larger problem: the reference's search alone takes ~20 s of one host core here, so one run each and no adapter leg
+    # (its 2.8 x is the 120^3 figure: most of the adapter's time is the reference's own StateSpace, not get_succ)
+    if os.environ.get("MPLX_BENCH_SKIP_PLAN_160") != "1":
+        out["3D_160"] = problem_3d(160, False, 256, 1)
     out["cpu_threads_used"] = 1
     return out
 
@@ -305,6 +320,12 @@ def extras(m, args, wl, out):
             r.update(stats)
             r["workload"] = WORKLOAD_DESC[name]
             res[name] = r
+        # the general kernels on the headline workload: what a control table outside the factorised kernel's scope
+        # (more than 16 distinct values per axis, gradient_weight != 0, SNP with yaw ...) costs at this size
+        for route in ("tile", "dense"):
+            r = run_config(m, wl, max(3, args.steps // 4), 1, route=route)
+            r["workload"] = WORKLOAD_DESC[args.workload] + " through the %s route" % route
+            res[args.workload + "_" + route + "_route"] = r
         return res
     leg("other_configs", others)
     leg("plan", lambda: extra_plan(m))

@@ -70,10 +70,12 @@
 // per (x / y entry, sample) the velocity, so that the per-sample heading cost of
 // traverse_primitive (env_map.h:121-129) is table look-ups, one sqrt and two
 // divisions.  Potential maps with gradient_weight == 0 read the int8 values per
-// sample (env_map.h:113-118).
+// sample (env_map.h:113-118); with gradient_weight != 0 the velocity rows of every
+// axis are built next to the cell rows and a sample inside the field adds
+// gradient_weight * |vel|.
 //
 // Scope: v_max > 0 (or VEL), Dim 2/3, K = 1..4 (K <= 3 with yaw or a potential
-// map), gradient_weight == 0, n_max <= 61.
+// map), n_max <= 61.
 #include "mplx_internal.h"
 #include "mplx_device_common.h"
 
@@ -88,11 +90,14 @@ struct GridLds {
   int o_uyaw, w_yaw, w_ycs, w_yq, w_hmask, w_vs, w_ycsr;  // yaw controls only
   int total;
   int F, EN, PN, tts, KQ;
-  // ym: 0 = no yaw, 1 = yaw, 2 = yaw with the per-sample heading cost (wyaw > 0); ndy = distinct yaw rates
+  // ym & 3: 0 = no yaw, 1 = yaw, 2 = yaw with the per-sample heading cost (wyaw > 0); ym & 4: per-sample |vel| of a
+  // potential map with gradient_weight != 0 (env_map.h:116); ndy = distinct yaw rates
   // ulex: the control table is the nested-loop enumeration of its per-axis values (GridArgs::ulex): the per-control
   // entry indices are arithmetic then, no table
   __host__ __device__ GridLds(int D, int K, int waves, int nU, int ndp, int n_max, int rmax, int boxcap, int ym,
                               int ndy, int ulex) {
+    const int grad = ym & 4;  // bit 2: velocity rows of ALL axes (potential maps with gradient_weight != 0)
+    ym &= 3;
     F = 4 * D + 2;
     EN = D * ndp;
     PN = (D == 3) ? ndp * ndp : ndp;
@@ -129,7 +134,7 @@ struct GridLds {
     w_yq = w; w += ym ? 16 * 4 : 0;             // lattice integer of yaw(T)
     w_hmask = w; w += ym ? ndp * ndp * 2 : 0;   // per (x entry, y entry): yaw values passing the heading limit
     w = (w + 15) & ~15;
-    w_vs = w; w += ym == 2 ? 2 * ndp * rmax * tts * 8 : 0;   // velocity of the x / y entries at the sample times
+    w_vs = w; w += grad ? D * ndp * rmax * tts * 8 : (ym == 2 ? 2 * ndp * rmax * tts * 8 : 0);  // velocity of the x / y (gradient cost: all) entries at the sample times
     w_ycsr = w; w += ym == 2 ? ndy * rmax * tts * 16 : 0;    // cos, sin of the yaw at the sample times
     wave_bytes = (w + 15) & ~15;
     total = o_wave0 + waves * wave_bytes;
@@ -279,7 +284,8 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
   // small control table it is the other way round (|U| = 125: ~700 samples against up to 1 156 rows).
   const bool gather = A.gather != 0;
   const int ndy = YAW ? A.ndy : 0;
-  const GridLds L(D, K, kWPB, nU, ndp, A.n_max, RM, A.boxcap, YAW ? (ycost ? 2 : 1) : 0, ndy, A.ulex);
+  const bool gcost = POT && A.grad_w != 0;  // env_map.h:116: gradient_weight * |vel| per sample inside the potential field
+  const GridLds L(D, K, kWPB, nU, ndp, A.n_max, RM, A.boxcap, (YAW ? (ycost ? 2 : 1) : 0) | (gcost ? 4 : 0), ndy, A.ulex);
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const double *s_uval = (const double *)(smem + L.o_uval);
@@ -818,7 +824,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
               s_cell[__umul24(aj, rowcap) + row + k] = (unsigned char)code;
               lo_l[ax] = code < lo_l[ax] ? code : lo_l[ax];
               hi_l[ax] = code > hi_l[ax] ? code : hi_l[ax];
-              if (YAW && ax < 2 && ycost)  // Waypoint::vel of the sample (primitive.h:321-331), x and y
+              if ((YAW && ax < 2 && ycost) || gcost)  // Waypoint::vel of the sample (primitive.h:321-331): x and y for the heading cost, every axis for |vel|
                 s_vs[__umul24(aj, rowcap) + row + k] = q.template vel<false>(trow[k]);
             }
           }
@@ -1003,7 +1009,19 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
                 if (!done && k0 + q < cntl) {
                   if (bad[q] || val[q] >= 100) { fb = k0 + q; done = true; }
                   else {
-                    if (val[q] > 0) csum += sdt * (A.pot_w * val[q]);
+                    if (val[q] > 0) {
+                      if (gcost) {  // env_map.h:115-116: dt * (potential_weight * value + gradient_weight * vel.norm())
+                        double vv = 0;
+#pragma unroll
+                        for (int i = 0; i < D; i++) {
+                          const double vi_ = s_vs[ptr[i] + k0 + q];
+                          vv += vi_ * vi_;
+                        }
+                        csum += sdt * (A.pot_w * val[q] + A.grad_w * sqrt(vv));
+                      } else {
+                        csum += sdt * (A.pot_w * val[q]);
+                      }
+                    }
                     if (YAW && ycost) heading_cost(k0 + q);
                   }
                 }
@@ -1286,7 +1304,8 @@ hipError_t launch_grid_inst(const GridArgs &a, hipStream_t stream) {
   if (a.n_nodes == 0) return hipSuccess;
   const int64_t n_wg = (a.n_nodes + kWPB - 1) / kWPB;
   const int64_t blocks = n_wg < (int64_t)a.grid_limit ? n_wg : (int64_t)a.grid_limit;
-  const size_t lds = grid_lds_bytes(D, K, a.nU, a.ndp, a.n_max, a.rmax, a.boxcap, YAW ? (a.wyaw > 0 ? 2 : 1) : 0, a.ndy, a.ulex);
+  const size_t lds = grid_lds_bytes(D, K, a.nU, a.ndp, a.n_max, a.rmax, a.boxcap,
+                                    (YAW ? (a.wyaw > 0 ? 2 : 1) : 0) | ((POT && a.grad_w != 0) ? 4 : 0), a.ndy, a.ulex);
   if (hipError_t e = grid_inst_attr<D, K, YAW, POT>()) return e;
   hipLaunchKernelGGL((expand_grid_kernel<D, K, YAW, POT>), dim3((unsigned)blocks), dim3(kBT), lds, stream, a);
   return hipGetLastError();

@@ -447,7 +447,6 @@ GridPlan plan_grid(const mplx_ctx *c) {
   const mplx_params &p = c->prm;
   const bool yaw = (p.control & 0x10) != 0;
   if (yaw && (c->udim != c->dim + 1 || c->u_nd[3] < 1)) return g;
-  if (c->has_pot && c->prm.gradient_weight != 0) return g;  // |vel| per sample: lane-per-pair kernel
   if (!c->u_factored || c->nU > 1024 || c->nU < 1) return g;
   double vbound;
   if ((p.control & 0x0f) == MPLX_VEL) vbound = c->u_absmax;
@@ -466,7 +465,8 @@ GridPlan plan_grid(const mplx_ctx *c) {
   // SNP: the rare primitives whose cell codes leave their range are sampled by direct evaluation, which the
   // kernel has for plain occupancy queries only
   if (order == 4 && (yaw || c->has_pot)) return g;
-  const int ym = yaw ? (p.wyaw > 0 ? 2 : 1) : 0, ndy = yaw ? c->u_nd[3] : 0;
+  // GridLds's mode word: bits 0-1 the yaw tables, bit 2 the velocity rows of every axis (gradient cost of a potential map)
+  const int ym = (yaw ? (p.wyaw > 0 ? 2 : 1) : 0) | ((c->has_pot && p.gradient_weight != 0) ? 4 : 0), ndy = yaw ? c->u_nd[3] : 0;
   int rmax = 4, boxcap = (c->dim == 3) ? (n_max + 3) * (n_max + 3) : 4 * (n_max + 3);
   if (boxcap < 64) boxcap = 64;
   if (boxcap > 1024) boxcap = 1024;
@@ -760,6 +760,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.pot = c->has_pot ? (const int8_t *)c->pot.p : nullptr;
     a.region = c->has_region ? (const uint32_t *)c->region_bits.p : nullptr;
     a.pot_w = c->prm.potential_weight;
+    a.grad_w = c->has_pot ? c->prm.gradient_weight : 0.0;
     const bool yaw = (c->prm.control & 0x10) != 0;
     // the free-box shortcut skips the sample loops, which a per-sample heading cost (wyaw > 0) still needs
     a.sat = (c->sat_ok && gp.order <= 3 && !(yaw && c->prm.wyaw > 0) && !c->tune.no_sat && gp.use_sat)

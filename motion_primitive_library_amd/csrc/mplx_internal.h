@@ -116,7 +116,7 @@ struct GridArgs {
   int64_t blk_words;
   const int8_t *pot;     // potential map (then blk / sat describe "potential > 0 or outside the region") or null
   const uint32_t *region; // search region bits (read by the potential path only; folded into blk otherwise)
-  double pot_w;
+  double pot_w, grad_w;  // env_map.h:115-116: potential_weight, gradient_weight
   const uint32_t *sat;   // summed-area table of blk, sizes dim+1 with a zero border (launch_build_sat), or null
   int32_t dim0, dim1, dim2;
   double org0, org1, org2;

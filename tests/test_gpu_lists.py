@@ -208,8 +208,8 @@ def test_control_tables_larger_than_a_workgroup_tile(engine, oracle_lib):
 def test_potential_map_on_the_factorised_kernel(engine, oracle_lib, monkeypatch, dim, control, nosat):
     """Potential maps with gradient_weight == 0 (env_map.h:113-118 reduces to dt * w_p * value per sample) stay on
     the factorised kernel: per-sample values from the int8 map, costs accumulated in the reference's order (bit-exact),
-    the free-box shortcut now meaning "zero potential in the whole reach box".  With a search region on top, and
-    dropping back to the lane-per-pair kernel when gradient_weight != 0."""
+    the free-box shortcut now meaning "zero potential in the whole reach box".  With a search region on top, and with
+    gradient_weight != 0 (per-sample |vel| from velocity rows)."""
     if nosat:
         monkeypatch.setenv("MPLX_GRID_NOSAT", "1")
     wl = _small_world(engine, dim, control, seed=7100 + 10 * dim + control, potential=True, region=True, n_nodes=120,
@@ -226,9 +226,14 @@ def test_potential_map_on_the_factorised_kernel(engine, oracle_lib, monkeypatch,
     got = env.expand_lists(wl.nodes)
     assert env.last_lists_route() == "grid"
     assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="potential on grid dim%d ctrl0x%x" % (dim, control))
+    # gradient_weight != 0 (env_map.h:116: + gradient_weight * |vel| per sample inside the field): the velocity rows of
+    # every axis are built next to the cell rows; still the factorised kernel, still bit-exact
     env.set_gradient_weight(0.25)
-    env.expand_lists(wl.nodes)
-    assert env.last_lists_route() == "dense"
+    got_g = env.expand_lists(wl.nodes)
+    assert env.last_lists_route() == "grid"
+    ref_g = oracle_lib.expand(oracle_env(wl, gradient_weight=0.25), wl.nodes, threads=8)
+    assert np.any(ref_g["cost"][fin] != ref["cost"][fin])  # the term really contributes
+    assert_lists_equal(got_g, ref_g, wl.n_nodes, wl.U.shape[0], what="potential + gradient on grid dim%d ctrl0x%x" % (dim, control))
     # switching back to a plain occupancy query on the same context rebuilds the blocked bits
     env.set_gradient_weight(0.0)
     env.set_potential_map(None)
@@ -244,14 +249,14 @@ def test_potential_map_on_the_factorised_kernel(engine, oracle_lib, monkeypatch,
 
 @pytest.mark.parametrize("dim", [2, 3])
 @pytest.mark.parametrize("control", [0x11, 0x13, 0x17])
-@pytest.mark.parametrize("variant", ["heading_cost", "no_cost", "no_limit", "potential", "region"])
+@pytest.mark.parametrize("variant", ["heading_cost", "no_cost", "no_limit", "potential", "potential_gradient", "region"])
 def test_yaw_controls_on_the_factorised_kernel(engine, oracle_lib, dim, control, variant):
     """Yaw controls (VELxYAW, ACCxYAW, JRKxYAW) with the yaw rate as a fourth factor of the control table: heading
     limit at both ends (primitive.h:504-525), yaw in the lattice hash and the successor state, per-sample heading
     cost (env_map.h:121-129) alone and on top of a potential map.  Same lists from the factorised kernel and from
     the lane-per-pair kernel, both against the oracle; cos / sin differ from glibc's in the last place, hence the
     cost tolerance."""
-    wl = _small_world(engine, dim, control, seed=8100 + 10 * dim + control, potential=(variant == "potential"),
+    wl = _small_world(engine, dim, control, seed=8100 + 10 * dim + control, potential=variant.startswith("potential"),
                       region=(variant == "region"), n_nodes=110, edge=56)
     if control != 0x11:
         # most headings roughly along the velocity, or the heading limit leaves almost nothing to traverse
@@ -261,6 +266,8 @@ def test_yaw_controls_on_the_factorised_kernel(engine, oracle_lib, dim, control,
         wl.nodes[4 * dim] = np.where(keep, wl.nodes[4 * dim], along)
     if variant == "potential":
         wl.params["gradient_weight"] = 0.0
+    if variant == "potential_gradient":
+        wl.params["gradient_weight"] = 0.3
     if variant == "no_cost":
         wl.params["wyaw"] = 0.0
     if variant == "no_limit":
