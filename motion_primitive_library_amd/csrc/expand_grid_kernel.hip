@@ -29,12 +29,17 @@
 // it computes) with ~60 instructions per map sample, most of them address
 // arithmetic of the global look-up, so here the occupancy bits of the node's
 // reachable box are staged into LDS once per node and a sample is 3 byte
-// look-ups + 1 word look-up; (3) with that done the kernel is bound by its list
-// stores (2.7 GB per launch on C4), so they are full 128-byte lines, carry the
-// `sc1 nt` policy (st_stream), and the waves' priority follows their progress
-// through a node (wave_prio) so that store bursts are issued ahead of set-up work;
-// nodes whose whole reach box is free (summed-area table) skip R and the sample
-// loops altogether.
+// look-ups + 1 word look-up; (3) the list stores (2.7 GB per launch on C4) are
+// full 128-byte lines, carry the `sc1 nt` policy (st_stream), and the waves'
+// priority follows their progress through a node (wave_prio) so that store bursts
+// are issued ahead of set-up work; nodes whose whole reach box is free
+// (summed-area table) skip R and the sample loops altogether.  (4) What bounds
+// the result (round 3, profiles/r03_c4_ablation.txt: same box, same allocation,
+// variants alternating): VALU ISSUE, still -- 206 M wave instructions per C4
+// launch = 0.336 ms of the 0.504; without any list store the kernel takes 0.378
+// ms, without sampling 0.285, with neither 0.201, and the parts add up almost
+// serially.  Instructions per node (3 189 on C4: 1 578 set-up + pair phase, 667
+// rows + staging, 615 sample loops, 329 stores) are the figure of merit.
 //
 // Per node (one wave):
 //   T1  axis entries (axis, value): limits, n_axis, end state, lattice integers,
