@@ -336,25 +336,27 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
   // later ones are claimed from this workgroup's counter.  The chunk after the current one is always claimed already
   // (its first node is being prefetched), so the atomic's round trip is never waited for.
   const bool pinned = YAW && A.yaw.tab != nullptr;
-  const int64_t wave_id = (int64_t)blockIdx.x * kWPB + wv;
-  const int64_t wave_stride = (int64_t)gridDim.x * kWPB;
+  // (node indices and chunk bookkeeping in 32 bits: a frontier has fewer than 2^31 nodes -- checked by the host -- and
+  // every 64-bit uniform costs two of the kernel's 102 SGPRs for its whole life)
+  const int wave_id = (int)blockIdx.x * kWPB + wv;
+  const int wave_stride = (int)gridDim.x * kWPB;
   // the override pass of the yaw pinning walks a list of nodes; everything else the whole frontier in order
   // (or, after a pre-screen launch, the list of nodes whose own heading passed validate_yaw at t = 0)
   const bool screened = YAW && A.live != nullptr;
-  const int64_t NN = screened ? (int64_t)*A.live_n : A.n_nodes;
-  auto node_of = [&](int64_t it) -> int64_t {
-    return screened ? (int64_t)A.live[it] : ((YAW && A.yaw.node_list) ? (int64_t)A.yaw.node_list[it] : it);
+  const int NN = screened ? (int)*A.live_n : (int)A.n_nodes;
+  auto node_of = [&](int it) -> int64_t {
+    return screened ? (int64_t)A.live[it] : ((YAW && A.yaw.node_list) ? (int64_t)A.yaw.node_list[it] : (int64_t)it);
   };
   const bool dyn = A.work != nullptr;
-  const int64_t ck = dyn ? A.work_chunk : 1;
-  int64_t dyn_beg = 0, dyn_len = 0, dyn_step = 1;  // this counter's share of the claimable chunks
+  const int ck = dyn ? A.work_chunk : 1;
+  int dyn_beg = 0, dyn_len = 0, dyn_step = 1;  // this counter's share of the claimable chunks
   unsigned int *ctr = nullptr;
   if (dyn) {
     if (blockIdx.x == 0 && threadIdx.x < kWorkCounters) A.work_zero[threadIdx.x * 32] = 0u;  // for the next launch
-    const int64_t n_chunks = (NN + ck - 1) / ck, n_dyn = n_chunks > wave_stride ? n_chunks - wave_stride : 0;
+    const int n_chunks = (NN + ck - 1) / ck, n_dyn = n_chunks > wave_stride ? n_chunks - wave_stride : 0;
     const int nc = gridDim.x < (unsigned)kWorkCounters ? (int)gridDim.x : kWorkCounters;  // counters in use
     const int cx = (int)(blockIdx.x % nc);
-    const int64_t base = n_dyn / nc, rem = n_dyn % nc;
+    const int base = n_dyn / nc, rem = n_dyn % nc;
     dyn_len = base + (cx < rem ? 1 : 0);
     // Which chunks are this counter's: dealt round-robin (chunk W + j * nc + cx is its j-th).  All counters advance
     // at about the same pace, so at any moment the whole launch works inside ONE window of the frontier and of every
@@ -363,17 +365,17 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
     else { dyn_beg = wave_stride + cx; dyn_step = nc; }
     ctr = A.work + cx * 32;
   }
-  auto claim = [&]() -> int64_t {  // first node of the next chunk of this counter, or past the end
+  auto claim = [&]() -> int {  // first node of the next chunk of this counter, or past the end
     unsigned int v = 0;
     if (lane == 0) v = atomicAdd(ctr, 1u);
-    const int64_t j = (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
-    return j < dyn_len ? (dyn_beg + j * dyn_step) * ck : NN;
+    const int j = __builtin_amdgcn_readfirstlane((int)v);
+    return (j >= 0 && j < dyn_len) ? (dyn_beg + j * dyn_step) * ck : NN;
   };
-  const int64_t it0 = wave_id * ck;
-  int64_t chunk_end = it0 + ck < NN ? it0 + ck : NN;
+  const int it0 = wave_id * ck;
+  int chunk_end = it0 + ck < NN ? it0 + ck : NN;
   double nxt = 0.0;  // lanes < F: one field of the next node (prefetched)
   if (it0 < NN && lane < F) nxt = A.nodes[(int64_t)lane * A.node_stride + node_of(it0)];
-  int64_t next_chunk = NN;  // (dynamic) first node of the chunk claimed ahead
+  int next_chunk = NN;  // (dynamic) first node of the chunk claimed ahead
   if (dyn && it0 < NN) next_chunk = claim();
 
   // ---- once per (persistent) workgroup: shared read-only tables
@@ -397,10 +399,10 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
 
   // primitive.h:521; in the override pass the host libm's value (see YawPin in mplx_internal.h)
   const double cos_lim = (YAW && A.yaw_max > 0) ? (pinned ? A.yaw.cos_lim : cos(A.yaw_max)) : 0.0;
-  int64_t it_next = 0;
+  int it_next = 0;
 
   PT_DECL;
-  for (int64_t it = it0; it < NN; it = it_next) {
+  for (int it = it0; it < NN; it = it_next) {
     PT(9);  // (loop overhead / tail of the previous node)
     asm volatile("" : "+s"(Ak));  // see the top of the kernel
     if (!dyn) {
@@ -413,7 +415,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
       next_chunk = it_next < NN ? claim() : NN;
     }
     const int64_t node = node_of(it);
-    const double *ytab = pinned ? A.yaw.tab + it * A.yaw.tab_stride : nullptr;  // [c0, s0, cT[16], sT[16]]
+    const double *ytab = pinned ? A.yaw.tab + (int64_t)it * A.yaw.tab_stride : nullptr;  // [c0, s0, cT[16], sT[16]]
     bool yaw_amb = false;  // a heading-limit decision of this node is within rounding noise of the threshold
     // ---- phase 0: node state into LDS, prefetch of the next node
     wave_prio(0);

@@ -751,6 +751,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
   // 32 us against 54 us per launch for 16 - 256 nodes at |U| = 729 (profiles/micro/route_latency.py; no
   // difference for |U| <= 125).
   if (route == MPLX_ROUTE_AUTO && gp.ok && n_nodes <= 512 && c->nU >= 512 && plan_tile(c).ok) gp.ok = false;
+  if (gp.ok && n_nodes >= 0x7fffffffLL - 4096) gp.ok = false;  // the factorised kernel counts nodes in 32 bits
   if (gp.ok) {
     if (int rc = ensure_tables(c)) return rc;
     mplx::GridArgs a{};
