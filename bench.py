@@ -626,7 +626,10 @@ def main():
             env.synchronize()
             merge_ms = (time.perf_counter() - t0) * 1e3
             unique = int((bufs["flags"].view(torch.uint8, int(res[4][-1])) & 4).ne(0).sum().item())
+            # cross-check of the merge on the device: the number of distinct lattice hashes among the gathered successors
+            distinct = int(torch.unique(rows_all["hash"][: int(res[4][-1])]).numel())
             gather["merge"] = {"ms": merge_ms, "entries": int(res[4][-1]), "first_occurrences": unique,
+                               "distinct_hashes_torch_unique": distinct, "ok": bool(unique == distinct),
                                "what": "mplx_post_packed_device on the gathered lists of all ranks, on every rank: "
                                        "heuristic + goal flags + node identity (first occurrence of each lattice state)"}
             for b_ in bufs.values():

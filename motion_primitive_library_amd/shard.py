@@ -41,6 +41,10 @@ class TorchArray:
 
         self.nbytes = int(nbytes)
         self.t = torch.zeros((self.nbytes + 7) // 8 + 1, dtype=torch.int64, device=device)
+        if self.t.is_cuda:
+            # the fill runs on TORCH's stream; the engine launches on its own: without this the zeroing can land after a
+            # kernel of the engine has written the buffer (seen as a merge that reported 1 first occurrence of 20 M)
+            torch.cuda.current_stream(self.t.device).synchronize()
         self.ptr = self.t.data_ptr()
 
     def view(self, dtype, n=None, offset=0):

@@ -160,6 +160,8 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(tmp_path, launcher):
     g = d["allgather"]
     assert "error" not in g, g
     assert g["edges"]["entries"] == g["full"]["entries"] == d["roofline"]["emitted_all_ranks"] > 0
+    # the consumer of the gather: first occurrences reported by the merge = distinct hashes counted by torch.unique
+    assert g["merge"]["ok"] is True and g["merge"]["first_occurrences"] == g["merge"]["distinct_hashes_torch_unique"] > 0
 
 
 def test_c_abi_allgather_refuses_a_short_gathered_side_collectively(engine):
