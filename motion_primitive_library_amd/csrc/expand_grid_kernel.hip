@@ -79,8 +79,8 @@
 // axis are built next to the cell rows and a sample inside the field adds
 // gradient_weight * |vel|.
 //
-// Scope: v_max > 0 (or VEL), Dim 2/3, K = 1..4 (K <= 3 with yaw or a potential
-// map), n_max <= 61.
+// Scope: v_max > 0 (or VEL), Dim 2/3, K = 1..4, with or without yaw and potential
+// maps, n_max <= 61, <= 16 distinct control values per axis, <= 1024 controls.
 #include "mplx_internal.h"
 #include "mplx_device_common.h"
 
@@ -580,8 +580,8 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
         unsigned int mask = 0xffffu;
         if (lim) {
           Ax<K> qx, qy;
-          qx.init(s_node[0], (K >= 2) ? s_node[1 * D] : 0.0, (K >= 3) ? s_node[2 * D] : 0.0, 0.0, s_uval[j0]);
-          qy.init(s_node[1], (K >= 2) ? s_node[1 * D + 1] : 0.0, (K >= 3) ? s_node[2 * D + 1] : 0.0, 0.0, s_uval[ndp + j1]);
+          qx.init(s_node[0], (K >= 2) ? s_node[1 * D] : 0.0, (K >= 3) ? s_node[2 * D] : 0.0, (K >= 4) ? s_node[3 * D] : 0.0, s_uval[j0]);
+          qy.init(s_node[1], (K >= 2) ? s_node[1 * D + 1] : 0.0, (K >= 3) ? s_node[2 * D + 1] : 0.0, (K >= 4) ? s_node[3 * D + 1] : 0.0, s_uval[ndp + j1]);
           const double vx0 = qx.template vel<true>(0.0), vy0 = qy.template vel<true>(0.0);
           if (vx0 != 0 || vy0 != 0) {
             const double sn = sqrt(vx0 * vx0 + vy0 * vy0);
@@ -986,8 +986,8 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
               csum += A.wyaw * v_value * sdt;
             }
           };
-          if (POT) {
-            // potential map (env_map.h:113-118; gradient_weight == 0 on this route): the values are needed, not
+          if (POT && !direct) {
+            // potential map (env_map.h:113-118): the values are needed, not
             // just a bit, so the samples read the int8 cells from HBM / L2 (8 in flight per lane) and the cost is
             // accumulated in the reference's order
             for (int k0 = 0; __ballot(!done) != 0ull; k0 += kUB) {
@@ -1066,7 +1066,11 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
               if (left <= kUB) done = true;
             }
           } else if (direct) {
-            // a cell code left its range: evaluate every sample of the pair directly (as expand_tile_kernel does)
+            // a cell code left its range (only a SNP primitive can do that: the reference's root loop stops at the first
+            // root >= T, primitive.h:158-159): every sample of the pair by direct evaluation, with everything the row
+            // paths do -- occupancy bit or potential value + search region, the potential / |vel| cost of
+            // env_map.h:113-118 and the heading cost of :121-129 -- in the reference's order, on the same expressions
+            // as the rows (Ax::pos / vel<false> at the table's accumulated times; wrap(u_yaw * t + yaw))
             double p0[D], v0[D], a0[D], j0d[D], uu[D];
 #pragma unroll
             for (int i = 0; i < D; i++) {
@@ -1076,11 +1080,13 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
               j0d[i] = (K >= 4) ? s_node[3 * D + i] : 0.0;
               uu[i] = s_uval[en[i]];
             }
+            const double cyaw_d = YAW ? s_node[4 * D] : 0.0, uyaw_d = YAW ? s_uyaw[jy] : 0.0;
             for (int k = 0; __ballot(!done) != 0ull; k++) {
               if (!done) {
                 const double t_k = A.ttab[n * kTabStride + k];
                 bool inside = true;
                 int64_t cell = 0, mul = 1;
+                double vk[D];
 #pragma unroll
                 for (int i = 0; i < D; i++) {
                   Ax<K> q;
@@ -1090,8 +1096,38 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
                   inside = inside && c >= 0 && c < dims[i];
                   cell += mul * c;
                   mul *= dims[i];
+                  vk[i] = (POT || (YAW && ycost)) ? q.template vel<false>(t_k) : 0.0;
                 }
-                const bool blocked = !inside || ((A.blk[inside ? (cell >> 5) : 0] >> (cell & 31)) & 1u);
+                bool blocked;
+                if (POT) {
+                  const int64_t ci_ = inside ? cell : 0;
+                  const bool in_reg = A.region == nullptr || ((A.region[ci_ >> 5] >> (ci_ & 31)) & 1u);
+                  const int pv = A.pot[ci_];
+                  blocked = !inside || !in_reg || pv >= 100;
+                  if (!blocked) {
+                    if (pv > 0) {
+                      if (gcost) {
+                        double vv = 0;
+#pragma unroll
+                        for (int i = 0; i < D; i++) vv += vk[i] * vk[i];
+                        csum += sdt * (A.pot_w * pv + A.grad_w * sqrt(vv));
+                      } else {
+                        csum += sdt * (A.pot_w * pv);
+                      }
+                    }
+                    if (YAW && ycost) {
+                      const double sn = sqrt(vk[0] * vk[0] + vk[1] * vk[1]);
+                      if (sn > 1e-5) {
+                        double sn_, cs_;
+                        sincos(wrap_angle(uyaw_d * t_k + cyaw_d), &sn_, &cs_);
+                        const double v_value = 1 - (vk[0] / sn * cs_ + vk[1] / sn * sn_);
+                        csum += A.wyaw * v_value * sdt;
+                      }
+                    }
+                  }
+                } else {
+                  blocked = !inside || ((A.blk[inside ? (cell >> 5) : 0] >> (cell & 31)) & 1u);
+                }
                 if (blocked) { fb = k; done = true; }
                 if (k + 1 >= cntl) done = true;
               }
@@ -1135,8 +1171,23 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
           for (int i = 0; i < 2; i++) ptr[i] = __umul24(en[i], rowcap) + r;
           const int pyr = __umul24(jy, rowcap) + r;
           const double sdt = go ? T / n : 0.0;
+          Ax<K> qx_d, qy_d;  // direct evaluation (a pass whose cell codes left their range): no velocity / trig rows
+          if (direct) {
+            qx_d.init(s_node[0], (K >= 2) ? s_node[1 * D] : 0.0, (K >= 3) ? s_node[2 * D] : 0.0, (K >= 4) ? s_node[3 * D] : 0.0, s_uval[en[0]]);
+            qy_d.init(s_node[1], (K >= 2) ? s_node[1 * D + 1] : 0.0, (K >= 3) ? s_node[2 * D + 1] : 0.0, (K >= 4) ? s_node[3 * D + 1] : 0.0, s_uval[en[1]]);
+          }
           for (int k = 0; __ballot(go && k < cntl) != 0ull; k++) {
-            if (go && k < cntl) {
+            if (go && k < cntl && direct) {
+              const double t_k = A.ttab[n * kTabStride + k];
+              const double vx = qx_d.template vel<false>(t_k), vy = qy_d.template vel<false>(t_k);
+              const double sn = sqrt(vx * vx + vy * vy);
+              if (sn > 1e-5) {
+                double sn_, cs_;
+                sincos(wrap_angle(s_uyaw[jy] * t_k + s_node[4 * D]), &sn_, &cs_);
+                const double v_value = 1 - (vx / sn * cs_ + vy / sn * sn_);
+                csum += A.wyaw * v_value * sdt;
+              }
+            } else if (go && k < cntl) {
               const double vx = s_vs[ptr[0] + k], vy = s_vs[ptr[1] + k];
               const double sn = sqrt(vx * vx + vy * vy);
               if (sn > 1e-5) {
@@ -1347,20 +1398,22 @@ R dispatch_grid(int dim, int control, bool pot, R none, F &&f) {
       case 0x01: return MPLX_GI(2, 1, false);
       case 0x03: return MPLX_GI(2, 2, false);
       case 0x07: return MPLX_GI(2, 3, false);
-      case 0x0f: return pot ? none : f(GridInst<2, 4, false, false>{});
+      case 0x0f: return MPLX_GI(2, 4, false);
       case 0x11: return MPLX_GI(2, 1, true);
       case 0x13: return MPLX_GI(2, 2, true);
       case 0x17: return MPLX_GI(2, 3, true);
+      case 0x1f: return MPLX_GI(2, 4, true);
     }
   } else if (dim == 3) {
     switch (control) {
       case 0x01: return MPLX_GI(3, 1, false);
       case 0x03: return MPLX_GI(3, 2, false);
       case 0x07: return MPLX_GI(3, 3, false);
-      case 0x0f: return pot ? none : f(GridInst<3, 4, false, false>{});
+      case 0x0f: return MPLX_GI(3, 4, false);
       case 0x11: return MPLX_GI(3, 1, true);
       case 0x13: return MPLX_GI(3, 2, true);
       case 0x17: return MPLX_GI(3, 3, true);
+      case 0x1f: return MPLX_GI(3, 4, true);
     }
   }
 #undef MPLX_GI
@@ -1431,6 +1484,8 @@ hipError_t launch_grid_prescreen(int dim, int control, const GridArgs &a, int32_
   else if (dim == 2 && control == 0x17) MPLX_PS(2, 3);
   else if (dim == 3 && control == 0x13) MPLX_PS(3, 2);
   else if (dim == 3 && control == 0x17) MPLX_PS(3, 3);
+  else if (dim == 2 && control == 0x1f) MPLX_PS(2, 4);
+  else if (dim == 3 && control == 0x1f) MPLX_PS(3, 4);
   else return hipErrorInvalidValue;
 #undef MPLX_PS
   return hipGetLastError();

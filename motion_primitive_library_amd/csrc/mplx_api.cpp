@@ -462,9 +462,8 @@ GridPlan plan_grid(const mplx_ctx *c) {
   // A box of (n_max + 3)^(D-1) rows covers every node whose per-axis velocities keep their sign.
   const int ctl = p.control & 0x0f;
   const int order = ctl == MPLX_VEL ? 1 : ctl == MPLX_ACC ? 2 : ctl == MPLX_JRK ? 3 : 4;
-  // SNP: the rare primitives whose cell codes leave their range are sampled by direct evaluation, which the
-  // kernel has for plain occupancy queries only
-  if (order == 4 && (yaw || c->has_pot)) return g;
+  // (SNP: the rare primitives whose cell codes leave their range are sampled by direct evaluation, which covers
+  // potential maps and the heading cost too since round 3)
   // GridLds's mode word: bits 0-1 the yaw tables, bit 2 the velocity rows of every axis (gradient cost of a potential map)
   const int ym = (yaw ? (p.wyaw > 0 ? 2 : 1) : 0) | ((c->has_pot && p.gradient_weight != 0) ? 4 : 0), ndy = yaw ? c->u_nd[3] : 0;
   int rmax = 4, boxcap = (c->dim == 3) ? (n_max + 3) * (n_max + 3) : 4 * (n_max + 3);

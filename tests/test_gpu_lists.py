@@ -132,6 +132,32 @@ def test_grid_kernel_small_lds_budgets(engine, oracle_lib, monkeypatch, rmax, bo
             rmax, boxcap, dim, control))
 
 
+@pytest.mark.parametrize("dim,control,potential,gradient", [(2, 0x1F, False, 0.0), (3, 0x1F, True, 0.0), (3, 0x0F, True, 0.3),
+                                                            (3, 0x13, True, 0.3), (2, 0x17, False, 0.0), (3, 0x03, True, 0.0)])
+def test_direct_evaluation_covers_potential_and_heading_costs(engine, oracle_lib, monkeypatch, dim, control, potential, gradient):
+    """MPLX_TILE_DBG bit 64 sends every pass through the direct-evaluation path (taken in production only when a SNP
+    primitive's cell code leaves its range, primitive.h:158-159): it must do everything the row paths do -- potential
+    values + search region, the potential / |vel| cost (env_map.h:113-118), the heading cost (:121-129) -- which is what
+    lets SNP x yaw and SNP on a potential map run on the factorised kernel at all."""
+    monkeypatch.setenv("MPLX_TILE_DBG", "64")
+    wl = _small_world(engine, dim, control, seed=3300 + dim + control, potential=potential, region=potential, n_nodes=90, edge=56)
+    if potential:
+        wl.params["gradient_weight"] = gradient
+    if control & 0x10:
+        rng = np.random.default_rng(dim + control)
+        along = np.arctan2(wl.nodes[dim + 1], wl.nodes[dim]) + rng.uniform(-0.4, 0.4, size=wl.n_nodes)
+        wl.nodes[4 * dim] = np.where(np.arange(wl.n_nodes) % 5 == 0, wl.nodes[4 * dim], along)
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+    assert np.count_nonzero(ref["status"] == 1) > 30 and np.count_nonzero(ref["status"] == 2) > 5
+    env = engine_env(engine, wl)
+    env.set_lists_route("grid")
+    got = env.expand_lists(wl.nodes)
+    assert env.last_lists_route() == "grid"
+    env.close()
+    assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], cost_rtol=1e-6 if control & 0x10 else 0.0,
+                       what="direct evaluation dim%d ctrl0x%x pot=%s" % (dim, control, potential))
+
+
 @pytest.mark.parametrize("nosat", [False, True])
 def test_free_box_shortcut_and_full_sampling_agree(engine, oracle_lib, monkeypatch, nosat):
     """Nodes whose whole reach box is free skip the sample loops (summed-area table look-up); a map with a
@@ -203,7 +229,7 @@ def test_control_tables_larger_than_a_workgroup_tile(engine, oracle_lib):
 
 
 @pytest.mark.parametrize("dim", [2, 3])
-@pytest.mark.parametrize("control", [0x01, 0x03, 0x07])
+@pytest.mark.parametrize("control", [0x01, 0x03, 0x07, 0x0F])
 @pytest.mark.parametrize("nosat", [False, True])
 def test_potential_map_on_the_factorised_kernel(engine, oracle_lib, monkeypatch, dim, control, nosat):
     """Potential maps with gradient_weight == 0 (env_map.h:113-118 reduces to dt * w_p * value per sample) stay on
@@ -221,7 +247,7 @@ def test_potential_map_on_the_factorised_kernel(engine, oracle_lib, monkeypatch,
     wl.nodes[:dim, :40] = np.round(np.random.default_rng(dim).uniform(1.4, 2.4, size=(dim, 40)), 2)
     ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
     fin = np.isfinite(ref["cost"]) & (ref["status"] >= 1)
-    assert np.count_nonzero(ref["status"] == 2) > 50 and np.count_nonzero(fin) > 200
+    assert np.count_nonzero(ref["status"] == 2) > 50 and np.count_nonzero(fin) > (80 if control == 0x0F else 200)
     env = engine_env(engine, wl)
     got = env.expand_lists(wl.nodes)
     assert env.last_lists_route() == "grid"
@@ -248,7 +274,7 @@ def test_potential_map_on_the_factorised_kernel(engine, oracle_lib, monkeypatch,
 
 
 @pytest.mark.parametrize("dim", [2, 3])
-@pytest.mark.parametrize("control", [0x11, 0x13, 0x17])
+@pytest.mark.parametrize("control", [0x11, 0x13, 0x17, 0x1F])
 @pytest.mark.parametrize("variant", ["heading_cost", "no_cost", "no_limit", "potential", "potential_gradient", "region"])
 def test_yaw_controls_on_the_factorised_kernel(engine, oracle_lib, dim, control, variant):
     """Yaw controls (VELxYAW, ACCxYAW, JRKxYAW) with the yaw rate as a fourth factor of the control table: heading
@@ -376,7 +402,9 @@ def test_lexicographic_enumeration_equals_the_table_walk(engine, monkeypatch, na
 
 
 def test_forcing_a_route_outside_its_scope_fails_loudly(engine):
-    wl = _small_world(engine, 2, 0x1F, seed=5, n_nodes=8)  # SNPxYAW: only the dense kernel covers it
+    # 17 distinct control values per axis: past the factorised kernel's 16 -- the workgroup-per-node kernel covers it
+    wl = _small_world(engine, 2, 0x03, seed=5, n_nodes=8)
+    wl.U = engine.workloads.grid_controls(list(np.linspace(-1.0, 1.0, 17)), 2)
     env = engine_env(engine, wl)
     env.set_lists_route("grid")
     with pytest.raises(engine._abi.MplxError) as e:
@@ -384,7 +412,13 @@ def test_forcing_a_route_outside_its_scope_fails_loudly(engine):
     assert e.value.code == engine._abi.ERR_STATE
     env.set_lists_route("auto")
     env.expand_lists(wl.nodes)
-    assert env.last_lists_route() == "dense"
+    assert env.last_lists_route() == "tile"
+    env.close()
+    # SNP x YAW: the lane-per-pair kernel's alone until round 3, on the factorised kernel since
+    wl = _small_world(engine, 2, 0x1F, seed=5, n_nodes=8)
+    env = engine_env(engine, wl)
+    env.expand_lists(wl.nodes)
+    assert env.last_lists_route() == "grid"
     env.close()
 
 
