@@ -18,6 +18,7 @@
 
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -52,9 +53,15 @@ Rccl &rccl() {
   std::call_once(once, [] {
     // A process that already has an RCCL (PyTorch-ROCm ships its own librccl.so) must keep using that one: two
     // RCCL builds in one process corrupt each other's state.  So first look for a loaded copy, then load ROCm's.
+    // MPLX_RCCL_LIB: a library with the NCCL C API to use instead (a site build of RCCL; in the tests a shared-memory
+    // stand-in that lets several processes on ONE GPU form a communicator, tests/fake_rccl/) -- takes precedence.
+    if (const char *over = getenv("MPLX_RCCL_LIB")) {
+      r.h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+      if (!r.h) { r.err = std::string("cannot load MPLX_RCCL_LIB: ") + dlerror(); return; }
+    }
     for (const char *name : {"librccl.so", "librccl.so.1"}) {
-      r.h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
       if (r.h) break;
+      r.h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
     }
     if (!r.h)
       for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {

@@ -252,3 +252,95 @@ def test_c_abi_all_pairs_exchange_on_two_gpus(engine):
     for rank, noff, eoff, got in res:
         assert noff == [0, 501, 1001] and eoff[-1] == want["total"]
         _assert_packed_equal(got, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The G > 1 branch of the C-ABI exchange, executed for real on a ONE-GPU box: several processes share device 0 and
+# libmplx.so binds tests/fake_rccl (the NCCL C API over a shared mapping; RCCL itself refuses two ranks on one device).
+FAKE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl")
+FAKE_SO = os.path.join(FAKE_DIR, "libfake_rccl.so")
+
+
+def _build_fake_rccl():
+    import shutil
+    import subprocess
+    src = os.path.join(FAKE_DIR, "fake_rccl.cpp")
+    if os.path.exists(FAKE_SO) and os.path.getmtime(FAKE_SO) >= os.path.getmtime(src):
+        return FAKE_SO
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.run([hipcc, "-O2", "-fPIC", "-shared", "-o", FAKE_SO, src], check=True, cwd=FAKE_DIR)
+    return FAKE_SO
+
+
+def _fake_rank(rank, world, n_nodes, short_rank, id_q, out_q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MPLX_RCCL_LIB"] = FAKE_SO
+    import motion_primitive_library_amd as m
+    from motion_primitive_library_amd.shard import partition
+    try:
+        real = m.workloads.make("C4", scale=0.25, n_nodes=n_nodes)
+        wl = real if rank == 0 else m.workloads.make("C4", scale=0.25, n_nodes=n_nodes, shell=True)  # others: an empty map
+        lo, hi = partition(n_nodes, world, rank)
+        env = m.EnvMap(wl.dim, 0)  # every rank on device 0
+        wl.apply(env)
+        if rank == 0:
+            uid = m.EnvMap.comm_unique_id()
+            for _ in range(world - 1):
+                id_q.put(uid)
+        else:
+            uid = id_q.get(timeout=120)
+        env.comm_init(uid, rank, world)
+        env.comm_broadcast_map(0)  # ranks > 0 receive rank 0's map
+        fr = env.upload_frontier(np.ascontiguousarray(real.nodes[:, lo:hi]))
+        lists = env.alloc_lists(hi - lo, want_state=True, want_iters=False)
+        env.expand_lists_resident(fr, lists)
+        packed = env.alloc_packed(hi - lo)
+        env.pack_lists(lists, packed)
+        cap = n_nodes * env.nU
+        err = None
+        if short_rank is not None:  # one rank's gathered side is too small: EVERY rank must get the error, none may hang
+            try:
+                env.comm_allgather_lists(packed, hi - lo, env.alloc_packed(n_nodes, capacity=64 if rank == short_rank else cap))
+            except m._abi.MplxError as e:
+                err = (e.code, str(e))
+        gathered = env.alloc_packed(n_nodes, capacity=cap)
+        noff, eoff = env.comm_allgather_lists(packed, hi - lo, gathered)  # and the communicator still works afterwards
+        got = gathered.download(n_nodes)
+        env.comm_destroy()
+        env.close()
+        out_q.put((rank, noff[:world + 1].tolist(), eoff[:world + 1].tolist(), got, err))
+    except Exception as e:  # noqa: BLE001 -- reported to the parent instead of a silent hang
+        out_q.put((rank, None, None, None, ("exception", repr(e))))
+
+
+@pytest.mark.parametrize("world,n_nodes,short_rank", [(2, 131, None), (3, 181, None), (4, 40, None), (3, 100, 1)])
+def test_c_abi_all_pairs_exchange_between_processes_on_one_gpu(engine, world, n_nodes, short_rank):
+    """mplx_comm_init / _broadcast_map / _allgather_lists with G = 2, 3, 4 ranks: one process per rank, all on device 0,
+    the transport a shared-memory stand-in with the NCCL API (MPLX_RCCL_LIB -> tests/fake_rccl).  Every rank must end up
+    with the packed lists of the WHOLE frontier, identical to a single-process expansion; ranks other than 0 start with an
+    empty map and get rank 0's through the broadcast; a rank with a short gathered side makes all ranks fail together."""
+    import torch.multiprocessing as mp
+    _build_fake_rccl()
+    ctx = mp.get_context("spawn")
+    id_q, out_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_fake_rank, args=(r, world, n_nodes, short_rank, id_q, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out_q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    wl = engine.workloads.make("C4", scale=0.25, n_nodes=n_nodes)
+    env = engine_env(engine, wl)
+    fr, lists = _expand(engine, env, wl)
+    want = engine.pack_host_lists(lists.download(), wl.n_nodes)
+    env.close()
+    from motion_primitive_library_amd.shard import partition
+    for rank, noff, eoff, got, err in sorted(res, key=lambda r: r[0]):
+        assert got is not None, err
+        assert noff == [0] + [partition(n_nodes, world, r)[1] for r in range(world)] and eoff[-1] == want["total"]
+        _assert_packed_equal(got, want)
+        if short_rank is not None:
+            assert err is not None and err[0] == engine._abi.ERR_ARG and "capacity" in err[1] and "rank %d" % short_rank in err[1], err
