@@ -872,7 +872,10 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
       if (fits && sub) {  // (never for a safe node)
         const float inv_ny = 1.0f / (float)nb[1];
         const int ax0 = base_c[0] + lo[0] - half;
-        constexpr int SU = 4;  // rows per lane with their loads in flight together
+#ifndef MPLX_GRID_SU
+#define MPLX_GRID_SU 4
+#endif
+        constexpr int SU = MPLX_GRID_SU;  // rows per lane with their loads in flight together
         const int ayb = base_c[1] + lo[1] - half, azb = (D == 3) ? base_c[2] + lo[2] - half : 0;
         for (int w = 0; w < WX; w++) {
           const int xw = ax0 + 32 * w;
