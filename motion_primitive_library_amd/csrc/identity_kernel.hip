@@ -125,7 +125,7 @@ __device__ __forceinline__ TileSrc tile_of(const IdentityArgs &A, const uint32_t
     t.hi = t.lo + kTile < A.n_slots ? t.lo + kTile : A.n_slots;
     t.ctr0 = tile;
     t.ctr_stride = A.tiles1;
-    t.shift = 64 - A.b1;
+    t.shift = A.b1 ? 64 - A.b1 : 0;  // (one bucket: the digit is masked to 0 whatever the shift)
     t.nb = 1 << A.b1;
     t.ok = true;
     t.node0 = (uint32_t)(t.lo / A.nstride);  // (uniform: one scalar division per workgroup)
@@ -395,11 +395,7 @@ __global__ __launch_bounds__(kBT) void id_tables_kernel(const IdentityArgs A) {
           const bool mine = ((have >> i) & 1u) && ((uint32_t)(m >> 12) & (R - 1u)) == r;
           fresh += mine ? 0x10000u : 0u;
           if (mine && h[i] == kEmpty) atomicMin(&special, g[i]);  // the one hash the key field cannot hold
-#ifdef MPLX_ID_NO_INSERT
-          if (false) {
-#else
           if (mine && h[i] != kEmpty) {
-#endif
             uint32_t s = (uint32_t)m & (kSlots - 1);
             for (int probes = 0;; probes++) {
               // plain reads first: LDS atomics are processed lane by lane, reads at full rate.  A key that is already
@@ -443,11 +439,7 @@ __global__ __launch_bounds__(kBT) void id_tables_kernel(const IdentityArgs A) {
         for (int i = 0; i < kPT; i++) {
           const uint64_t m = mix(h[i]);
           const bool mine = ((have >> i) & 1u) && ((uint32_t)(m >> 12) & (R - 1u)) == r;
-#ifdef MPLX_ID_NO_LOOKUP
-          if (false) {
-#else
           if (mine) {
-#endif
             uint32_t c;
             if (h[i] == kEmpty) {
               c = special;
@@ -457,11 +449,7 @@ __global__ __launch_bounds__(kBT) void id_tables_kernel(const IdentityArgs A) {
               while (keys[s] != h[i] && probes++ <= kMaxProbe) s = (s + 1) & (kSlots - 1);
               c = keys[s] == h[i] ? vals[s] : g[i];  // (a key that was not inserted: only past the 2^20-round limit)
             }
-#ifndef MPLX_ID_NO_STORE
             if (c != g[i]) A.canon[g[i]] = (int32_t)c;  // (first occurrences were written by the level-1 histogram pass)
-#else
-            if (c == 0x12345u) A.canon[g[i]] = (int32_t)c;
-#endif
           }
         }
       }
