@@ -299,6 +299,21 @@ def extras(m, args, wl, out):
 
     leg("e2e", lambda: extra_e2e(m, wl))
 
+    def edges_only():
+        """The same launch without the 14 state rows: count + action + cost + hash per successor -- what the engine's
+        own host search asks for (it evaluates the states of NEW nodes itself, bit-identically, host_planner.hpp)."""
+        env = m.EnvMap(wl.dim, 0)
+        wl.apply(env)
+        fr = env.upload_frontier(wl.nodes)
+        lists = env.alloc_lists(wl.n_nodes, want_state=False, want_iters=False)
+        ms = time_lists(env, fr, lists, args.steps, args.warmup)
+        lists.free()
+        fr.free()
+        env.close()
+        return {"kernel_ms": ms, "value": wl.n_pairs / (ms * 1e-3), "unit": "pairs/s",
+                "what": "resident lists without the Waypoint rows (action + cost + hash: 20 B per successor instead of 132)"}
+    leg("edges_only", edges_only)
+
     def wavefront():
         import copy
         w2 = copy.copy(wl)
