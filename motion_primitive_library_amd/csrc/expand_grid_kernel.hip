@@ -86,10 +86,14 @@
 
 namespace mplx {
 
+#ifndef MPLX_GRID_TT_RESIDENT
+#define MPLX_GRID_TT_RESIDENT 1
+#endif
+
 // LDS carve-up, shared by host (size) and device (offsets).
 struct GridLds {
   // shared by the workgroup (read-only after set-up)
-  int o_uval, o_uidx, o_tc, o_wave0;
+  int o_uval, o_uidx, o_tc, o_tt, o_wave0;
   // per wave, relative to the wave's block
   int w_node, w_est, w_hp, w_eq, w_eflag, w_box, w_misc, w_rowmap, w_list, w_cell, w_uq, wave_bytes;
   int o_uyaw, w_yaw, w_ycs, w_yq, w_hmask, w_vs, w_ycsr;  // yaw controls only
@@ -102,6 +106,7 @@ struct GridLds {
   __host__ __device__ GridLds(int D, int K, int waves, int nU, int ndp, int n_max, int rmax, int boxcap, int ym,
                               int ndy, int ulex) {
     const int grad = ym & 4;  // bit 2: velocity rows of ALL axes (potential maps with gradient_weight != 0)
+    const int tt_resident = MPLX_GRID_TT_RESIDENT;
     ym &= 3;
     F = 4 * D + 2;
     EN = D * ndp;
@@ -112,9 +117,10 @@ struct GridLds {
     o_uval = b; b += EN * 8;
     o_uidx = b; b += ulex ? 0 : ((nU + 1) & ~1) * 2;  // 4 bits per axis
     o_tc = b; b += 64;
-    // (tried in round 2: the sample-time rows of every n <= n_max resident in shared LDS, to save the per-pass round
-    // trip to the global table -- no measurable gain on any configuration, 3.9 KB per workgroup at C4: not kept)
     b = (b + 7) & ~7;
+    // the accumulated sample times of every count n <= n_max, [n_max + 1][tts]: resident for the workgroup's life, so
+    // that a pass needs no round trip to the global table between the pair phase and the rows
+    o_tt = b; b += tt_resident ? (n_max + 1) * tts * 8 : 0;
     o_uyaw = b; b += ym ? 16 * 8 : 0;
     b = (b + 15) & ~15;
     o_wave0 = b;
@@ -393,6 +399,14 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
     }
     if (YAW && threadIdx.x < ndy) ((double *)(smem + L.o_uyaw))[threadIdx.x] = A.uvals[3 * 16 + threadIdx.x];
     if (threadIdx.x < 64) smem[L.o_tc + threadIdx.x] = A.tcnt[threadIdx.x];
+    if (MPLX_GRID_TT_RESIDENT) {
+      double *tt = (double *)(smem + L.o_tt);
+      const int ntt = (A.n_max + 1) * L.tts;
+      for (int i = threadIdx.x; i < ntt; i += kBT) {
+        const int nn = i / L.tts, k = i - nn * L.tts;
+        tt[i] = A.ttab[nn * kTabStride + k];
+      }
+    }
   }
   __syncthreads();  // the only workgroup barrier
   asm volatile("" ::"v"(nxt));  // arrived before the loop: no wait for it at the loop head (see the pin after phase A)
@@ -773,7 +787,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
         for (unsigned long long t = sub; t; t &= t - 1ull) {
           const int nn = __ffsll((long long)t) - 1;
           const int cn = (int)s_tc[nn];
-          if (lane < cn) s_trow[off + lane] = A.ttab[nn * kTabStride + lane];
+          if (!MPLX_GRID_TT_RESIDENT && lane < cn) s_trow[off + lane] = A.ttab[nn * kTabStride + lane];
           off += cn;
         }
       }
@@ -789,7 +803,7 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
           const int nn = __ffsll((long long)t) - 1;
           const int cn = (int)s_tc[nn];
           const float inv_cn = 1.0f / (float)cn;
-          const double *trow = s_trow + row;
+          const double *trow = MPLX_GRID_TT_RESIDENT ? (const double *)(smem + L.o_tt) + nn * tts : s_trow + row;
           // The row of (entry, count nn) is only ever read by a pair whose count max(n_axis) IS nn, i.e. by entries
           // with n_entry <= nn: the small counts of a node need the rows of few entries (a JRK node uses 4 - 8 counts
           // between 5 and 31; building every entry's row for every count was ~40 % of C3's instructions).  Per count:
