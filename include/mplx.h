@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MPLX_ABI_VERSION 3
+#define MPLX_ABI_VERSION 4
 
 typedef struct mplx_ctx mplx_ctx;
 
