@@ -881,7 +881,11 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
       wave_sync();  // rows complete; the sample times (aliasing the box) are no longer needed
       const int WX = (nb[0] + 31) >> 5;
       const int n_rows = nb[1] * nb[2];
-      const bool direct = (__ballot(ovf) != 0ull) || (A.dbg & 64);  // dbg 64: test hook, force direct evaluation
+      // Only a SNP primitive's code can leave its range (the entries of K <= 3 have exact velocity maxima): the
+      // direct-evaluation path is compiled into the K = 4 instantiations alone -- in the others it was dead code that
+      // cost the yaw / potential instantiations 52 - 96 bytes of scratch per lane (C5 +7 %).
+      constexpr bool kDirectPossible = K == 4;
+      const bool direct = kDirectPossible && ((__ballot(ovf) != 0ull) || (A.dbg & 64));  // dbg 64: test hook, force direct evaluation
       const bool fits = !safe && !direct && !POT && have_box && n_rows * WX <= A.boxcap;
       if (fits && sub) {  // (never for a safe node)
         const float inv_ny = 1.0f / (float)nb[1];

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kBT) void id_ranges_kernel(const IdentityArgs A, ui
 }
 
 // ---- one workgroup per fine bucket: identity table in LDS
-__global__ __launch_bounds__(kBT) void id_tables_kernel(const IdentityArgs A) {
+__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(6))) void id_tables_kernel(const IdentityArgs A) {
   __shared__ unsigned long long keys[kSlots];
   __shared__ uint32_t vals[kSlots];
   __shared__ uint32_t nuniq, nseen, ovf, special;
@@ -364,19 +364,24 @@ __global__ __launch_bounds__(kBT) void id_tables_kernel(const IdentityArgs A) {
   // chunk: it is loaded once and both sweeps (insert, look-up) run from registers.  Rounds over further hash bits when
   // the bucket holds more distinct keys than the table takes.
   constexpr int kPT = kChunk / kBT;
+  static_assert(kPT == 8, "the eight pairs of a thread are written out below");
   const bool single = hi - lo <= kChunk;
-  uint64_t h[kPT];
-  uint32_t g[kPT];
+  // (eight scalars each, not arrays: hipcc kept an indexed array in scratch memory -- 200 MB of spill traffic per launch)
+  uint64_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0, h7 = 0;
+  uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0;
   uint32_t have = 0;  // bit i: pair i of the chunk exists
-#define MPLX_ID_LOAD(base_)                                         \
-  do {                                                              \
-    have = 0;                                                       \
-    _Pragma("unroll") for (int i_ = 0; i_ < kPT; i_++) {            \
-      const int64_t p_ = (base_) + i_ * kBT + threadIdx.x;          \
-      have |= (p_ < hi ? 1u : 0u) << i_;                            \
-      h[i_] = hk[p_ < hi ? p_ : lo];                                \
-      g[i_] = gi[p_ < hi ? p_ : lo];                                \
-    }                                                               \
+#define MPLX_ID_LOAD1(i_, base_)                                  \
+  {                                                               \
+    const int64_t p_ = (base_) + (i_) * kBT + threadIdx.x;        \
+    have |= (p_ < hi ? 1u : 0u) << (i_);                          \
+    h##i_ = hk[p_ < hi ? p_ : lo];                                \
+    g##i_ = gi[p_ < hi ? p_ : lo];                                \
+  }
+#define MPLX_ID_LOAD(base_)                                                                           \
+  do {                                                                                                \
+    have = 0;                                                                                         \
+    MPLX_ID_LOAD1(0, base_) MPLX_ID_LOAD1(1, base_) MPLX_ID_LOAD1(2, base_) MPLX_ID_LOAD1(3, base_)   \
+    MPLX_ID_LOAD1(4, base_) MPLX_ID_LOAD1(5, base_) MPLX_ID_LOAD1(6, base_) MPLX_ID_LOAD1(7, base_)   \
   } while (0)
   if (single) MPLX_ID_LOAD(lo);
   for (uint32_t R = 1;; R <<= 1) {
@@ -389,13 +394,12 @@ __global__ __launch_bounds__(kBT) void id_tables_kernel(const IdentityArgs A) {
         if (ovf) break;  // (not uniform, no barrier inside this loop: the round is void anyway)
         if (!single) MPLX_ID_LOAD(base);
         uint32_t fresh = 0;  // keys this thread put into the table | pairs it looked at << 16 (counted per wave below: one LDS atomic each per wave and chunk)
-#pragma unroll
-        for (int i = 0; i < kPT; i++) {
-          const uint64_t m = mix(h[i]);
-          const bool mine = ((have >> i) & 1u) && ((uint32_t)(m >> 12) & (R - 1u)) == r;
+        auto insert = [&](const uint64_t hh, const uint32_t gg, const bool exists) {
+          const uint64_t m = mix(hh);
+          const bool mine = exists && ((uint32_t)(m >> 12) & (R - 1u)) == r;
           fresh += mine ? 0x10000u : 0u;
-          if (mine && h[i] == kEmpty) atomicMin(&special, g[i]);  // the one hash the key field cannot hold
-          if (mine && h[i] != kEmpty) {
+          if (mine && hh == kEmpty) atomicMin(&special, gg);  // the one hash the key field cannot hold
+          if (mine && hh != kEmpty) {
             uint32_t s = (uint32_t)m & (kSlots - 1);
             for (int probes = 0;; probes++) {
               // plain reads first: LDS atomics are processed lane by lane, reads at full rate.  A key that is already
@@ -403,11 +407,11 @@ __global__ __launch_bounds__(kBT) void id_tables_kernel(const IdentityArgs A) {
               // up to a tile's run -- its index is rarely smaller than the one recorded, so usually no atomicMin either.
               unsigned long long k = keys[s];
               if (k == kEmpty) {
-                k = atomicCAS(&keys[s], (unsigned long long)kEmpty, (unsigned long long)h[i]);
-                if (k == kEmpty) { fresh++; k = h[i]; }
+                k = atomicCAS(&keys[s], (unsigned long long)kEmpty, (unsigned long long)hh);
+                if (k == kEmpty) { fresh++; k = hh; }
               }
-              if (k == h[i]) {
-                if (vals[s] > g[i]) atomicMin(&vals[s], g[i]);
+              if (k == hh) {
+                if (vals[s] > gg) atomicMin(&vals[s], gg);
                 break;
               }
               // a probe sequence this long means the table is (nearly) full: more distinct keys than `fill` are on
@@ -417,7 +421,9 @@ __global__ __launch_bounds__(kBT) void id_tables_kernel(const IdentityArgs A) {
               s = (s + 1) & (kSlots - 1);
             }
           }
-        }
+        };
+        insert(h0, g0, have & 1u); insert(h1, g1, have & 2u); insert(h2, g2, have & 4u); insert(h3, g3, have & 8u);
+        insert(h4, g4, have & 16u); insert(h5, g5, have & 32u); insert(h6, g6, have & 64u); insert(h7, g7, have & 128u);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) fresh += (uint32_t)__shfl_xor((int)fresh, d, 64);
         if ((threadIdx.x & 63) == 0 && fresh) {  // (8 pairs per lane x 64 lanes: both halves stay below 2^16)
@@ -435,28 +441,29 @@ __global__ __launch_bounds__(kBT) void id_tables_kernel(const IdentityArgs A) {
       if (all_first) continue;
       for (int64_t base = lo; base < hi; base += kChunk) {
         if (!single) MPLX_ID_LOAD(base);
-#pragma unroll
-        for (int i = 0; i < kPT; i++) {
-          const uint64_t m = mix(h[i]);
-          const bool mine = ((have >> i) & 1u) && ((uint32_t)(m >> 12) & (R - 1u)) == r;
-          if (mine) {
+        auto lookup = [&](const uint64_t hh, const uint32_t gg, const bool exists) {
+          const uint64_t m = mix(hh);
+          if (exists && ((uint32_t)(m >> 12) & (R - 1u)) == r) {
             uint32_t c;
-            if (h[i] == kEmpty) {
+            if (hh == kEmpty) {
               c = special;
             } else {
               uint32_t s = (uint32_t)m & (kSlots - 1);
               int probes = 0;
-              while (keys[s] != h[i] && probes++ <= kMaxProbe) s = (s + 1) & (kSlots - 1);
-              c = keys[s] == h[i] ? vals[s] : g[i];  // (a key that was not inserted: only past the 2^20-round limit)
+              while (keys[s] != hh && probes++ <= kMaxProbe) s = (s + 1) & (kSlots - 1);
+              c = keys[s] == hh ? vals[s] : gg;  // (a key that was not inserted: only past the 2^20-round limit)
             }
-            if (c != g[i]) A.canon[g[i]] = (int32_t)c;  // (first occurrences were written by the level-1 histogram pass)
+            if (c != gg) A.canon[gg] = (int32_t)c;  // (first occurrences were written by the level-1 histogram pass)
           }
-        }
+        };
+        lookup(h0, g0, have & 1u); lookup(h1, g1, have & 2u); lookup(h2, g2, have & 4u); lookup(h3, g3, have & 8u);
+        lookup(h4, g4, have & 16u); lookup(h5, g5, have & 32u); lookup(h6, g6, have & 64u); lookup(h7, g7, have & 128u);
       }
       __syncthreads();
     }
     if (!split) break;
   }
+#undef MPLX_ID_LOAD1
 #undef MPLX_ID_LOAD
 }
 

@@ -133,10 +133,11 @@ def test_grid_kernel_small_lds_budgets(engine, oracle_lib, monkeypatch, rmax, bo
 
 
 @pytest.mark.parametrize("dim,control,potential,gradient", [(2, 0x1F, False, 0.0), (3, 0x1F, True, 0.0), (3, 0x0F, True, 0.3),
-                                                            (3, 0x13, True, 0.3), (2, 0x17, False, 0.0), (3, 0x03, True, 0.0)])
+                                                            (2, 0x0F, True, 0.0), (3, 0x1F, False, 0.0), (2, 0x1F, True, 0.3)])
 def test_direct_evaluation_covers_potential_and_heading_costs(engine, oracle_lib, monkeypatch, dim, control, potential, gradient):
-    """MPLX_TILE_DBG bit 64 sends every pass through the direct-evaluation path (taken in production only when a SNP
-    primitive's cell code leaves its range, primitive.h:158-159): it must do everything the row paths do -- potential
+    """MPLX_TILE_DBG bit 64 sends every pass of a SNP instantiation through the direct-evaluation path (taken in production
+    only when a SNP primitive's cell code leaves its range, primitive.h:158-159; compiled into the K = 4 instantiations
+    alone: the velocity maxima of K <= 3 are exact): it must do everything the row paths do -- potential
     values + search region, the potential / |vel| cost (env_map.h:113-118), the heading cost (:121-129) -- which is what
     lets SNP x yaw and SNP on a potential map run on the factorised kernel at all."""
     monkeypatch.setenv("MPLX_TILE_DBG", "64")
