@@ -69,31 +69,6 @@ __global__ __launch_bounds__(kBT) void id_scan_blocks_kernel(uint32_t *cnt, uint
   for (int i = 0; i < kPer; i++) { p[i] = run; run += v[i]; }
   if (threadIdx.x == kBT - 1) tot[blockIdx.x] = part[kBT - 1];
 }
-// exclusive scan of the block totals in place, one workgroup; tot[n] = grand total
-__global__ __launch_bounds__(1024) void id_scan_totals_kernel(uint32_t *tot, int n) {
-  __shared__ uint32_t part[1024];
-  __shared__ uint32_t carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + threadIdx.x;
-    const uint32_t v = i < n ? tot[i] : 0u;
-    part[threadIdx.x] = v;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-      const uint32_t o = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0u;
-      __syncthreads();
-      part[threadIdx.x] += o;
-      __syncthreads();
-    }
-    if (i < n) tot[i] = carry + part[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += part[1023];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) tot[n] = carry;
-}
-
 // ---- one partition pass.  LEVEL 1 reads the lists (strided slots, only j < count[node] carry a successor; packed
 // lists are one node), LEVEL 2 reads level 1's output segment by segment (a tile never straddles two coarse buckets).
 struct TileSrc {
@@ -233,7 +208,10 @@ template <int LEVEL>
 __global__ __launch_bounds__(kBT) void id_scatter_kernel(const IdentityArgs A) {
   __shared__ uint32_t s_seg[2 * 65 + 2];
   __shared__ uint32_t hist[256], lbase[256], gbase[256], wtot[4];
-  constexpr bool kStagePairs = LEVEL == 2;
+#ifndef MPLX_ID_L2_PAIRS
+#define MPLX_ID_L2_PAIRS 1
+#endif
+  constexpr bool kStagePairs = LEVEL == 2 && MPLX_ID_L2_PAIRS;
   __shared__ unsigned short st_i[kStagePairs ? 1 : kTile];
   __shared__ uint64_t st_h[kStagePairs ? kTile : 1];
   __shared__ uint32_t st_g[kStagePairs ? kTile : 1];
@@ -253,6 +231,7 @@ __global__ __launch_bounds__(kBT) void id_scatter_kernel(const IdentityArgs A) {
       g[i] = A.gi[0][p < t.hi ? p : t.lo];
     }
   }
+  const uint64_t *src_h = LEVEL == 1 ? A.hash : A.hk[0];
 #pragma unroll
   for (int i = 0; i < kPer; i++) {
     rk[i] = 0;
@@ -292,46 +271,94 @@ __global__ __launch_bounds__(kBT) void id_scatter_kernel(const IdentityArgs A) {
   const uint32_t total = lbase[255] + hist[255];
   uint64_t *oh = A.hk[LEVEL == 1 ? 0 : 1];
   uint32_t *og = A.gi[LEVEL == 1 ? 0 : 1];
-  for (uint32_t p = threadIdx.x; p < total; p += kBT) {  // consecutive lanes -> consecutive addresses inside a digit's run
-    uint64_t hh;
-    uint32_t gg;
-    if (kStagePairs) {
-      hh = st_h[p];
-      gg = st_g[p];
-    } else {
-      const int64_t src = t.lo + st_i[p];
-      hh = A.hash[src];
-      gg = (uint32_t)src;
+  if (kStagePairs) {
+    for (uint32_t p = threadIdx.x; p < total; p += kBT) {  // consecutive lanes -> consecutive addresses inside a digit's run
+      const uint64_t hh = st_h[p];
+      const uint32_t d = (uint32_t)((mix(hh) >> t.shift) & (uint64_t)(t.nb - 1));
+      const uint32_t o = gbase[d] + (p - lbase[d]);
+      oh[o] = hh;
+      og[o] = st_g[p];
     }
-    const uint32_t d = (uint32_t)((mix(hh) >> t.shift) & (uint64_t)(t.nb - 1));
-    const uint32_t o = gbase[d] + (p - lbase[d]);
-    oh[o] = hh;
-    og[o] = gg;
+  } else {
+    // the hashes are read again through the staged positions: all kPer re-reads of a thread in flight at once (a loop
+    // with one dependent load per trip, the first version, spent a round trip to L2 per 256 pairs)
+    uint64_t hh[kPer];
+    uint32_t src[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; i++) {
+      const uint32_t p = i * kBT + threadIdx.x;
+      src[i] = p < total ? (uint32_t)st_i[p] : 0u;
+      hh[i] = src_h[t.lo + src[i]];
+    }
+    uint32_t gg[LEVEL == 2 ? kPer : 1];
+    if (LEVEL == 2) {
+#pragma unroll
+      for (int i = 0; i < kPer; i++) gg[i] = A.gi[0][t.lo + src[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; i++) {
+      const uint32_t p = i * kBT + threadIdx.x;
+      if (p < total) {
+        const uint32_t d = (uint32_t)((mix(hh[i]) >> t.shift) & (uint64_t)(t.nb - 1));
+        const uint32_t o = gbase[d] + (p - lbase[d]);
+        oh[o] = hh[i];
+        og[o] = LEVEL == 2 ? gg[LEVEL == 2 ? i : 0] : (uint32_t)(t.lo + src[i]);
+      }
+    }
   }
 }
 
-// the coarse buckets as segments of level 2: start[c] (c = 0 .. nb1), tile prefix tpre[c] (c = 0 .. nb1)
-__global__ __launch_bounds__(128) void id_segments_kernel(const IdentityArgs A) {
+// ---- exclusive scan of the block totals of one level in place, ONE workgroup (tot[n] = grand total); at level 1 of
+// two, in the same launch (a dependent single-workgroup dispatch costs ~5 us + the gap), the coarse buckets as segments
+// of level 2: seg[c] = start[c] (c = 0 .. nb1), seg[nb1 + 1 + c] = tile prefix tpre[c]
+__global__ __launch_bounds__(1024) void id_scan_totals_kernel(const IdentityArgs A, int level, int n) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t carry;
   __shared__ uint32_t start[66], nt[66];
-  const int nb1 = 1 << A.b1;
-  const int c = threadIdx.x;
-  if (c <= nb1) start[c] = scanned(A.cnt[0], A.tot[0], (int64_t)c * A.tiles1);  // c == nb1: one past the counters = the total
+  uint32_t *tot = A.tot[level - 1];
+  if (threadIdx.x == 0) carry = 0;
   __syncthreads();
-  if (c < nb1) nt[c] = (start[c + 1] - start[c] + kTile - 1) / kTile;
-  __syncthreads();
-  if (c == 0) {
-    uint32_t run = 0;
-    for (int k = 0; k < nb1; k++) {
-      A.seg[nb1 + 1 + k] = run;
-      run += nt[k];
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = i < n ? tot[i] : 0u;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const uint32_t o = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0u;
+      __syncthreads();
+      part[threadIdx.x] += o;
+      __syncthreads();
     }
-    A.seg[nb1 + 1 + nb1] = run;
+    if (i < n) tot[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
   }
-  if (c <= nb1) A.seg[c] = start[c];
+  if (threadIdx.x == 0) tot[n] = carry;
+  __threadfence_block();
+  __syncthreads();  // (this workgroup's own writes to tot[] are read back below by other threads of it)
+  const int nb1 = 1 << A.b1;
+  if (level == 1 && A.b2 > 0) {
+    const int c = threadIdx.x;
+    if (c <= nb1) start[c] = scanned(A.cnt[0], A.tot[0], (int64_t)c * A.tiles1);  // c == nb1: one past the counters = the total
+    __syncthreads();
+    if (c < nb1) nt[c] = (start[c + 1] - start[c] + kTile - 1) / kTile;
+    __syncthreads();
+    if (c == 0) {
+      uint32_t run = 0;
+      for (int k = 0; k < nb1; k++) {
+        A.seg[nb1 + 1 + k] = run;
+        run += nt[k];
+      }
+      A.seg[nb1 + 1 + nb1] = run;
+    }
+    if (c <= nb1) A.seg[c] = start[c];
+  }
 }
 
 // where every fine bucket starts in the partitioned pairs: range[b], b = 0 .. buckets (one thread per bucket), so that a
-// table workgroup starts with ONE load instead of segment table + two scanned counters
+// table workgroup starts with ONE load instead of segment table + two scanned counters.  (Its own launch: 16 385 buckets
+// through the ONE workgroup of the totals scan measured +10 us, 17 trips of dependent look-ups on one CU.)
 __global__ __launch_bounds__(kBT) void id_ranges_kernel(const IdentityArgs A, uint32_t n_buckets) {
   const uint32_t b = blockIdx.x * kBT + threadIdx.x;
   if (b > n_buckets) return;
@@ -492,18 +519,19 @@ hipError_t launch_identity(const IdentityArgs &a, int64_t ctr1, int64_t ctr2, hi
   if (a.n_slots <= 0) return hipSuccess;
   hipError_t e;
   auto up8 = [](int64_t tiles) { return (unsigned)(((tiles + 7) / 8) * 8); };  // whole rounds over the 8 XCDs (xcd_tile)
-  if ((e = hipMemsetAsync(a.cnt[0], 0, (size_t)ctr1 * 4, s)) != hipSuccess) return e;
+  // counters of both levels in one fill when they are adjacent (post_api.cpp carves them so)
+  const bool one_fill = a.b2 > 0 && a.cnt[1] == a.cnt[0] + ctr1;
+  if ((e = hipMemsetAsync(a.cnt[0], 0, (size_t)(ctr1 + (one_fill ? ctr2 : 0)) * 4, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(id_hist_kernel<1>, dim3(up8(a.tiles1)), dim3(kBT), 0, s, a);
   hipLaunchKernelGGL(id_scan_blocks_kernel, dim3((unsigned)(ctr1 / kTile)), dim3(kBT), 0, s, a.cnt[0], a.tot[0]);
-  hipLaunchKernelGGL(id_scan_totals_kernel, dim3(1), dim3(1024), 0, s, a.tot[0], (int)(ctr1 / kTile));
+  hipLaunchKernelGGL(id_scan_totals_kernel, dim3(1), dim3(1024), 0, s, a, 1, (int)(ctr1 / kTile));  // + segments
   hipLaunchKernelGGL(id_scatter_kernel<1>, dim3(up8(a.tiles1)), dim3(kBT), 0, s, a);
   unsigned buckets = 1u << a.b1;
   if (a.b2 > 0) {
-    if ((e = hipMemsetAsync(a.cnt[1], 0, (size_t)ctr2 * 4, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(id_segments_kernel, dim3(1), dim3(128), 0, s, a);
+    if (!one_fill && (e = hipMemsetAsync(a.cnt[1], 0, (size_t)ctr2 * 4, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(id_hist_kernel<2>, dim3(up8(a.tiles2_cap)), dim3(kBT), 0, s, a);
     hipLaunchKernelGGL(id_scan_blocks_kernel, dim3((unsigned)(ctr2 / kTile)), dim3(kBT), 0, s, a.cnt[1], a.tot[1]);
-    hipLaunchKernelGGL(id_scan_totals_kernel, dim3(1), dim3(1024), 0, s, a.tot[1], (int)(ctr2 / kTile));
+    hipLaunchKernelGGL(id_scan_totals_kernel, dim3(1), dim3(1024), 0, s, a, 2, (int)(ctr2 / kTile));
     hipLaunchKernelGGL(id_scatter_kernel<2>, dim3(up8(a.tiles2_cap)), dim3(kBT), 0, s, a);
     buckets <<= a.b2;
   }
