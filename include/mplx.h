@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MPLX_ABI_VERSION 4
+#define MPLX_ABI_VERSION 5
 
 typedef struct mplx_ctx mplx_ctx;
 
@@ -477,6 +477,23 @@ enum { MPLX_ROUTE_AUTO = 0, MPLX_ROUTE_DENSE = 1, MPLX_ROUTE_TILE = 2, MPLX_ROUT
 int mplx_set_lists_route(mplx_ctx *ctx, int route);
 /* Route taken by the last mplx_expand_lists* call (MPLX_ROUTE_*).            */
 int mplx_last_lists_route(const mplx_ctx *ctx);
+/* The service: how mplx_expand_lists (and mplx_get_succ, which calls it) serves
+ * the small synchronous batches of a search -- at most MPLX_SERVICE_MAX_NODES
+ * (256) nodes, control tables without yaw, no potential map, bounded velocity.
+ * From the second such call in a row the batch goes to a kernel that STAYS
+ * RESIDENT between the calls and takes its requests from a mailbox in pinned
+ * host memory: ~4 us per round trip instead of the ~12 us of launch +
+ * synchronise (expand_tile_kernel.hip, "SERVICE MODE").  The lists are the same
+ * bytes either way.  The resident kernel leaves on its own after
+ * MPLX_SERVICE_IDLE_US (2000) without a request and is asked to leave by every
+ * other call into the context, so no call ever sees it; while it waits it
+ * occupies a few workgroups of the device.  mode: 1 = on (the default; env
+ * MPLX_SERVICE=0 turns it off per process), 0 = off (ends a resident kernel),
+ * -1 = leave as is.  stats (may be NULL): [0] batches served by a resident
+ * kernel, [1] times one was launched, [2] times one failed to answer (the batch
+ * is then run as a launch of its own and the service stays off for the
+ * context), [3] 1 if one is resident now.                                     */
+int mplx_service(mplx_ctx *ctx, int mode, int64_t stats[4]);
 /* Fills name (up to cap bytes) with the device name and gcn arch.            */
 int mplx_device_info(mplx_ctx *ctx, char *name, size_t cap, int32_t *compute_units);
 

@@ -37,6 +37,20 @@
 // has a capacity), Dim 2/3, K = 1..4.  Everything is bit-exact; arithmetic rules
 // as in expand_kernel.hip (-ffp-contract=off, explicit fma only inside the
 // division tail).
+//
+// SERVICE MODE (template flag SVC; mplx_api.cpp, "service").  A search asks for a few nodes at a time and waits for
+// the answer: one launch + hipStreamSynchronize is 11 - 12 us before the kernel has done anything
+// (profiles/micro/mailbox_latency.hip), as much as the work itself.  In service mode the same kernel stays RESIDENT:
+// its workgroups wait for requests on a doorbell word in pinned host memory, run the tile loop on the nodes the host
+// put into the landing block, and publish `done` -- a round trip of ~4 us instead of ~12.
+//   * workgroup 0 is the coordinator: its wave 0 polls the host doorbell ((seq << 32) | n_nodes), republishes it in
+//     device memory (cmd) for the other workgroups, and decides alone when to leave (quit word, or no request for
+//     svc_idle ticks of the 100 MHz clock: a resident kernel must not outlive a host that went away);
+//   * every workgroup reports the request it finished in fin[g]; workgroup 0 waits for all of them and then stores
+//     `done` = seq with system-scope release: every list of the request is in the landing block before the host sees it;
+//   * ALL 64 lanes of wave 0 poll and publish together (same address, same value).  `if (tid == 0)` next to the
+//     barriers of the request loop is lane divergence around a convergent operation: hipcc threaded the other lanes of
+//     wave 0 into the next trip's s_barrier while lane 0 still had its store to do, and the workgroup hung.
 #include "mplx_internal.h"
 #include "mplx_device_common.h"
 
@@ -115,9 +129,12 @@ __device__ __forceinline__ void split_pair(int p, int nU, float inv_nU, int *nl,
 
 constexpr int kUB = 4;  // samples in flight per lane in phase B
 
-template <int D, int K, bool ONE>
+constexpr uint64_t kSvcExit = ~0ull;
+
+template <int D, int K, bool ONE, bool SVC>
 __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ uint64_t s_cmd;
   // The argument block is read where it lies, through the kernarg segment pointer (constant address space: scalar
   // loads), laundered once per tile so that the loads stay next to their uses -- preloaded, the block takes most of
   // the 102 SGPRs and a quarter of the kernel's VALU instructions were lane spills (see expand_grid_kernel.hip).
@@ -162,12 +179,53 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A_kerna
   }
   for (int i = tid; i < nU * udim; i += kBT) s_U[i] = A.U[i];
 
-  const int64_t n_tiles = (A.n_nodes + A.npb - 1) / A.npb;
+  const bool wave0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+  uint32_t svc_seq = SVC ? (uint32_t)A.svc_seq0 : 0u;
+  for (;;) {  // requests (service mode); one trip otherwise
+  int64_t n_nodes = A.n_nodes;
+  if (SVC) {
+    if (wave0) {
+      uint64_t v;
+      if (blockIdx.x == 0) {
+        const uint64_t t0 = wall_clock64();
+        for (;;) {
+          v = __hip_atomic_load(&A.svc_mb->doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if ((uint32_t)(v >> 32) == svc_seq + 1u) break;
+          if (__hip_atomic_load(&A.svc_mb->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u ||
+              wall_clock64() - t0 > A.svc_idle) {
+            v = kSvcExit;
+            break;
+          }
+        }
+        __hip_atomic_store(&A.svc_dev[0], v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == kSvcExit) __hip_atomic_store(&A.svc_mb->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        for (;;) {
+          v = __hip_atomic_load(&A.svc_dev[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if (v == kSvcExit || (uint32_t)(v >> 32) == svc_seq + 1u) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      s_cmd = v;
+    }
+    __syncthreads();
+    const uint64_t cmd = s_cmd;
+    __syncthreads();
+    if (cmd == kSvcExit) break;
+    svc_seq = (uint32_t)(cmd >> 32);
+    n_nodes = (int64_t)(uint32_t)cmd;
+    // the host wrote the nodes (and may have replaced the map) since the last request: nothing read before this
+    // point may be served from a cache (vector L1 / L2 by the fence; the scalar cache, which the ONE variant
+    // reads its node through, on its own)
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    __builtin_amdgcn_s_dcache_inv();
+  }
+  const int64_t n_tiles = (n_nodes + A.npb - 1) / A.npb;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
   asm volatile("" : "+s"(Ak));
   __syncthreads();  // LDS of the previous tile is free; tables visible
   const int64_t node0 = tile * A.npb;
-  const int nn = ONE ? 1 : (int)((A.n_nodes - node0) < (int64_t)A.npb ? (A.n_nodes - node0) : (int64_t)A.npb);
+  const int nn = ONE ? 1 : (int)((n_nodes - node0) < (int64_t)A.npb ? (n_nodes - node0) : (int64_t)A.npb);
   const int P = nn * nU;
 
   // ---- phase 0: node states into LDS, per-node hash, counters
@@ -459,6 +517,26 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A_kerna
   for (int nl = tid; nl < nn; nl += kBT)
     if (A.l_count) A.l_count[node0 + nl] = s_ncnt[nl];
   }  // tile loop
+  if (!SVC) break;
+  // every store of this workgroup has left for the landing block before the workgroup reports the request
+  __threadfence_system();
+  __syncthreads();
+  if (wave0) {
+    if (blockIdx.x != 0) {
+      __hip_atomic_store(&A.svc_dev[1 + blockIdx.x], (uint64_t)svc_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const int lane = tid & 63;
+      for (;;) {  // lane l watches workgroups l + 1, l + 65, ...
+        bool all = true;
+        for (unsigned g = 1 + lane; g < gridDim.x; g += 64)
+          all = all && __hip_atomic_load(&A.svc_dev[1 + g], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == (uint64_t)svc_seq;
+        if (__ballot(!all) == 0ull) break;
+      }
+      __hip_atomic_store(&A.svc_mb->done, (uint64_t)svc_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  }  // request loop
 }
 #undef A
 
@@ -478,29 +556,36 @@ __global__ void make_tables_kernel(double T, double res, double *ttab, unsigned 
   tcnt[n] = (unsigned char)k;
 }
 
-template <int D, int K, bool ONE>
+template <int D, int K, bool ONE, bool SVC>
 hipError_t launch_tile_inst(const TileArgs &a, hipStream_t stream) {
   const int64_t n_tiles = (a.n_nodes + a.npb - 1) / a.npb;
+  // service mode: a.n_nodes is the CAPACITY of a request, a.grid_limit the resident workgroups (all of them must fit
+  // on the device at once: each waits for the others)
   const int64_t blocks = n_tiles < (int64_t)a.grid_limit ? n_tiles : (int64_t)a.grid_limit;
   const size_t lds = tile_lds_bytes(a.tile_pairs, a.npb, a.wl_cap, a.n_max, 4 * D + 2, a.nU * a.udim, nullptr);
   static bool attr_set[64] = {};  // per device: see expand_grid_kernel.hip
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
   if (!attr_set[dev] || dev == 63) {
-    hipError_t e = hipFuncSetAttribute((const void *)expand_tile_kernel<D, K, ONE>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void *)expand_tile_kernel<D, K, ONE, SVC>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024 - (SVC ? 64 : 0));  // (the service form has a static command word)
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((expand_tile_kernel<D, K, ONE>), dim3((unsigned)blocks), dim3(kBT), lds, stream, a);
+  hipLaunchKernelGGL((expand_tile_kernel<D, K, ONE, SVC>), dim3((unsigned)blocks), dim3(kBT), lds, stream, a);
   return hipGetLastError();
 }
 
 template <int D, int K>
 hipError_t launch_tile_one(const TileArgs &a, hipStream_t stream) {
   if (a.n_nodes == 0) return hipSuccess;
-  if (a.npb == 1) return launch_tile_inst<D, K, true>(a, stream);
-  return launch_tile_inst<D, K, false>(a, stream);
+  if (a.svc_mb) {
+    if (a.npb == 1) return launch_tile_inst<D, K, true, true>(a, stream);
+    return launch_tile_inst<D, K, false, true>(a, stream);
+  }
+  if (a.npb == 1) return launch_tile_inst<D, K, true, false>(a, stream);
+  return launch_tile_inst<D, K, false, false>(a, stream);
 }
 
 }  // namespace

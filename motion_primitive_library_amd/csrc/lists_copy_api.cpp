@@ -233,10 +233,39 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
                         PackedLists *out) {
   if (!c || !out || !h_nodes || n_nodes <= 0 || node_stride < n_nodes) return fail(c, MPLX_ERR_ARG, "expand_lists_packed: bad arguments");
   if (int rc = ctx_ready(c)) return rc;
-  if (int rc = bind_device(c)) return rc;
   const int F = 4 * c->dim + 2;
   const int64_t S = (c->nU + 31) & ~31;  // line-aligned node stride (see expand_grid_kernel.hip)
   const int64_t n_slots = n_nodes * S;
+  {
+    // the batches of a search, from the second in a row: the resident kernel (mplx_api.cpp, "service"); the view
+    // describes the lists in its landing block
+    mplx_succ_lists want{}, v{};
+    int32_t dummy_i = 0;
+    double dummy_d = 0;
+    uint64_t dummy_h = 0;
+    want.count = &dummy_i; want.action = &dummy_i; want.cost = &dummy_d; want.hash = &dummy_h;  // (names the rows only)
+    if (want_state) want.state = &dummy_d;
+    want.node_stride = S;
+    const int streak = c->svc.streak;
+    bool handled = false;
+    if (int rc = svc_request(c, h_nodes, n_nodes, node_stride, &want, &handled, &v)) return rc;
+    if (handled) {
+      c->pk_hoffs.resize((size_t)n_nodes + 1);
+      for (int64_t k = 0; k <= n_nodes; k++) c->pk_hoffs[(size_t)k] = k * S;
+      *out = PackedLists{};
+      out->total = want_state ? v.state_stride : n_slots;  // row stride of the state rows
+      out->count = v.count;
+      out->offs = c->pk_hoffs.data();
+      out->cost = v.cost;
+      out->hash = v.hash;
+      out->action = v.action;
+      out->state = want_state ? v.state : nullptr;
+      return MPLX_OK;
+    }
+    const int counted = c->svc.streak > streak ? c->svc.streak : streak;
+    if (int rc = bind_device(c)) return rc;
+    c->svc.streak = counted;
+  }
   if (c->tune.zero_copy && (size_t)n_slots * (size_t)((want_state ? F * 8 : 0) + 24) <= ((size_t)32 << 20)) {
     // Batches of a search: the kernel reads the nodes from and writes the lists into one pinned host block itself
     // (only the used entries cross PCIe, while the kernel runs): the call is the kernel and one synchronisation.

@@ -12,6 +12,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -133,6 +135,30 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
     c->tune.prescreen_min = env_int("MPLX_GRID_PRESCREEN_MIN");
     c->tune.yaw_pin = !(getenv("MPLX_YAW_PIN") && atoi(getenv("MPLX_YAW_PIN")) == 0);
     c->tune.yaw_margin = getenv("MPLX_YAW_MARGIN") ? atof(getenv("MPLX_YAW_MARGIN")) : 0.0;
+    if (getenv("MPLX_SERVICE")) c->tune.service = env_int("MPLX_SERVICE");
+    if (env_int("MPLX_SERVICE_IDLE_US") > 0) c->tune.service_idle_us = env_int("MPLX_SERVICE_IDLE_US");
+    if (env_int("MPLX_SERVICE_MAX_NODES") > 0) c->tune.service_max_nodes = env_int("MPLX_SERVICE_MAX_NODES");
+  }
+  if (c->tune.service) {
+    // what the first resident kernel needs, now rather than inside the first search (stream, mailbox, command words and
+    // a landing block for small control tables: ~1 ms of runtime calls otherwise paid by the first plan())
+    mplx_ctx::Service &sv = c->svc;
+    e = hipStreamCreateWithFlags(&sv.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&sv.mb, sizeof(mplx::SvcMailbox), hipHostMallocCoherent);
+    if (e == hipSuccess) {
+      std::memset(sv.mb, 0, sizeof(mplx::SvcMailbox));
+      e = hipHostMalloc((void **)&sv.block, (size_t)1 << 20, hipHostMallocCoherent);
+    }
+    if (e == hipSuccess) {
+      sv.block_cap = (size_t)1 << 20;
+      e = hipMalloc(&sv.dev.p, 1025 * 8);
+    }
+    if (e == hipSuccess) sv.dev.cap = 1025 * 8;
+    if (e != hipSuccess) {
+      fail(nullptr, MPLX_ERR_HIP, "mplx_create: HIP set-up of the service failed: %s", hipGetErrorString(e));
+      mplx_destroy(c);
+      return MPLX_ERR_HIP;
+    }
   }
   *out = c;
   return MPLX_OK;
@@ -141,6 +167,11 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
 void mplx_destroy(mplx_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  (void)mplx_detail::svc_stop(c);
+  if (c->svc.stream) (void)hipStreamDestroy(c->svc.stream);
+  if (c->svc.mb) (void)hipHostFree(c->svc.mb);
+  if (c->svc.block) (void)hipHostFree(c->svc.block);
+  release(c->svc.dev);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->map, &c->pot, &c->region_bits, &c->region_bytes, &c->U, &c->s_nodes, &c->s_status,
                     &c->s_cost, &c->s_hash, &c->s_state, &c->s_iters, &c->s_count, &c->s_action, &c->tables,
@@ -234,6 +265,7 @@ int mplx_set_params(mplx_ctx *c, const mplx_params *p) {
   if (!control_ok(p->control)) return fail(c, MPLX_ERR_ARG, "mplx_set_params: unknown control flag 0x%x", p->control);
   if (!(p->dt > 0)) return fail(c, MPLX_ERR_ARG, "mplx_set_params: dt must be > 0");
   if (int rc = resolve_pending(c)) return rc;
+  if (int rc = mplx_detail::svc_stop(c)) return rc;  // a resident kernel carries the old parameters in its arguments
   c->prm = *p;
   c->has_params = true;
   return MPLX_OK;
@@ -421,7 +453,7 @@ TilePlan plan_tile(const mplx_ctx *c) {
     int uoff = 0;
     const size_t lds = mplx::tile_lds_bytes(tp, npb, tp * cnt_max, n_max, 4 * c->dim + 2, c->nU * c->udim, &uoff);
     if (lds <= 80 * 1024 || npb == 1) {   // at least two 512-thread workgroups per CU (160 KiB LDS)
-      if (lds > 160 * 1024) return t;
+      if (lds > 160 * 1024 - 64) return t;  // (- 64: the service form's static command word)
       t.ok = true;
       t.npb = npb;
       t.tile_pairs = tp;
@@ -738,6 +770,32 @@ int ensure_tables(mplx_ctx *c) {
   return MPLX_OK;
 }
 
+mplx::TileArgs tile_args(mplx_ctx *c, const TilePlan &tp, const double *d_nodes, int64_t n_nodes, int64_t node_stride,
+                         const mplx_succ_lists *o) {
+  mplx::TileArgs a{};
+  a.map = (const int8_t *)c->map.p;
+  a.region = c->has_region ? (const uint32_t *)c->region_bits.p : nullptr;
+  a.dim0 = c->mdim[0]; a.dim1 = c->mdim[1]; a.dim2 = c->mdim[2];
+  a.org0 = c->origin[0]; a.org1 = c->origin[1]; a.org2 = c->origin[2];
+  a.res = c->res;
+  a.dt = c->prm.dt; a.w = c->prm.w;
+  a.v_max = c->prm.v_max; a.a_max = c->prm.a_max; a.j_max = c->prm.j_max;
+  a.U = (const double *)c->U.p;
+  a.nU = c->nU; a.udim = c->udim;
+  a.inv_nU = 1.0f / (float)c->nU;
+  a.nodes = d_nodes; a.n_nodes = n_nodes; a.node_stride = node_stride;
+  a.npb = tp.npb; a.tile_pairs = tp.tile_pairs; a.wl_cap = tp.wl_cap; a.n_max = tp.n_max;
+  a.lds_u_offset = tp.u_offset; a.grid_limit = tp.grid;
+  a.dbg = c->tune.dbg;  // timing ablations, 0 in production
+  a.ttab = (const double *)c->tables.p;
+  a.tcnt = (const unsigned char *)c->tables.p + 64 * 64 * 8;
+  a.Rres = c->recips[0]; a.R001 = c->recips[1]; a.R01 = c->recips[2];
+  a.l_count = o->count; a.l_action = o->action; a.l_cost = o->cost; a.l_hash = o->hash;
+  a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
+  a.l_nstride = o->node_stride ? o->node_stride : c->nU;
+  return a;
+}
+
 int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride,
                  const mplx_succ_lists *o) {
   const int F = 4 * c->dim + 2;
@@ -818,27 +876,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     return fail(c, MPLX_ERR_STATE, "lists route TILE does not cover this configuration");
   if (tp.ok) {
     if (int rc = ensure_tables(c)) return rc;
-    mplx::TileArgs a{};
-    a.map = (const int8_t *)c->map.p;
-    a.region = c->has_region ? (const uint32_t *)c->region_bits.p : nullptr;
-    a.dim0 = c->mdim[0]; a.dim1 = c->mdim[1]; a.dim2 = c->mdim[2];
-    a.org0 = c->origin[0]; a.org1 = c->origin[1]; a.org2 = c->origin[2];
-    a.res = c->res;
-    a.dt = c->prm.dt; a.w = c->prm.w;
-    a.v_max = c->prm.v_max; a.a_max = c->prm.a_max; a.j_max = c->prm.j_max;
-    a.U = (const double *)c->U.p;
-    a.nU = c->nU; a.udim = c->udim;
-    a.inv_nU = 1.0f / (float)c->nU;
-    a.nodes = d_nodes; a.n_nodes = n_nodes; a.node_stride = node_stride;
-    a.npb = tp.npb; a.tile_pairs = tp.tile_pairs; a.wl_cap = tp.wl_cap; a.n_max = tp.n_max;
-    a.lds_u_offset = tp.u_offset; a.grid_limit = tp.grid;
-    a.dbg = c->tune.dbg;  // timing ablations, 0 in production
-    a.ttab = (const double *)c->tables.p;
-    a.tcnt = (const unsigned char *)c->tables.p + 64 * 64 * 8;
-    a.Rres = c->recips[0]; a.R001 = c->recips[1]; a.R01 = c->recips[2];
-    a.l_count = o->count; a.l_action = o->action; a.l_cost = o->cost; a.l_hash = o->hash;
-    a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
-    a.l_nstride = o->node_stride ? o->node_stride : c->nU;
+    const mplx::TileArgs a = tile_args(c, tp, d_nodes, n_nodes, node_stride, o);
     HIP_TRY(c, mplx::launch_expand_tile(c->dim, c->prm.control, a, c->stream));
     c->last_route = MPLX_ROUTE_TILE;
     return MPLX_OK;
@@ -952,6 +990,203 @@ int resolve_pending(mplx_ctx *c) {
   return MPLX_OK;
   MPLX_GUARD_END(c)
 }
+// ---- the service: small synchronous batches through a resident kernel (expand_tile_kernel.hip, SERVICE MODE)
+namespace {
+struct ArenaLayout {  // one block: node rows, counts, then the list rows that were asked for, all sized for n_alloc nodes
+  size_t o_count = 0, o_action = 0, o_cost = 0, o_hash = 0, o_iters = 0, o_state = 0, total = 0;
+  int64_t n_alloc = 0, n_slots = 0;
+};
+enum : unsigned { kRowAction = 1, kRowCost = 2, kRowHash = 4, kRowIters = 8, kRowState = 16 };
+
+unsigned rows_of(const mplx_succ_lists *o) {
+  return (o->action ? kRowAction : 0u) | (o->cost ? kRowCost : 0u) | (o->hash ? kRowHash : 0u) |
+         (o->iters ? kRowIters : 0u) | (o->state ? kRowState : 0u);
+}
+
+ArenaLayout arena_layout(int F, int64_t n_alloc, int64_t S, unsigned rows) {
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  ArenaLayout L;
+  L.n_alloc = n_alloc;
+  L.n_slots = n_alloc * S;
+  L.o_count = up((size_t)F * n_alloc * 8);
+  L.o_action = L.o_count + up((size_t)n_alloc * 4);
+  L.o_cost = L.o_action + ((rows & kRowAction) ? up((size_t)L.n_slots * 4) : 0);
+  L.o_hash = L.o_cost + ((rows & kRowCost) ? up((size_t)L.n_slots * 8) : 0);
+  L.o_iters = L.o_hash + ((rows & kRowHash) ? up((size_t)L.n_slots * 8) : 0);
+  L.o_state = L.o_iters + ((rows & kRowIters) ? up((size_t)L.n_slots * 4) : 0);
+  L.total = L.o_state + ((rows & kRowState) ? up((size_t)F * L.n_slots * 8) : 0);
+  return L;
+}
+
+void arena_put_nodes(char *hb, const ArenaLayout &L, int F, const double *h_nodes, int64_t n_nodes, int64_t node_stride) {
+  for (int f = 0; f < F; f++)
+    std::memcpy(hb + (size_t)f * L.n_alloc * 8, h_nodes + (size_t)f * node_stride, (size_t)n_nodes * 8);
+}
+
+mplx_succ_lists arena_lists(char *b, const ArenaLayout &L, int64_t S, unsigned rows) {
+  mplx_succ_lists d{};
+  d.count = (int32_t *)(b + L.o_count);
+  if (rows & kRowAction) d.action = (int32_t *)(b + L.o_action);
+  if (rows & kRowCost) d.cost = (double *)(b + L.o_cost);
+  if (rows & kRowHash) d.hash = (uint64_t *)(b + L.o_hash);
+  if (rows & kRowIters) d.iters = (int32_t *)(b + L.o_iters);
+  if (rows & kRowState) { d.state = (double *)(b + L.o_state); d.state_stride = L.n_slots; }
+  d.node_stride = S;
+  return d;
+}
+
+// the used prefix of every list, from the landing block into the caller's arrays
+void arena_get_lists(const char *hb, const ArenaLayout &L, int F, int64_t S, int64_t n_nodes, const mplx_succ_lists *h_out) {
+  const int32_t *cnt = (const int32_t *)(hb + L.o_count);
+  std::memcpy(h_out->count, cnt, (size_t)n_nodes * 4);
+  for (int64_t k = 0; k < n_nodes; k++) {
+    const size_t m = (size_t)cnt[k], at = (size_t)k * (size_t)S;
+    if (!m) continue;
+    if (h_out->action) std::memcpy(h_out->action + at, hb + L.o_action + at * 4, m * 4);
+    if (h_out->cost) std::memcpy(h_out->cost + at, hb + L.o_cost + at * 8, m * 8);
+    if (h_out->hash) std::memcpy(h_out->hash + at, hb + L.o_hash + at * 8, m * 8);
+    if (h_out->iters) std::memcpy(h_out->iters + at, hb + L.o_iters + at * 4, m * 4);
+    if (h_out->state)
+      for (int f = 0; f < F; f++)
+        std::memcpy(h_out->state + (size_t)f * h_out->state_stride + at,
+                    hb + L.o_state + ((size_t)f * L.n_slots + at) * 8, m * 8);
+  }
+}
+
+double mono_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// (Re)launch the resident kernel with the signature in c->svc (cap, S, rows); seq_served = the last request that
+// has been answered.  The context's own stream is drained
+// first: the resident kernel runs on a stream of its own and reads what earlier calls uploaded.
+int svc_launch(mplx_ctx *c, const TilePlan &tp, uint32_t seq_served) {
+  mplx_ctx::Service &sv = c->svc;
+  const int F = 4 * c->dim + 2;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!sv.stream) HIP_TRY(c, hipStreamCreateWithFlags(&sv.stream, hipStreamNonBlocking));
+  if (!sv.mb) {
+    HIP_TRY(c, hipHostMalloc((void **)&sv.mb, sizeof(mplx::SvcMailbox), hipHostMallocCoherent));
+    std::memset(sv.mb, 0, sizeof(mplx::SvcMailbox));
+  }
+  if (int rc = ensure_tables(c)) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const ArenaLayout L = arena_layout(F, sv.cap, sv.S, sv.rows);
+  if (L.total > sv.block_cap) {
+    if (sv.block) HIP_TRY(c, hipHostFree(sv.block));
+    sv.block = nullptr;
+    sv.block_cap = 0;
+    HIP_TRY(c, hipHostMalloc((void **)&sv.block, L.total, hipHostMallocCoherent));
+    sv.block_cap = L.total;
+  }
+  int64_t g = (sv.cap + tp.npb - 1) / tp.npb;
+  if (g > tp.grid) g = tp.grid;  // every workgroup must be resident: each waits for the others
+  if (g > 1024) g = 1024;
+  sv.workgroups = (int)g;
+  if (int rc = ensure(c, sv.dev, (size_t)(1 + g) * 8)) return rc;
+  HIP_TRY(c, hipMemsetAsync(sv.dev.p, 0, (size_t)(1 + g) * 8, sv.stream));
+  const mplx_succ_lists d = arena_lists(sv.block, L, sv.S, sv.rows);
+  mplx::TileArgs a = tile_args(c, tp, (const double *)sv.block, sv.cap, sv.cap, &d);
+  a.grid_limit = (int32_t)g;
+  a.svc_mb = sv.mb;
+  a.svc_dev = (uint64_t *)sv.dev.p;
+  a.svc_seq0 = seq_served;  // the kernel waits for the request after this one
+  a.svc_idle = (uint64_t)c->tune.service_idle_us * 100ull;  // ticks of the 100 MHz clock
+  *(volatile uint32_t *)&sv.mb->quit = 0;
+  *(volatile uint32_t *)&sv.mb->alive = 1;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  HIP_TRY(c, mplx::launch_expand_tile(c->dim, c->prm.control, a, sv.stream));
+  sv.running = true;
+  sv.launches++;
+  return MPLX_OK;
+}
+}  // namespace
+
+int svc_stop(mplx_ctx *c) {
+  mplx_ctx::Service &sv = c->svc;
+  if (!sv.running) return MPLX_OK;
+  sv.running = false;
+  *(volatile uint32_t *)&sv.mb->quit = 1;  // the coordinator polls this word between requests
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  const hipError_t e = hipStreamSynchronize(sv.stream);
+  *(volatile uint32_t *)&sv.mb->quit = 0;
+  if (e != hipSuccess) {
+    sv.disabled = true;
+    return fail(c, MPLX_ERR_HIP, "the resident expansion kernel did not leave: %s", hipGetErrorString(e));
+  }
+  return MPLX_OK;
+}
+
+// One small batch through the resident kernel.  *handled = false: not this time (not eligible, or the service gave
+// up) -- the caller runs the batch as a launch of its own.  h_out names the rows (and the list stride) wanted; the
+// used prefixes are copied into its arrays, or, with `view`, left in the landing block and described there (row stride
+// view->state_stride = capacity x list stride).
+int svc_request(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t node_stride, const mplx_succ_lists *h_out,
+                bool *handled, mplx_succ_lists *view) {
+  *handled = false;
+  mplx_ctx::Service &sv = c->svc;
+  if (!c->tune.service || sv.disabled) return MPLX_OK;
+  if (!(c->lists_route == MPLX_ROUTE_AUTO || c->lists_route == MPLX_ROUTE_TILE)) return MPLX_OK;
+  if (n_nodes > c->tune.service_max_nodes) return MPLX_OK;
+  const TilePlan tp = plan_tile(c);
+  if (!tp.ok) return MPLX_OK;
+  const int F = 4 * c->dim + 2;
+  const int64_t S = h_out->node_stride ? h_out->node_stride : c->nU;
+  const unsigned rows = rows_of(h_out);
+  if (!sv.running || S != sv.S || (rows & ~sv.rows) != 0 || n_nodes > sv.cap) {
+    if (!sv.running && ++sv.streak < 2) return MPLX_OK;  // a single call is not a search
+    if (int rc = svc_stop(c)) return rc;
+    int64_t cap = 64;
+    while (cap < n_nodes) cap <<= 1;
+    const size_t arena_max = c->tune.arena_kb > 0 ? (size_t)c->tune.arena_kb << 10 : (size_t)8 << 20;
+    while (cap > n_nodes && arena_layout(F, cap, S, rows).total > arena_max) cap >>= 1;
+    if (cap < n_nodes) cap = n_nodes;
+    if (arena_layout(F, cap, S, rows).total > arena_max) return MPLX_OK;
+    sv.cap = cap;
+    sv.S = S;
+    sv.rows = rows;
+    if (sv.seq > 0xfffffff0u) {  // (the doorbell of the last request still carries the old number)
+      sv.seq = 0;
+      if (sv.mb) *(volatile uint64_t *)&sv.mb->doorbell = 0;
+    }
+    if (int rc = svc_launch(c, tp, sv.seq)) return rc;
+  }
+  const ArenaLayout L = arena_layout(F, sv.cap, sv.S, sv.rows);
+  arena_put_nodes(sv.block, L, F, h_nodes, n_nodes, node_stride);
+  const uint32_t seq = ++sv.seq;
+  std::atomic_thread_fence(std::memory_order_release);
+  *(volatile uint64_t *)&sv.mb->doorbell = ((uint64_t)seq << 32) | (uint64_t)(uint32_t)n_nodes;
+  volatile uint64_t *done = &sv.mb->done;
+  volatile uint32_t *alive = &sv.mb->alive;
+  double t0 = 0;
+  int relaunches = 0;
+  for (uint32_t spins = 1; *done != (uint64_t)seq; spins++) {
+    __builtin_ia32_pause();
+    if ((spins & 0x3ffu) != 0) continue;
+    const double now = mono_us();
+    if (t0 == 0) t0 = now;
+    if (*alive == 0 && *done != (uint64_t)seq && relaunches < 2) {
+      // the kernel left (no request for service_idle_us) before it saw this one: the next one picks it up
+      sv.running = false;
+      relaunches++;
+      if (int rc = svc_launch(c, tp, seq - 1)) return rc;
+    } else if (now - t0 > 2e6) {
+      // no answer: give the batch to an ordinary launch and never try again in this context
+      sv.failures++;
+      (void)svc_stop(c);
+      sv.disabled = true;
+      return MPLX_OK;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  if (view) *view = arena_lists(sv.block, L, sv.S, sv.rows);  // the lists where they landed (valid until the next call)
+  else arena_get_lists(sv.block, L, F, sv.S, n_nodes, h_out);
+  sv.requests++;
+  c->last_route = MPLX_ROUTE_TILE;
+  *handled = true;
+  return MPLX_OK;
+}
+
 int ctx_ready(mplx_ctx *c) { return ready(c); }
 int lists_on_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride, const mplx_succ_lists *d) {
   return lists_device(c, d_nodes, n_nodes, node_stride, d);
@@ -982,7 +1217,6 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
     return fail(c, MPLX_ERR_ARG, "mplx_expand_lists: bad arguments");
   if (int rc = ready(c)) return rc;
   if (n_nodes == 0) return MPLX_OK;
-  if (int rc = bind_device(c)) return rc;
   const int F = 4 * c->dim + 2;
   if (h_out->node_stride != 0 && h_out->node_stride < c->nU)
     return fail(c, MPLX_ERR_ARG, "mplx_expand_lists: node_stride %lld < nU %d", (long long)h_out->node_stride, c->nU);
@@ -990,20 +1224,27 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
   if (h_out->state && h_out->state_stride < n_slots)
     return fail(c, MPLX_ERR_ARG, "mplx_expand_lists: state_stride < n_nodes*node_stride");
   {
+    // The batches of a search (a few nodes, the answer awaited before the next one is known) go through a kernel
+    // that stays resident between them, from the second such call in a row: a mailbox round trip instead of launch +
+    // synchronise (see expand_tile_kernel.hip, SERVICE MODE).  Any other call into the context ends it (bind_device).
+    const int streak = c->svc.streak;
+    bool handled = false;
+    if (int rc = mplx_detail::svc_request(c, h_nodes, n_nodes, node_stride, h_out, &handled, nullptr)) return rc;
+    if (handled) return MPLX_OK;
+    const int counted = c->svc.streak > streak ? c->svc.streak : streak;
+    if (int rc = bind_device(c)) return rc;
+    c->svc.streak = counted;
+  }
+  {
     // Small batches (one get_succ, or the speculative batches of a search) are latency bound: nodes and every
     // output row live in ONE pinned host block that the kernel reads and writes itself over PCIe (only the used
     // list entries cross the link, while the kernel runs), so a call is the kernel and one synchronisation; the
     // used prefixes are then copied into the caller's arrays.  (A 2D 9-control get_succ: 25 us; with one pageable
     // copy per row 111 us, with one upload + one download through a device arena 28 us -- MPLX_ZERO_COPY=0.)
-    const size_t S = (size_t)(h_out->node_stride ? h_out->node_stride : c->nU);
-    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_count = up((size_t)F * n_nodes * 8);
-    const size_t o_action = o_count + up((size_t)n_nodes * 4);
-    const size_t o_cost = o_action + (h_out->action ? up((size_t)n_slots * 4) : 0);
-    const size_t o_hash = o_cost + (h_out->cost ? up((size_t)n_slots * 8) : 0);
-    const size_t o_iters = o_hash + (h_out->hash ? up((size_t)n_slots * 8) : 0);
-    const size_t o_state = o_iters + (h_out->iters ? up((size_t)n_slots * 4) : 0);
-    const size_t total = o_state + (h_out->state ? up((size_t)F * n_slots * 8) : 0);
+    const int64_t S = h_out->node_stride ? h_out->node_stride : c->nU;
+    const unsigned rows = mplx_detail::rows_of(h_out);
+    const mplx_detail::ArenaLayout L = mplx_detail::arena_layout(F, n_nodes, S, rows);
+    const size_t total = L.total, o_count = L.o_count;
     const size_t arena_max = c->tune.arena_kb > 0 ? (size_t)c->tune.arena_kb << 10 : (size_t)8 << 20;
     if (total <= arena_max) {
       if (int rc = ensure(c, c->s_arena, total)) return rc;
@@ -1015,19 +1256,11 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
         c->h_arena_cap = arena_max;
       }
       char *hb = (char *)c->h_arena, *db = (char *)c->s_arena.p;
-      for (int f = 0; f < F; f++)
-        std::memcpy(hb + (size_t)f * n_nodes * 8, h_nodes + (size_t)f * node_stride, (size_t)n_nodes * 8);
+      mplx_detail::arena_put_nodes(hb, L, F, h_nodes, n_nodes, node_stride);
       const bool zero_copy = c->tune.zero_copy != 0;
       if (zero_copy) db = hb;  // the kernel reads the nodes from and writes the lists to the pinned host block itself
       else HIP_TRY(c, hipMemcpyAsync(db, hb, (size_t)F * n_nodes * 8, hipMemcpyHostToDevice, c->stream));
-      mplx_succ_lists d{};
-      d.count = (int32_t *)(db + o_count);
-      if (h_out->action) d.action = (int32_t *)(db + o_action);
-      if (h_out->cost) d.cost = (double *)(db + o_cost);
-      if (h_out->hash) d.hash = (uint64_t *)(db + o_hash);
-      if (h_out->iters) d.iters = (int32_t *)(db + o_iters);
-      if (h_out->state) { d.state = (double *)(db + o_state); d.state_stride = n_slots; }
-      d.node_stride = h_out->node_stride;
+      const mplx_succ_lists d = mplx_detail::arena_lists(db, L, h_out->node_stride, rows);
       if (int rc = lists_device(c, (const double *)db, n_nodes, n_nodes, &d)) return rc;
       if (!zero_copy)
         HIP_TRY(c, hipMemcpyAsync(hb + o_count, db + o_count, total - o_count, hipMemcpyDeviceToHost, c->stream));
@@ -1039,20 +1272,7 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
           HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
       }
-      const int32_t *cnt = (const int32_t *)(hb + o_count);
-      std::memcpy(h_out->count, cnt, (size_t)n_nodes * 4);
-      for (int64_t k = 0; k < n_nodes; k++) {
-        const size_t m = (size_t)cnt[k], at = (size_t)k * S;
-        if (!m) continue;
-        if (h_out->action) std::memcpy(h_out->action + at, hb + o_action + at * 4, m * 4);
-        if (h_out->cost) std::memcpy(h_out->cost + at, hb + o_cost + at * 8, m * 8);
-        if (h_out->hash) std::memcpy(h_out->hash + at, hb + o_hash + at * 8, m * 8);
-        if (h_out->iters) std::memcpy(h_out->iters + at, hb + o_iters + at * 4, m * 4);
-        if (h_out->state)
-          for (int f = 0; f < F; f++)
-            std::memcpy(h_out->state + (size_t)f * h_out->state_stride + at,
-                        hb + o_state + ((size_t)f * n_slots + at) * 8, m * 8);
-      }
+      mplx_detail::arena_get_lists(hb, L, F, S, n_nodes, h_out);
       return MPLX_OK;
     }
   }
@@ -1206,6 +1426,25 @@ int mplx_set_lists_route(mplx_ctx *c, int route) {
 }
 
 int mplx_last_lists_route(const mplx_ctx *c) { return c ? c->last_route : MPLX_ERR_ARG; }
+
+int mplx_service(mplx_ctx *c, int mode, int64_t stats[4]) {
+  if (!c) return MPLX_ERR_ARG;
+  if (mode < -1 || mode > 1) return fail(c, MPLX_ERR_ARG, "mplx_service: mode must be -1, 0 or 1");
+  if (mode >= 0) {
+    c->tune.service = mode;
+    c->svc.streak = 0;
+    if (mode == 0) {
+      if (int rc = mplx_detail::svc_stop(c)) return rc;
+    }
+  }
+  if (stats) {
+    stats[0] = c->svc.requests;
+    stats[1] = c->svc.launches;
+    stats[2] = c->svc.failures;
+    stats[3] = c->svc.running ? 1 : 0;
+  }
+  return MPLX_OK;
+}
 
 int mplx_yaw_pin_stats(const mplx_ctx *c, int64_t *flagged_nodes, int64_t *fix_passes) {
   if (!c) return MPLX_ERR_ARG;

@@ -68,6 +68,9 @@ struct mplx_ctx {
     int prescreen_min = 0;     // MPLX_GRID_PRESCREEN_MIN: smallest frontier that gets the lane-per-node pre-screen (0 = automatic, -1 = never)
     bool yaw_pin = true;       // MPLX_YAW_PIN=0: raw device trig decisions (to measure what the pinning is for)
     double yaw_margin = 0;     // MPLX_YAW_MARGIN: detection band (tests widen it to drive many nodes through the fix pass)
+    int service = 1;           // MPLX_SERVICE=0: every small batch is its own launch (mplx_service)
+    int service_idle_us = 2000;   // MPLX_SERVICE_IDLE_US: the resident kernel leaves after this long without a request
+    int service_max_nodes = 256;  // MPLX_SERVICE_MAX_NODES: larger batches are launches of their own
   } tune;
   int lists_route = MPLX_ROUTE_AUTO;
   int last_route = MPLX_ROUTE_AUTO;
@@ -86,6 +89,23 @@ struct mplx_ctx {
   mplx_detail::DevBuf s_arena;
   void *h_arena = nullptr;
   size_t h_arena_cap = 0;
+  // Resident form of the tiled kernel for the small synchronous batches of a search ("service", mplx_api.cpp and
+  // expand_tile_kernel.hip): requests go through a mailbox in pinned memory instead of launch + synchronise.
+  struct Service {
+    bool running = false;   // a resident kernel has been launched and has not been seen to leave
+    bool disabled = false;  // it failed to answer once: never again in this context
+    int streak = 0;         // eligible batches since the last other API call (the second one starts the service)
+    hipStream_t stream = nullptr;
+    mplx::SvcMailbox *mb = nullptr;  // pinned
+    char *block = nullptr;           // pinned landing block: node rows, then the list rows, sized for `cap` nodes
+    size_t block_cap = 0;
+    mplx_detail::DevBuf dev;         // command word + one word per workgroup
+    uint32_t seq = 0;
+    int64_t cap = 0, S = 0;          // signature of the resident kernel: capacity in nodes, list stride,
+    unsigned rows = 0;               // ... and which list rows it writes (bit 0 action, 1 cost, 2 hash, 3 iters, 4 state)
+    int workgroups = 0;
+    int64_t requests = 0, launches = 0, failures = 0;  // statistics (mplx_service)
+  } svc;
   // pipelined copy back of the lists (lists_copy_api.cpp): packed chunks on the device, pinned landing buffers
   mplx_detail::DevBuf pk_dev[2], pk_offs;
   void *pk_pin[2] = {nullptr, nullptr};
@@ -150,8 +170,17 @@ inline int fail(mplx_ctx *c, int code, const char *fmt, ...) {
   catch (const std::exception &e) { return mplx_detail::fail((c), MPLX_ERR_NOMEM, "unexpected exception: %s", e.what()); } \
   catch (...) { return mplx_detail::fail((c), MPLX_ERR_NOMEM, "unexpected exception"); }
 
+int svc_stop(mplx_ctx *c);  // mplx_api.cpp
+int svc_request(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t node_stride, const mplx_succ_lists *h_out,
+                bool *handled, mplx_succ_lists *view);
+
+// Every entry point that touches the device comes through here first.  A resident service kernel reads the
+// context's tables through the arguments it was launched with and writes into the context's landing block: it is
+// asked to leave before anything else happens (only the small-batch path of mplx_expand_lists talks to it instead).
 inline int bind_device(mplx_ctx *c) {
   HIP_TRY(c, hipSetDevice(c->device));
+  c->svc.streak = 0;
+  if (c->svc.running) return svc_stop(c);
   return MPLX_OK;
 }
 

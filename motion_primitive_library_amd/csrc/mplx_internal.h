@@ -65,6 +65,18 @@ struct ExpandArgs {
 };
 
 // Arguments of the tiled, list-producing kernel (expand_tile_kernel.hip).
+// Mailbox of the resident (service) form of the tiled kernel, in pinned host memory; every word on its own line.
+struct SvcMailbox {
+  uint64_t doorbell;  // host -> device: (seq << 32) | n_nodes of the request in the landing block
+  uint64_t pad0[7];
+  uint64_t done;      // device -> host: seq of the last request whose lists are complete in the landing block
+  uint64_t pad1[7];
+  uint32_t quit;      // host -> device: leave now
+  uint32_t pad2[15];
+  uint32_t alive;     // device -> host: 0 once the coordinator has decided to leave (the stream then drains)
+  uint32_t pad3[15];
+};
+
 struct TileArgs {
   const int8_t *map;
   const uint32_t *region;
@@ -100,6 +112,11 @@ struct TileArgs {
   int32_t *l_iters;
   int64_t l_nstride;  // entries reserved per node (>= nU)
   int32_t l_pad;      // 1: complete the last 128-byte line of every list row (node stride is a multiple of 32)
+  // service mode (expand_tile_kernel.hip): null / 0 for an ordinary launch
+  SvcMailbox *svc_mb;   // pinned host memory
+  uint64_t *svc_dev;    // device memory, zeroed before the launch: [0] = command, [1 + g] = last request workgroup g finished
+  uint64_t svc_seq0;    // seq of the last request served before this launch
+  uint64_t svc_idle;    // ticks of the 100 MHz clock without a request after which the kernel leaves
 };
 
 size_t tile_lds_bytes(int tile_pairs, int npb, int wl_cap, int n_max, int n_fields, int u_doubles,

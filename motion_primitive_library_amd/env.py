@@ -709,6 +709,13 @@ class EnvMap:
         _abi.check(self._ctx, _abi.lib().mplx_yaw_pin_stats(self._ctx, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def service(self, mode=-1):
+        """The resident kernel behind small synchronous batches (include/mplx.h, mplx_service): mode 1 on, 0 off,
+        -1 unchanged; returns dict(requests, launches, failures, resident)."""
+        st = (C.c_int64 * 4)()
+        _abi.check(self._ctx, _abi.lib().mplx_service(self._ctx, int(mode), st))
+        return {"requests": st[0], "launches": st[1], "failures": st[2], "resident": bool(st[3])}
+
     def selftest_math(self, op, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float64)
         b = a if b is None else np.ascontiguousarray(b, dtype=np.float64)
