@@ -203,8 +203,18 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A_kerna
         for (;;) {
           v = __hip_atomic_load(&A.svc_dev[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
           if (v == kSvcExit || (uint32_t)(v >> 32) == svc_seq + 1u) break;
-          __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_s_sleep(2);
         }
+      }
+      // the host wrote the nodes (and may have replaced the map) since the last request: nothing read after this
+      // point may be served from a cache (vector L1 of this CU and L2 by the fence; the scalar cache, which the ONE
+      // variant reads its node through, on its own).  Once per workgroup, before the barrier that lets the other waves
+      // go on: per wave it was 8 x 64 L2 invalidations a request.
+      // A workgroup without a tile in this request reads and writes nothing: no fences (each one empties or writes
+      // back the L2 under the workgroups that are at work).
+      if (v != kSvcExit && (int64_t)blockIdx.x * A.npb < (int64_t)(uint32_t)v) {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        __builtin_amdgcn_s_dcache_inv();
       }
       s_cmd = v;
     }
@@ -214,11 +224,6 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A_kerna
     if (cmd == kSvcExit) break;
     svc_seq = (uint32_t)(cmd >> 32);
     n_nodes = (int64_t)(uint32_t)cmd;
-    // the host wrote the nodes (and may have replaced the map) since the last request: nothing read before this
-    // point may be served from a cache (vector L1 / L2 by the fence; the scalar cache, which the ONE variant
-    // reads its node through, on its own)
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    __builtin_amdgcn_s_dcache_inv();
   }
   const int64_t n_tiles = (n_nodes + A.npb - 1) / A.npb;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -518,10 +523,12 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A_kerna
     if (A.l_count) A.l_count[node0 + nl] = s_ncnt[nl];
   }  // tile loop
   if (!SVC) break;
-  // every store of this workgroup has left for the landing block before the workgroup reports the request
-  __threadfence_system();
+  // Every store of this workgroup has been acknowledged (the barrier's workgroup-scope release waits for each wave's
+  // outstanding stores) before wave 0 writes back what the L2 still holds and reports the request.  (A system-scope
+  // fence in every wave was 8 x 64 L2 write-backs a request: + 7 us on a one-node request of the 729-control table.)
   __syncthreads();
   if (wave0) {
+    if ((int64_t)blockIdx.x * A.npb < n_nodes) __threadfence_system();
     if (blockIdx.x != 0) {
       __hip_atomic_store(&A.svc_dev[1 + blockIdx.x], (uint64_t)svc_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     } else {
