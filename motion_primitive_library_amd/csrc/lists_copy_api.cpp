@@ -246,7 +246,6 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
     want.count = &dummy_i; want.action = &dummy_i; want.cost = &dummy_d; want.hash = &dummy_h;  // (names the rows only)
     if (want_state) want.state = &dummy_d;
     want.node_stride = S;
-    const int streak = c->svc.streak;
     bool handled = false;
     if (int rc = svc_request(c, h_nodes, n_nodes, node_stride, &want, &handled, &v)) return rc;
     if (handled) {
@@ -262,7 +261,7 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
       out->state = want_state ? v.state : nullptr;
       return MPLX_OK;
     }
-    const int counted = c->svc.streak > streak ? c->svc.streak : streak;
+    const int counted = c->svc.streak;  // (what svc_request made of it; bind_device resets it)
     if (int rc = bind_device(c)) return rc;
     c->svc.streak = counted;
   }

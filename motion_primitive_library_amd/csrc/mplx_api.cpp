@@ -1126,10 +1126,11 @@ int svc_request(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t nod
   *handled = false;
   mplx_ctx::Service &sv = c->svc;
   if (!c->tune.service || sv.disabled) return MPLX_OK;
-  if (!(c->lists_route == MPLX_ROUTE_AUTO || c->lists_route == MPLX_ROUTE_TILE)) return MPLX_OK;
-  if (n_nodes > c->tune.service_max_nodes) return MPLX_OK;
-  const TilePlan tp = plan_tile(c);
-  if (!tp.ok) return MPLX_OK;
+  const TilePlan tp = (c->lists_route == MPLX_ROUTE_AUTO || c->lists_route == MPLX_ROUTE_TILE) ? plan_tile(c) : TilePlan();
+  if (!tp.ok || n_nodes > c->tune.service_max_nodes) {  // not a search's batch: the row of such batches ends here
+    sv.streak = 0;
+    return MPLX_OK;
+  }
   const int F = 4 * c->dim + 2;
   const int64_t S = h_out->node_stride ? h_out->node_stride : c->nU;
   const unsigned rows = rows_of(h_out);
@@ -1227,11 +1228,10 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
     // The batches of a search (a few nodes, the answer awaited before the next one is known) go through a kernel
     // that stays resident between them, from the second such call in a row: a mailbox round trip instead of launch +
     // synchronise (see expand_tile_kernel.hip, SERVICE MODE).  Any other call into the context ends it (bind_device).
-    const int streak = c->svc.streak;
     bool handled = false;
     if (int rc = mplx_detail::svc_request(c, h_nodes, n_nodes, node_stride, h_out, &handled, nullptr)) return rc;
     if (handled) return MPLX_OK;
-    const int counted = c->svc.streak > streak ? c->svc.streak : streak;
+    const int counted = c->svc.streak;  // (what svc_request made of it; bind_device resets it)
     if (int rc = bind_device(c)) return rc;
     c->svc.streak = counted;
   }
@@ -1422,6 +1422,7 @@ int mplx_set_lists_route(mplx_ctx *c, int route) {
   if (!c) return MPLX_ERR_ARG;
   if (route < MPLX_ROUTE_AUTO || route > MPLX_ROUTE_GRID) return fail(c, MPLX_ERR_ARG, "mplx_set_lists_route: unknown route %d", route);
   c->lists_route = route;
+  c->svc.streak = 0;
   return MPLX_OK;
 }
 
