@@ -4,6 +4,8 @@
 // The kernel in (b) leaves after `idle_us` without a request (watchdog) and on a quit word.
 #include <hip/hip_runtime.h>
 
+#include <immintrin.h>
+
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -19,7 +21,7 @@ __global__ void empty_kernel(uint64_t *out, const uint64_t *in) { if (in) out[th
 // All 64 lanes of wave 0 poll / publish together (same address, same value): a single lane doing it (if (threadIdx.x
 // == 0) ...) next to the barriers of a loop is lane divergence around a convergent operation -- hipcc threaded lanes
 // 1..63 of wave 0 into the next trip's s_barrier while lane 0 still had its store to do, and the workgroup hung.
-__global__ void service_kernel(Mailbox *mb, uint64_t seq0, uint64_t idle_ticks) {
+__global__ void service_kernel(Mailbox *mb, uint64_t seq0, uint64_t idle_ticks, uint64_t *bell, uint64_t *payload) {
   uint64_t seq = seq0;
   __shared__ uint64_t s_cmd;
   const bool wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
@@ -28,7 +30,7 @@ __global__ void service_kernel(Mailbox *mb, uint64_t seq0, uint64_t idle_ticks) 
       const uint64_t t0 = wall_clock64();
       uint64_t v;
       for (;;) {
-        v = __hip_atomic_load(&mb->doorbell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        v = __hip_atomic_load(bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (v == seq + 1) break;
         if (__hip_atomic_load(&mb->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || wall_clock64() - t0 > idle_ticks) { v = ~0ull; break; }
       }
@@ -40,7 +42,7 @@ __global__ void service_kernel(Mailbox *mb, uint64_t seq0, uint64_t idle_ticks) 
     if (cmd == ~0ull) break;
     seq = cmd;
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    if (threadIdx.x < 64) mb->payload[threadIdx.x] += 1;  // read + write of host memory: the "work"
+    if (threadIdx.x < 64) mb->payload[threadIdx.x] = payload[threadIdx.x] + 1;  // read the request, write the answer
     __threadfence_system();
     __syncthreads();
     if (wave0) __hip_atomic_store(&mb->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -77,14 +79,14 @@ int main() {
   {  // watchdog alone
     mb->quit = 0; mb->alive = 1;
     const double t0 = now_us();
-    hipLaunchKernelGGL(service_kernel, dim3(1), dim3(256), 0, s, mb, 0ull, hz / 1000 * 5);  // 5 ms
+    hipLaunchKernelGGL(service_kernel, dim3(1), dim3(256), 0, s, mb, 0ull, hz / 1000 * 5, &mb->doorbell, mb->payload);  // 5 ms
     CK(hipStreamSynchronize(s));
     printf("watchdog exit after %.1f ms idle, alive %u\n", (now_us() - t0) / 1e3, mb->alive);
   }
   {  // quit word alone
     mb->quit = 0; mb->alive = 1;
     const double t0 = now_us();
-    hipLaunchKernelGGL(service_kernel, dim3(1), dim3(256), 0, s, mb, 0ull, hz * 3);  // 3 s
+    hipLaunchKernelGGL(service_kernel, dim3(1), dim3(256), 0, s, mb, 0ull, hz * 3, &mb->doorbell, mb->payload);  // 3 s
     while (now_us() - t0 < 2000.0) {}
     *(volatile uint32_t *)&mb->quit = 1;
     CK(hipStreamSynchronize(s));
@@ -93,7 +95,7 @@ int main() {
   }
   // (b) resident kernel
   mb->alive = 1;
-  hipLaunchKernelGGL(service_kernel, dim3(1), dim3(256), 0, s, mb, 0ull, hz / 1000 * 500);  // 0.5 s idle watchdog
+  hipLaunchKernelGGL(service_kernel, dim3(1), dim3(256), 0, s, mb, 0ull, hz / 1000 * 500, &mb->doorbell, mb->payload);  // 0.5 s idle watchdog
   CK(hipGetLastError());
   volatile uint64_t *done = &mb->done;
   uint64_t seq = 0;
@@ -114,10 +116,45 @@ int main() {
   *(volatile uint32_t *)&mb->quit = 1;
   CK(hipStreamSynchronize(s));
   printf("alive after quit: %u\n", mb->alive);
+  {  // (c) doorbell and request payload in DEVICE memory that the host writes directly (fine-grained, large BAR)
+    uint64_t *dreq = nullptr;
+    hipError_t e = hipExtMallocWithFlags((void **)&dreq, 4096, hipDeviceMallocFinegrained);
+    printf("hipExtMallocWithFlags(fine-grained): %s\n", hipGetErrorString(e));
+    if (e == hipSuccess) {
+      CK(hipMemset(dreq, 0, 4096));
+      CK(hipDeviceSynchronize());
+      mb->quit = 0; mb->alive = 1; mb->done = 0;
+      hipLaunchKernelGGL(service_kernel, dim3(1), dim3(256), 0, s, mb, 0ull, hz / 1000 * 500, dreq, dreq + 8);
+      CK(hipGetLastError());
+      volatile uint64_t *bell = dreq;
+      uint64_t q = 0;
+      for (int rep = 0; rep < 2; rep++) {
+        const double t0 = now_us();
+        for (int i = 0; i < N; i++) {
+          q++;
+          for (int k = 0; k < 16; k++) ((volatile uint64_t *)dreq)[8 + k] = q + k;  // the request
+          std::atomic_thread_fence(std::memory_order_release);
+          _mm_sfence();  // device memory is mapped write-combining: the request must leave the WC buffers before the bell
+          *bell = q;
+          _mm_sfence();
+          const double w0 = now_us();
+          while (*done != q) {
+            if (now_us() - w0 > 2e6) { fprintf(stderr, "(c) no answer at %llu\n", (unsigned long long)q); *(volatile uint32_t *)&mb->quit = 1; (void)hipStreamSynchronize(s); return 2; }
+          }
+          std::atomic_thread_fence(std::memory_order_acquire);
+          if (mb->payload[3] != q + 3 + 1) { fprintf(stderr, "(c) wrong payload %llu at %llu\n", (unsigned long long)mb->payload[3], (unsigned long long)q); *(volatile uint32_t *)&mb->quit = 1; (void)hipStreamSynchronize(s); return 3; }
+        }
+        if (rep) printf("resident kernel, doorbell in device memory:    %.2f us\n", (now_us() - t0) / N);
+      }
+      *(volatile uint32_t *)&mb->quit = 1;
+      CK(hipStreamSynchronize(s));
+      mb->quit = 0;
+    }
+  }
   // watchdog: start again, post nothing
   mb->quit = 0; mb->alive = 1;
   const double t0 = now_us();
-  hipLaunchKernelGGL(service_kernel, dim3(1), dim3(256), 0, s, mb, seq, hz / 1000 * 5);  // 5 ms
+  hipLaunchKernelGGL(service_kernel, dim3(1), dim3(256), 0, s, mb, seq, hz / 1000 * 5, &mb->doorbell, mb->payload);  // 5 ms
   CK(hipStreamSynchronize(s));
   printf("watchdog exit after %.1f ms idle, alive %u\n", (now_us() - t0) / 1e3, mb->alive);
   return 0;
