@@ -1127,7 +1127,11 @@ int svc_request(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t nod
   mplx_ctx::Service &sv = c->svc;
   if (!c->tune.service || sv.disabled) return MPLX_OK;
   const TilePlan tp = (c->lists_route == MPLX_ROUTE_AUTO || c->lists_route == MPLX_ROUTE_TILE) ? plan_tile(c) : TilePlan();
-  if (!tp.ok || n_nodes > c->tune.service_max_nodes) {  // not a search's batch: the row of such batches ends here
+  // (more than 64 workgroups in the handshake cost more than they save: 256 nodes of the 729-control table, a
+  // workgroup each, 88 us per request against 65 us as a launch; 64 nodes 30 against 41)
+  constexpr int64_t kMaxWorkgroups = 64;
+  if (!tp.ok || n_nodes > c->tune.service_max_nodes || (n_nodes + tp.npb - 1) / tp.npb > kMaxWorkgroups) {
+    // not a search's batch: the row of such batches ends here
     sv.streak = 0;
     return MPLX_OK;
   }
@@ -1140,7 +1144,7 @@ int svc_request(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t nod
     int64_t cap = 64;
     while (cap < n_nodes) cap <<= 1;
     const size_t arena_max = c->tune.arena_kb > 0 ? (size_t)c->tune.arena_kb << 10 : (size_t)8 << 20;
-    while (cap > n_nodes && arena_layout(F, cap, S, rows).total > arena_max) cap >>= 1;
+    while (cap > n_nodes && (arena_layout(F, cap, S, rows).total > arena_max || (cap + tp.npb - 1) / tp.npb > kMaxWorkgroups)) cap >>= 1;
     if (cap < n_nodes) cap = n_nodes;
     if (arena_layout(F, cap, S, rows).total > arena_max) return MPLX_OK;
     sv.cap = cap;
