@@ -257,3 +257,37 @@ def test_two_contexts_resident_at_once(engine):
     assert ea.service()["resident"] and eb.service()["resident"]
     for e in (ea, eb, ra, rb):
         e.close()
+
+
+@pytest.mark.parametrize("which", ["2d_9_controls", "3d_125_controls"])
+def test_soak_every_request_is_complete_when_done_is_seen(engine, which):
+    """Thousands of requests back to back, each compared with a launch of the same batch: a list entry that reached
+    the landing block after `done` did (a store overtaking the release) would show up as a stale or torn entry."""
+    if which == "2d_9_controls":
+        wl = _small_world(engine, 2, 0x03, seed=7900, n_nodes=500)
+        wl.U = engine.workloads.grid_controls([-1.0, 0.0, 1.0], 2)
+        rounds = 2500
+    else:
+        wl = _small_world(engine, 3, 0x03, seed=7901, n_nodes=500)
+        wl.U = engine.workloads.grid_controls([-1.0, -0.5, 0.0, 0.5, 1.0], 3)
+        rounds = 1200
+    env = engine_env(engine, wl)
+    ref = engine_env(engine, wl)
+    ref.service(0)
+    rng = np.random.default_rng(17)
+    out_a = out_b = None
+    n_prev = -1
+    for _ in range(rounds):
+        n = int(rng.integers(1, 65))
+        b = np.ascontiguousarray(wl.nodes[:, rng.integers(0, wl.n_nodes, size=n)])
+        if n != n_prev:
+            out_a = out_b = None
+            n_prev = n
+        out_a = env.expand_lists(b, out=out_a)
+        out_b = ref.expand_lists(b, out=out_b)
+        _same(out_a, out_b, n)
+    st = env.service()
+    assert st["failures"] == 0 and st["requests"] == rounds - 1
+    env.close()
+    ref.close()
+
