@@ -25,8 +25,8 @@
 // bound, so here a wave never waits for another wave: all phases are
 // wave-synchronous (LDS is in-order per wave) and a workgroup is only a
 // container for kWPB independent waves; (2) the wave-per-node version was VALU
-// ISSUE bound (a wave64 VALU instruction occupies the SIMD for 4 cycles whatever
-// it computes) with ~60 instructions per map sample, most of them address
+// ISSUE bound (a wave64 VALU instruction of the kinds this kernel is made of occupies
+// the SIMD for 4 cycles: profiles/r03_valu_issue_rates.txt) with ~60 instructions per map sample, most of them address
 // arithmetic of the global look-up, so here the occupancy bits of the node's
 // reachable box are staged into LDS once per node and a sample is 3 byte
 // look-ups + 1 word look-up; (3) the list stores (2.7 GB per launch on C4) are
