@@ -1237,6 +1237,18 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
     }
   }
   PT_FLUSH;
+  if (A.done.flag != nullptr) {
+    // small synchronous batch: the host spins on a pinned word instead of synchronising the stream.  Every wave's
+    // stores are out (and written back) before it counts itself; the last one resets the counter and signals.
+    __threadfence_system();
+    if (lane == 0) {
+      const unsigned int waves = gridDim.x * (unsigned int)kWPB;
+      if (__hip_atomic_fetch_add(A.done.count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == waves - 1u) {
+        __hip_atomic_store(A.done.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.done.flag, A.done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 #undef A
 }
 

@@ -544,6 +544,16 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A_kerna
   }
   __syncthreads();
   }  // request loop
+  if (!SVC && A.done.flag != nullptr) {  // see DoneSignal (mplx_internal.h); no barrier follows: one lane may act alone
+    __syncthreads();  // every wave's stores have been acknowledged
+    if (tid == 0) {
+      __threadfence_system();
+      if (__hip_atomic_fetch_add(A.done.count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+        __hip_atomic_store(A.done.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.done.flag, A.done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 #undef A
 

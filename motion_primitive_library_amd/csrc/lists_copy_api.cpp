@@ -294,9 +294,12 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
     d.hash = (uint64_t *)(hb + o_hash);
     if (want_state) { d.state = (double *)(hb + o_state); d.state_stride = n_slots; }
     d.node_stride = S;
-    if (int rc = lists_on_device(c, (const double *)hb, n_nodes, n_nodes, &d)) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (int rc = resolve_pending(c)) return rc;  // yaw pinning: lists final before the search reads them
+    c->want_done = true;  // the kernel tells the host itself when the lists are in the block (DoneSignal)
+    const int rc_launch = lists_on_device(c, (const double *)hb, n_nodes, n_nodes, &d);
+    c->want_done = false;
+    if (rc_launch) return rc_launch;
+    if (int rc = wait_small_launch(c)) return rc;
+    if (int rc = resolve_pending(c, true)) return rc;  // yaw pinning: lists final before the search reads them
     int64_t *offs = (int64_t *)(hb + o_off);
     for (int64_t k = 0; k <= n_nodes; k++) offs[k] = k * S;
     *out = PackedLists{};

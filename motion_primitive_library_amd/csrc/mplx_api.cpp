@@ -34,6 +34,10 @@ int yaw_slot(mplx_ctx *c, mplx::YawPin *y);  // yaw pinning, defined with the li
 int grid_work(mplx_ctx *c, mplx::GridArgs *a);
 int launch_grid(mplx_ctx *c, mplx::GridArgs *a);
 
+double mono_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 bool control_ok(int32_t control) {
   switch (control) {
     case MPLX_VEL: case MPLX_ACC: case MPLX_JRK: case MPLX_SNP:
@@ -136,8 +140,19 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
     c->tune.yaw_pin = !(getenv("MPLX_YAW_PIN") && atoi(getenv("MPLX_YAW_PIN")) == 0);
     c->tune.yaw_margin = getenv("MPLX_YAW_MARGIN") ? atof(getenv("MPLX_YAW_MARGIN")) : 0.0;
     if (getenv("MPLX_SERVICE")) c->tune.service = env_int("MPLX_SERVICE");
+    if (getenv("MPLX_DONE_FLAG")) c->tune.done_flag = env_int("MPLX_DONE_FLAG");
     if (env_int("MPLX_SERVICE_IDLE_US") > 0) c->tune.service_idle_us = env_int("MPLX_SERVICE_IDLE_US");
     if (env_int("MPLX_SERVICE_MAX_NODES") > 0) c->tune.service_max_nodes = env_int("MPLX_SERVICE_MAX_NODES");
+  }
+  if (c->tune.done_flag) {
+    e = hipHostMalloc((void **)&c->done_host, 64, hipHostMallocCoherent);
+    if (e == hipSuccess) { *c->done_host = 0; e = hipMalloc(&c->done_count.p, 64); }
+    if (e == hipSuccess) { c->done_count.cap = 64; e = hipMemset(c->done_count.p, 0, 64); }
+    if (e != hipSuccess) {
+      fail(nullptr, MPLX_ERR_HIP, "mplx_create: HIP set-up of the completion word failed: %s", hipGetErrorString(e));
+      mplx_destroy(c);
+      return MPLX_ERR_HIP;
+    }
   }
   if (c->tune.service) {
     // what the first resident kernel needs, now rather than inside the first search (stream, mailbox, command words and
@@ -173,6 +188,8 @@ void mplx_destroy(mplx_ctx *c) {
   if (c->svc.block) (void)hipHostFree(c->svc.block);
   release(c->svc.dev);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->done_host) (void)hipHostFree(c->done_host);
+  release(c->done_count);
   for (DevBuf *b : {&c->map, &c->pot, &c->region_bits, &c->region_bytes, &c->U, &c->s_nodes, &c->s_status,
                     &c->s_cost, &c->s_hash, &c->s_state, &c->s_iters, &c->s_count, &c->s_action, &c->tables,
                     &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx, &c->blk, &c->sat, &c->prep_lut, &c->prep_a, &c->prep_b, &c->post_keys, &c->post_ws, &c->live_list, &c->e_parents, &c->e_action, &c->e_free, &c->e_cost, &c->e_cells, &c->e_count})
@@ -859,7 +876,14 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
       a.live = live;
       a.live_n = live_n;
     }
+    c->done_armed = false;
+    if (c->want_done && c->tune.done_flag && c->done_host) {
+      a.done.flag = c->done_host;
+      a.done.count = (uint32_t *)c->done_count.p;
+      a.done.seq = ++c->done_seq;
+    }
     if (int rc = launch_grid(c, &a)) return rc;
+    c->done_armed = a.done.flag != nullptr;
     if (a.yaw.amb) {
       mplx_ctx::YawPending p;
       p.kind = 0;
@@ -876,12 +900,20 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     return fail(c, MPLX_ERR_STATE, "lists route TILE does not cover this configuration");
   if (tp.ok) {
     if (int rc = ensure_tables(c)) return rc;
-    const mplx::TileArgs a = tile_args(c, tp, d_nodes, n_nodes, node_stride, o);
+    mplx::TileArgs a = tile_args(c, tp, d_nodes, n_nodes, node_stride, o);
+    c->done_armed = false;
+    if (c->want_done && c->tune.done_flag && c->done_host) {
+      a.done.flag = c->done_host;
+      a.done.count = (uint32_t *)c->done_count.p;
+      a.done.seq = ++c->done_seq;
+    }
     HIP_TRY(c, mplx::launch_expand_tile(c->dim, c->prm.control, a, c->stream));
+    c->done_armed = a.done.flag != nullptr;
     c->last_route = MPLX_ROUTE_TILE;
     return MPLX_OK;
   }
   // dense kernel into scratch, chunk by chunk, then ordered compaction on the device
+  c->done_armed = false;
   const int64_t max_chunk_slots = (int64_t)(256u << 20) / (F * 8 + 21);  // ~256 MiB of scratch
   int64_t chunk_nodes = max_chunk_slots / c->nU;
   if (chunk_nodes < 1) chunk_nodes = 1;
@@ -942,11 +974,45 @@ int resolve_failed(mplx_ctx *c, int rc) {
 }
 }  // namespace
 
-int resolve_pending(mplx_ctx *c) {
+int wait_small_launch(mplx_ctx *c) {
+  if (!c->done_armed) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MPLX_OK;
+  }
+  c->done_armed = false;
+  volatile uint64_t *f = c->done_host;
+  const uint64_t want = c->done_seq;
+  double t0 = 0;
+  c->done_waits++;
+  for (uint32_t spins = 1; *f != want; spins++) {
+    __builtin_ia32_pause();
+    if ((spins & 0xfffu) != 0) continue;
+    const double now = mono_us();
+    if (t0 == 0) t0 = now;
+    if (now - t0 > 2e5) {  // 200 ms: the word did not come -- the stream decides, and this context stops asking for it
+      c->done_timeouts++;
+      c->tune.done_flag = 0;
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      (void)hipMemsetAsync(c->done_count.p, 0, 64, c->stream);
+      return MPLX_OK;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return MPLX_OK;
+}
+
+int resolve_pending(mplx_ctx *c, bool stream_is_idle) {
   if (c->yaw_pending.empty()) return MPLX_OK;
   MPLX_GUARD_BEGIN
   // several contexts of one process may sit on different GPUs: the fix pass allocates (yaw_ids, yaw_tab) and launches,
   // so the context's device must be the current one whatever entry point came through here
+  if (stream_is_idle) {
+    // (the caller has just seen the last launch of the stream finish: the common case below needs no runtime call)
+    if (c->yaw_any_host && *(volatile int32_t *)c->yaw_any_host == 0) {
+      c->yaw_pending.clear();
+      return MPLX_OK;
+    }
+  }
   if (int rc = bind_device(c)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->yaw_any_host && *(volatile int32_t *)c->yaw_any_host == 0) {
@@ -1051,10 +1117,6 @@ void arena_get_lists(const char *hb, const ArenaLayout &L, int F, int64_t S, int
         std::memcpy(h_out->state + (size_t)f * h_out->state_stride + at,
                     hb + L.o_state + ((size_t)f * L.n_slots + at) * 8, m * 8);
   }
-}
-
-double mono_us() {
-  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 // (Re)launch the resident kernel with the signature in c->svc (cap, S, rows); seq_served = the last request that
@@ -1265,12 +1327,15 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
       if (zero_copy) db = hb;  // the kernel reads the nodes from and writes the lists to the pinned host block itself
       else HIP_TRY(c, hipMemcpyAsync(db, hb, (size_t)F * n_nodes * 8, hipMemcpyHostToDevice, c->stream));
       const mplx_succ_lists d = mplx_detail::arena_lists(db, L, h_out->node_stride, rows);
-      if (int rc = lists_device(c, (const double *)db, n_nodes, n_nodes, &d)) return rc;
+      c->want_done = zero_copy;  // the kernel tells the host itself when the lists are in the block (DoneSignal)
+      const int rc_launch = lists_device(c, (const double *)db, n_nodes, n_nodes, &d);
+      c->want_done = false;
+      if (rc_launch) return rc_launch;
       if (!zero_copy)
         HIP_TRY(c, hipMemcpyAsync(hb + o_count, db + o_count, total - o_count, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (int rc = mplx_detail::wait_small_launch(c)) return rc;
       if (!c->yaw_pending.empty()) {  // a fix pass of the yaw pinning rewrites lists on the device side
-        if (int rc = resolve_pending(c)) return rc;
+        if (int rc = resolve_pending(c, true)) return rc;
         if (!zero_copy) {
           HIP_TRY(c, hipMemcpyAsync(hb + o_count, db + o_count, total - o_count, hipMemcpyDeviceToHost, c->stream));
           HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -68,6 +68,7 @@ struct mplx_ctx {
     int prescreen_min = 0;     // MPLX_GRID_PRESCREEN_MIN: smallest frontier that gets the lane-per-node pre-screen (0 = automatic, -1 = never)
     bool yaw_pin = true;       // MPLX_YAW_PIN=0: raw device trig decisions (to measure what the pinning is for)
     double yaw_margin = 0;     // MPLX_YAW_MARGIN: detection band (tests widen it to drive many nodes through the fix pass)
+    int done_flag = 1;         // MPLX_DONE_FLAG=0: small synchronous launches end with hipStreamSynchronize (DoneSignal)
     int service = 1;           // MPLX_SERVICE=0: every small batch is its own launch (mplx_service)
     int service_idle_us = 2000;   // MPLX_SERVICE_IDLE_US: the resident kernel leaves after this long without a request
     int service_max_nodes = 256;  // MPLX_SERVICE_MAX_NODES: larger batches are launches of their own
@@ -89,6 +90,13 @@ struct mplx_ctx {
   mplx_detail::DevBuf s_arena;
   void *h_arena = nullptr;
   size_t h_arena_cap = 0;
+  // Completion of small synchronous launches through a word the kernel writes itself (DoneSignal, mplx_internal.h)
+  uint64_t *done_host = nullptr;     // pinned
+  mplx_detail::DevBuf done_count;    // 4 bytes, zero between launches
+  uint64_t done_seq = 0;
+  bool want_done = false;            // set by a caller that will wait for the launch on the spot (around lists_device)
+  bool done_armed = false;           // ... and the launch that went in carries the signal
+  int64_t done_waits = 0, done_timeouts = 0;
   // Resident form of the tiled kernel for the small synchronous batches of a search ("service", mplx_api.cpp and
   // expand_tile_kernel.hip): requests go through a mailbox in pinned memory instead of launch + synchronise.
   struct Service {
@@ -224,7 +232,10 @@ int lists_on_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t
 // mplx_api.cpp: synchronises the stream and, where a launch flagged heading-limit decisions within rounding noise of
 // their threshold, re-expands those nodes with the host libm's trig values (YawPin, mplx_internal.h).  Every
 // synchronising entry point and every call that changes what a pending launch read goes through it.
-int resolve_pending(mplx_ctx *c);
+int resolve_pending(mplx_ctx *c, bool stream_is_idle = false);
+// after a small-batch launch through lists_on_device with want_done set: waits for it (kernel-written word, or the
+// stream); *idle = everything enqueued on the context's stream so far is complete
+int wait_small_launch(mplx_ctx *c);
 
 // lists_copy_api.cpp: device lists -> host lists, only the used prefixes, pipelined through pinned memory
 int copy_lists_to_host(mplx_ctx *c, const mplx_succ_lists &d, const mplx_succ_lists *h_out, int64_t n_nodes);

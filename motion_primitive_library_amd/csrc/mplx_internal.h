@@ -65,6 +65,16 @@ struct ExpandArgs {
 };
 
 // Arguments of the tiled, list-producing kernel (expand_tile_kernel.hip).
+// Completion of a small synchronous launch seen through a word the KERNEL writes into pinned host memory when its last
+// wave (workgroup) is through, instead of through hipStreamSynchronize: 8.2 us per empty launch + completion against
+// 12.8 us (profiles/micro/mailbox_latency.hip).  flag == nullptr: no signalling (every launch the caller does not wait
+// for on the spot).
+struct DoneSignal {
+  uint64_t *flag;   // pinned host memory; receives `seq` (system-scope release) after every store of the launch
+  uint32_t *count;  // device memory, 0 between launches: waves (workgroups) that have finished
+  uint64_t seq;
+};
+
 // Mailbox of the resident (service) form of the tiled kernel, in pinned host memory; every word on its own line.
 struct SvcMailbox {
   uint64_t doorbell;  // host -> device: (seq << 32) | n_nodes of the request in the landing block
@@ -117,6 +127,7 @@ struct TileArgs {
   uint64_t *svc_dev;    // device memory, zeroed before the launch: [0] = command, [1 + g] = last request workgroup g finished
   uint64_t svc_seq0;    // seq of the last request served before this launch
   uint64_t svc_idle;    // ticks of the 100 MHz clock without a request after which the kernel leaves
+  DoneSignal done;      // ordinary launches of small synchronous batches
 };
 
 size_t tile_lds_bytes(int tile_pairs, int npb, int wl_cap, int n_max, int n_fields, int u_doubles,
@@ -185,6 +196,7 @@ struct GridArgs {
   // stream).  Null: the kernel walks [0, n_nodes) and tests every node itself.
   const int32_t *live;
   const uint32_t *live_n;
+  DoneSignal done;      // small synchronous batches: see DoneSignal
 };
 constexpr int kWorkCounters = 64;
 // lane-per-node validate_yaw(t = 0) over a whole frontier (expand_grid_kernel.hip); fills live / live_n of `a`'s launch

@@ -17,6 +17,12 @@
 struct Mailbox { uint64_t doorbell; uint64_t pad0[7]; uint64_t done; uint64_t pad1[7]; uint32_t quit, alive; uint32_t stage, pad2; uint64_t payload[64]; };
 
 __global__ void empty_kernel(uint64_t *out, const uint64_t *in) { if (in) out[threadIdx.x] = in[threadIdx.x] + 1; }
+// the kernel itself tells the host that it is through: the host spins on `flag` instead of hipStreamSynchronize
+__global__ void flag_kernel(uint64_t *out, const uint64_t *in, uint64_t *flag, uint64_t seq) {
+  if (in) out[threadIdx.x] = in[threadIdx.x] + 1;
+  __threadfence_system();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // All 64 lanes of wave 0 poll / publish together (same address, same value): a single lane doing it (if (threadIdx.x
 // == 0) ...) next to the barriers of a loop is lane divergence around a convergent operation -- hipcc threaded lanes
@@ -75,6 +81,35 @@ int main() {
     for (int i = 0; i < N; i++) { hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s, mb->payload, (const uint64_t *)mb->payload); CK(hipStreamSynchronize(s)); }
     if (rep) printf("launch + sync, kernel reads+writes host block: %.2f us\n", (now_us() - t0) / N);
   }
+  // (a2) launch, completion seen through a flag the kernel writes into pinned memory (no hipStreamSynchronize per launch)
+  for (int rep = 0; rep < 2; rep++) {
+    volatile uint64_t *fl = &mb->done;
+    const double t0 = now_us();
+    for (int i = 0; i < N; i++) {
+      const uint64_t q = (uint64_t)rep * N + i + 1;
+      hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(64), 0, s, mb->payload, (const uint64_t *)mb->payload, (uint64_t *)&mb->done, q);
+      while (*fl != q) {}
+    }
+    if (rep) printf("launch, kernel-written flag instead of sync:   %.2f us\n", (now_us() - t0) / N);
+    CK(hipStreamSynchronize(s));
+  }
+  // (a3) the flag written by a stream memory operation behind the kernel / (a4) by a second one-wave kernel
+  for (int variant = 0; variant < 2; variant++) {
+    for (int rep = 0; rep < 2; rep++) {
+      volatile uint64_t *fl = &mb->done;
+      const double t0 = now_us();
+      for (int i = 0; i < N; i++) {
+        const uint64_t q = 100000 + (uint64_t)variant * 10 * N + (uint64_t)rep * N + i + 1;
+        hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s, mb->payload, (const uint64_t *)mb->payload);
+        if (variant == 0) CK(hipStreamWriteValue64(s, (void *)&mb->done, q, 0));
+        else hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(64), 0, s, mb->payload + 64 - 64, (const uint64_t *)nullptr, (uint64_t *)&mb->done, q);
+        while (*fl != q) {}
+      }
+      if (rep) printf("launch + %s, host spins on the flag: %.2f us\n", variant == 0 ? "hipStreamWriteValue64" : "a second (flag) kernel ", (now_us() - t0) / N);
+      CK(hipStreamSynchronize(s));
+    }
+  }
+  mb->done = 0;
   uint64_t hz = 100000000ull;  // wall_clock64: 100 MHz
   {  // watchdog alone
     mb->quit = 0; mb->alive = 1;
