@@ -281,7 +281,7 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
       if (c->pk_hb) HIP_TRY(c, hipHostFree(c->pk_hb));
       c->pk_hb = nullptr;
       c->pk_hb_cap = 0;
-      HIP_TRY(c, hipHostMalloc(&c->pk_hb, bytes + bytes / 2, hipHostMallocDefault));
+      HIP_TRY(c, hipHostMalloc(&c->pk_hb, bytes + bytes / 2, hipHostMallocCoherent));  // read by the host while the kernel may still run (DoneSignal)
       c->pk_hb_cap = bytes + bytes / 2;
     }
     char *hb = (char *)c->pk_hb;
@@ -320,7 +320,7 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
     if (c->pk_hb) HIP_TRY(c, hipHostFree(c->pk_hb));
     c->pk_hb = nullptr;
     c->pk_hb_cap = 0;
-    HIP_TRY(c, hipHostMalloc(&c->pk_hb, hb_bytes * 2, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(&c->pk_hb, hb_bytes * 2, hipHostMallocCoherent));
     c->pk_hb_cap = hb_bytes * 2;
   }
   char *hb = (char *)c->pk_hb;

@@ -651,7 +651,7 @@ int yaw_slot(mplx_ctx *c, mplx::YawPin *y) {
     HIP_TRY(c, hipMemsetAsync(c->yaw_ring.p, 0, bytes, c->stream));
   }
   if (!c->yaw_any_host) {
-    HIP_TRY(c, hipHostMalloc((void **)&c->yaw_any_host, 64, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void **)&c->yaw_any_host, 64, hipHostMallocCoherent));
     *c->yaw_any_host = 0;
   }
   y->any_host = c->yaw_any_host;
@@ -1318,7 +1318,7 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
         if (c->h_arena) HIP_TRY(c, hipHostFree(c->h_arena));
         c->h_arena = nullptr;
         c->h_arena_cap = 0;
-        HIP_TRY(c, hipHostMalloc(&c->h_arena, arena_max, hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc(&c->h_arena, arena_max, hipHostMallocCoherent));  // read by the host while the kernel may still run (DoneSignal)
         c->h_arena_cap = arena_max;
       }
       char *hb = (char *)c->h_arena, *db = (char *)c->s_arena.p;
