@@ -7,8 +7,8 @@ import time
 import numpy as np
 import pytest
 
-from helpers import engine_env, oracle_env
-from test_gpu_parity import _small_world
+from helpers import assert_lists_equal, engine_env, oracle_env
+from test_gpu_parity import YAW_COST_RTOL, _small_world
 
 pytestmark = pytest.mark.gpu
 
@@ -290,4 +290,28 @@ def test_soak_every_request_is_complete_when_done_is_seen(engine, which):
     assert st["failures"] == 0 and st["requests"] == rounds - 1
     env.close()
     ref.close()
+
+
+@pytest.mark.parametrize("control,potential", [(0x13, False), (0x03, True), (0x03, False)])
+def test_launches_that_end_with_the_completion_word_against_the_oracle(engine, oracle_lib, control, potential):
+    """Small batches that are launches of their own (yaw controls and potential maps never go to the resident kernel;
+    the plain case with the service switched off): the host reads the landing block as soon as the kernel's last wave
+    has written the completion word, without synchronising the stream.  Hundreds of launches against the CPU
+    restatement; a list entry that arrived after the word would differ."""
+    wl = _small_world(engine, 2, control, seed=8000 + control + (100 if potential else 0), n_nodes=300, potential=potential)
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+    nU = wl.U.shape[0]
+    env = engine_env(engine, wl)
+    env.service(0)
+    rng = np.random.default_rng(23)
+    rtol = YAW_COST_RTOL if control & 0x10 else 0.0
+    for k in range(400):
+        n = int(rng.integers(1, 49))
+        ids = rng.integers(0, wl.n_nodes, size=n)
+        got = env.expand_lists(np.ascontiguousarray(wl.nodes[:, ids]))
+        slots = (ids[:, None] * nU + np.arange(nU)[None, :]).ravel()
+        sub = {key: (ref[key][:, slots] if key == "state" else ref[key][slots]) for key in ("status", "cost", "hash", "state", "iters")}
+        assert_lists_equal(got, sub, n, nU, cost_rtol=rtol, what="launch %d" % k)
+    assert env.service()["requests"] == 0
+    env.close()
 
