@@ -372,6 +372,7 @@ struct PlanResult {
   int expansions = 0;       // expand_iteration (graph_search.h:64)
   int closed = 0, opened = 0, nodes = 0;
   int device_launches = 0;  // provider calls actually made
+  int spec_hits = 0;        // expansions served from lists that rode along in an earlier launch (speculated children)
   int64_t pairs = 0;        // node x control pairs evaluated by the provider
   int64_t state_mismatches = 0;  // check_states: successors whose host-evaluated state differs from the device's
   double total_time = 0;
@@ -444,6 +445,8 @@ class Planner {
     checked_states = 0;
     hm.clear();
     pool.clear();
+    if (spec.cap) spec.clear();  // (the map may have changed since the last plan)
+    spec_now = spec_cfg();
     preds.clear();
     all_blobs.clear();
     free_blobs.clear();
@@ -595,6 +598,65 @@ class Planner {
   uint32_t cur_batch = 0, pick_counter = 0;
   std::vector<NodePtr> cur_group;
   std::vector<int> aux_buf;  // storage of the candidate walk's position heap, recycled between launches
+
+  // ---- speculation on states that are not nodes yet.  The open list can only offer nodes that exist; in a goal-directed
+  // descent the next node to be popped is usually a CHILD of one that is being expanded in this very launch, created
+  // only after the launch returns -- a miss and another launch (C1: 75 launches for 615 expansions whatever the batch
+  // size).  The children's states are a pure function of parent and control (forward_state, bit-identical to the
+  // device's), so they ride along in the parent's launch; their lists wait here under their lattice hash, together with
+  // the exact state they were computed from (a node of that hash may have been created from another parent with another
+  // state: only a bitwise equal state is served).  get_succ is pure: the search cannot tell where a list came from.
+  // Measured on C1 (profiles/micro/plan_spec_sweep.sh): children of the first 1 / 2 / 4 / 8 nodes of a launch: 59 / 55 /
+  // 49 / 46 launches and 1.11 / 1.14 / 1.09 / 1.21 ms against 75 launches and 1.25 - 1.33 ms without; a second level
+  // (children of the popped node's most promising children) removed no launch at all -- the remaining misses are old
+  // open nodes and children of nodes served from the cache, not a descent two levels deep.
+  int spec_parents = -1;  // nodes of a launch whose children ride along (0: none; -1: automatic -- env MPLX_PLAN_SPEC)
+  struct SpecStore {
+    int nU = 0, F = 0;
+    size_t cap = 0, count = 0, mask = 0;
+    bool has_keys = false;
+    std::vector<uint64_t> tab_key;
+    std::vector<int32_t> tab_val;  // entry + 1, 0 = empty
+    std::vector<double> coord, cost;
+    std::vector<uint64_t> keys;
+    std::vector<int32_t> act, m;
+    void reset(int nU_, int F_, size_t cap_) {
+      nU = nU_; F = F_; cap = cap_;
+      size_t t = 1;
+      while (t < 4 * cap) t <<= 1;
+      mask = t - 1;
+      tab_key.assign(t, 0); tab_val.assign(t, 0);
+      coord.resize(cap * (size_t)F); cost.resize(cap * (size_t)nU); keys.resize(cap * (size_t)nU);
+      act.resize(cap * (size_t)nU); m.assign(cap, 0);
+      count = 0;
+    }
+    void clear() { std::fill(tab_val.begin(), tab_val.end(), 0); count = 0; }
+    static size_t mixk(uint64_t k) { k ^= k >> 31; k *= 0x9e3779b97f4a7c15ull; k ^= k >> 29; return (size_t)k; }
+    int find(uint64_t key) const {
+      if (!cap) return -1;
+      for (size_t i = mixk(key) & mask;; i = (i + 1) & mask) {
+        if (!tab_val[i]) return -1;
+        if (tab_key[i] == key) return tab_val[i] - 1;
+      }
+    }
+    int insert(uint64_t key) {  // a new entry (the caller has checked that the key is absent)
+      if (count == cap) clear();  // full: forget everything (entries are only ever hints)
+      size_t i = mixk(key) & mask;
+      while (tab_val[i]) i = (i + 1) & mask;
+      tab_key[i] = key;
+      tab_val[i] = (int32_t)++count;
+      return (int)count - 1;
+    }
+  } spec;
+  std::vector<double> nodes_buf;     // the launch's node rows (recycled)
+  std::vector<double> spec_states;   // [n][F] of the launch being assembled
+  std::vector<uint64_t> spec_keys;   // their lattice hashes
+  int spec_now = 0;  // spec_cfg() of the plan() under way
+  int spec_cfg() {
+    if (spec_parents >= 0) return spec_parents;
+    if (const char *e = getenv("MPLX_PLAN_SPEC")) return atoi(e);
+    return nU <= 32 ? 4 : 0;  // (a child per control per parent: small control tables only)
+  }
   void keep(Node &nd) {  // lists of `nd` out of the landing buffer into a recycled buffer
     const int f = F();
     const size_t m = (size_t)cur_view.count[nd.c_slot], o = (size_t)cur_view.offs[nd.c_slot];
@@ -633,6 +695,19 @@ class Planner {
       if (int rc = run_batch({curr})) return rc;
       return fetch(curr, v);
     }
+    const int n_spec_parents = spec_now;
+    if (!curr->cached && n_spec_parents > 0 && spec.cap) {
+      const int e = spec.find(curr->key);
+      if (e >= 0 && std::memcmp(&spec.coord[(size_t)e * f], curr->coord, sizeof(double) * (size_t)f) == 0) {
+        const int32_t m = spec.m[(size_t)e];
+        std::copy(&spec.cost[(size_t)e * nU], &spec.cost[(size_t)e * nU] + m, v_cost.begin());
+        std::copy(&spec.act[(size_t)e * nU], &spec.act[(size_t)e * nU] + m, v_act.begin());
+        if (spec.has_keys) std::copy(&spec.keys[(size_t)e * nU], &spec.keys[(size_t)e * nU] + m, v_keys.begin());
+        *v = SuccView{m, v_cost.data(), spec.has_keys ? v_keys.data() : nullptr, v_act.data(), nullptr, 1, f};
+        last.spec_hits++;
+        return 0;
+      }
+    }
     if (!curr->cached) {
       const auto t_p0 = std::chrono::steady_clock::now();
       // the popped node plus the best open nodes that have no list yet: best-first walk of the heap
@@ -668,6 +743,37 @@ class Planner {
         if (2 * i + 1 < (int)h.size()) push(2 * i + 1);
         if (2 * i + 2 < (int)h.size()) push(2 * i + 2);
       }
+      // children of the first nodes of the launch (the popped one, then the best of the open list)
+      spec_states.clear();
+      spec_keys.clear();
+      if (n_spec_parents > 0) {
+        if (spec.cap == 0 || spec.nU != nU || spec.F != f) spec.reset(nU, f, 2048);
+        double cs[14];
+        // children of `par`: into the launch -- as nodes when they exist and wait for lists, as bare states otherwise
+        auto children = [&](const double *par) {
+          for (int i = 0; i < nU; i++) {
+            forward_state(dim, control, par, &U[(size_t)i * udim], dt, cs);
+            const uint64_t key = lattice_hash(dim, control, cs);
+            if (Node *ex = hm.peek(key)) {
+              // a node already: closed or served -> nothing to do; open without lists -> an ordinary member of the launch
+              if (!ex->closed && !ex->cached && ex->pick_stamp != pick_counter && group.size() < (size_t)batch + 64) {
+                ex->pick_stamp = pick_counter;
+                group.push_back(ex);
+              }
+              continue;
+            }
+            if (spec.find(key) >= 0) continue;  // waiting already (or another state of that hash is: first come, first kept)
+            bool dup = false;
+            for (uint64_t k2 : spec_keys) dup = dup || k2 == key;
+            if (dup) continue;
+            spec_keys.push_back(key);
+            spec_states.insert(spec_states.end(), cs, cs + f);
+          }
+        };
+        // (the group grows while its first members' children are looked at: only members picked from the heap count)
+        const size_t n_par = std::min(group.size(), (size_t)n_spec_parents);
+        for (size_t gi = 0; gi < n_par; gi++) children(group[gi]->coord);
+      }
       t_pick += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p0).count();
       if (int rc = run_batch(group)) return rc;
     }
@@ -676,11 +782,24 @@ class Planner {
 
   int run_batch(const std::vector<NodePtr> &group) {
     const int f = F();
-    const int64_t n = (int64_t)group.size();
-    std::vector<double> nodes((size_t)f * n);
-    for (int64_t k = 0; k < n; k++)
+    const int64_t ng = (int64_t)group.size(), ns = (int64_t)spec_keys.size();
+    const int64_t n = ng + ns;  // the launch: the nodes of the group, then the speculated states
+    std::vector<double> &nodes = nodes_buf;
+    nodes.resize((size_t)f * n);
+    for (int64_t k = 0; k < ng; k++)
       for (int r = 0; r < f; r++) nodes[(size_t)r * n + k] = group[(size_t)k]->coord[(size_t)r];
+    for (int64_t k = 0; k < ns; k++)
+      for (int r = 0; r < f; r++) nodes[(size_t)r * n + ng + k] = spec_states[(size_t)k * f + r];
     const int64_t slots = n * nU;
+    // lists of the speculated states into the store (entry e <- column ng + k of the launch)
+    auto harvest = [&](int64_t k, int32_t m, const double *cost, const uint64_t *keys, const int32_t *act) {
+      const int e = spec.insert(spec_keys[(size_t)k]);
+      std::copy(&spec_states[(size_t)k * f], &spec_states[(size_t)k * f] + f, &spec.coord[(size_t)e * f]);
+      spec.m[(size_t)e] = m;
+      std::copy(cost, cost + m, &spec.cost[(size_t)e * nU]);
+      std::copy(act, act + m, &spec.act[(size_t)e * nU]);
+      if (keys) std::copy(keys, keys + m, &spec.keys[(size_t)e * nU]);
+    };
     last.device_launches++;
     last.pairs += slots;
     if (packed) {
@@ -693,11 +812,16 @@ class Planner {
       cur_batch++;
       if (int rc = packed(user, nodes.data(), n, &cur_view)) return rc;
       t_provider += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_l0).count();
-      for (int64_t k = 0; k < n; k++) {
+      for (int64_t k = 0; k < ng; k++) {
         Node &nd = *group[(size_t)k];
         nd.c_slot = (int32_t)k;
         nd.c_batch = cur_batch;
         nd.cached = true;
+      }
+      if (ns) spec.has_keys = true;
+      for (int64_t k = 0; k < ns; k++) {
+        const size_t o = (size_t)cur_view.offs[ng + k];
+        harvest(k, cur_view.count[ng + k], cur_view.cost + o, cur_view.hash + o, cur_view.action + o);
       }
       cur_group.assign(group.begin(), group.end());
       return 0;
@@ -714,7 +838,12 @@ class Planner {
         return rc;
       const auto t_l1 = std::chrono::steady_clock::now();
       t_provider += std::chrono::duration<double, std::milli>(t_l1 - t_l0).count();
-      for (int64_t k = 0; k < n; k++) {
+      if (ns) spec.has_keys = true;
+      for (int64_t k = 0; k < ns; k++) {
+        const int64_t o = (ng + k) * nU;
+        harvest(k, b_cnt[(size_t)(ng + k)], b_cost.data() + o, b_hash.data() + o, b_act.data() + o);
+      }
+      for (int64_t k = 0; k < ng; k++) {
         Node &nd = *group[(size_t)k];
         const int32_t m = b_cnt[(size_t)k];
         const int64_t o = k * nU;
@@ -737,7 +866,19 @@ class Planner {
     if (int rc = batched(user, nodes.data(), n, st.data(), cs.data(), state.data())) return rc;
     const auto t_b1 = std::chrono::steady_clock::now();
     t_provider += std::chrono::duration<double, std::milli>(t_b1 - t_b0).count();
-    for (int64_t k = 0; k < n; k++) {
+    if (ns) spec.has_keys = false;
+    for (int64_t k = 0; k < ns; k++) {  // dense slots: the emitted ones, in control order
+      int32_t m = 0;
+      for (int i = 0; i < nU; i++) {
+        const int64_t sl = (ng + k) * nU + i;
+        if (st[(size_t)sl] != 1 && st[(size_t)sl] != 2) continue;
+        v_cost[(size_t)m] = cs[(size_t)sl];
+        v_act[(size_t)m] = i;
+        m++;
+      }
+      harvest(k, m, v_cost.data(), nullptr, v_act.data());
+    }
+    for (int64_t k = 0; k < ng; k++) {
       Node &nd = *group[(size_t)k];
       nd.c_succ.clear(); nd.c_cost.clear(); nd.c_act.clear();
       for (int i = 0; i < nU; i++) {

@@ -144,3 +144,26 @@ def test_reference_test_scenarios_on_the_cpu(scenario, closed, cost, T, region):
         assert r[0]["closed"] == 615 and r[0]["total_time"] == 35.0 and r[0]["J"][:2] == [36.75, 1.5]
     assert last["ok"] and last["closed"] == closed and last["total_time"] == T
     assert r[1]["region_cells"] == region and abs(last["cost"] - cost) <= 1e-12 * cost
+
+
+def test_c1_children_that_ride_along_change_nothing_but_the_launch_count(engine, monkeypatch):
+    """Speculation on states that are not nodes yet (host_planner.hpp): the children of the first nodes of a launch,
+    evaluated on the host, are expanded in the same launch and served later by hash + bitwise equal state.  Same
+    expansions, same closed set, same trajectory; fewer provider calls."""
+    monkeypatch.setenv("MPLX_PLAN_SPEC", "0")
+    ok0, s0, t0, c0 = run_c1(engine, batch=16)
+    launches = {0: s0["device_launches"]}
+    for parents in (1, 4, 16):
+        monkeypatch.setenv("MPLX_PLAN_SPEC", str(parents))
+        ok, s, t, c = run_c1(engine, batch=16)
+        assert ok and ok0
+        for k in ("expansions", "closed", "opened", "nodes", "cost"):
+            assert s[k] == s0[k], (parents, k)
+        assert np.array_equal(c, c0)
+        assert t.getTotalTime() == t0.getTotalTime()
+        launches[parents] = s["device_launches"]
+    assert launches[0] == 75 and launches[1] < 65 and launches[4] < 55 and launches[16] < 45
+    monkeypatch.delenv("MPLX_PLAN_SPEC")
+    ok, s, t, c = run_c1(engine, batch=16)      # the default: on for a 9-control table
+    assert s["device_launches"] == launches[4] and s["closed"] == 615
+
