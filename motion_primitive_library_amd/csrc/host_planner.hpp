@@ -608,8 +608,8 @@ class Planner {
   // state: only a bitwise equal state is served).  get_succ is pure: the search cannot tell where a list came from.
   // Measured on C1 (profiles/micro/plan_spec_sweep.sh): children of the first 1 / 2 / 4 / 8 nodes of a launch: 59 / 55 /
   // 49 / 46 launches and 1.11 / 1.14 / 1.09 / 1.21 ms against 75 launches and 1.25 - 1.33 ms without; a second level
-  // (children of the popped node's most promising children) removed no launch at all -- the remaining misses are old
-  // open nodes and children of nodes served from the cache, not a descent two levels deep.
+  // (children of the popped node's most promising children) removed no launch at all -- every remaining miss is a node
+  // created since the last launch, a child of a node served from the cache, not a descent two levels deep.
   int spec_parents = -1;  // nodes of a launch whose children ride along (0: none; -1: automatic -- env MPLX_PLAN_SPEC)
   struct SpecStore {
     int nU = 0, F = 0;
