@@ -1206,12 +1206,15 @@ int svc_request(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t nod
     int64_t cap = 64;
     while (cap < n_nodes) cap <<= 1;
     const size_t arena_max = c->tune.arena_kb > 0 ? (size_t)c->tune.arena_kb << 10 : (size_t)8 << 20;
-    while (cap > n_nodes && (arena_layout(F, cap, S, rows).total > arena_max || (cap + tp.npb - 1) / tp.npb > kMaxWorkgroups)) cap >>= 1;
+    const unsigned want_rows = (S == sv.S) ? (rows | sv.rows) : rows;
+    while (cap > n_nodes && (arena_layout(F, cap, S, want_rows).total > arena_max || (cap + tp.npb - 1) / tp.npb > kMaxWorkgroups)) cap >>= 1;
     if (cap < n_nodes) cap = n_nodes;
-    if (arena_layout(F, cap, S, rows).total > arena_max) return MPLX_OK;
+    if (arena_layout(F, cap, S, want_rows).total > arena_max) return MPLX_OK;
     sv.cap = cap;
+    // (callers that alternate between two sets of rows -- a search's batches and single get_succ calls -- get the union,
+    // not a restart per call)
+    sv.rows = (S == sv.S) ? (rows | sv.rows) : rows;
     sv.S = S;
-    sv.rows = rows;
     if (sv.seq > 0xfffffff0u) {  // (the doorbell of the last request still carries the old number)
       sv.seq = 0;
       if (sv.mb) *(volatile uint64_t *)&sv.mb->doorbell = 0;
