@@ -159,6 +159,12 @@ __device__ unsigned long long g_phase_ticks[16];
 #define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter(), pt_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PT(i) do { const unsigned long long pt_now = __builtin_readcyclecounter(); pt_acc[i] += pt_now - pt_last; pt_last = pt_now; } while (0)
 #define PT_FLUSH do { if (lane == 0) for (int pi = 0; pi < 10; pi++) atomicAdd(&g_phase_ticks[pi], pt_acc[pi]); } while (0)
+#elif defined(MPLX_PHASE_MARK)
+// static phase split: `hipcc -S -DMPLX_PHASE_MARK` leaves "; PTMARK i" comments where the markers are
+// (profiles/micro/isa_phase_count.py counts the instructions between them)
+#define PT_DECL
+#define PT(i) asm volatile("; PTMARK " #i)
+#define PT_FLUSH
 #else
 #define PT_DECL
 #define PT(i)

@@ -523,9 +523,12 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A_kerna
     if (A.l_count) A.l_count[node0 + nl] = s_ncnt[nl];
   }  // tile loop
   if (!SVC) break;
-  // Every store of this workgroup has been acknowledged (the barrier's workgroup-scope release waits for each wave's
-  // outstanding stores) before wave 0 writes back what the L2 still holds and reports the request.  (A system-scope
-  // fence in every wave was 8 x 64 L2 write-backs a request: + 7 us on a one-node request of the 729-control table.)
+  // Every store of this workgroup must have been ACKNOWLEDGED before wave 0 writes back what the L2 still holds and
+  // reports the request.  The barrier alone does not give that: on gfx9 a workgroup-scope release only waits for
+  // lgkmcnt (hipcc emits `global_store ... s_waitcnt lgkmcnt(0) ; s_barrier`), so every wave drains its own vmcnt
+  // first -- an s_waitcnt, no cache maintenance.  (A system-scope fence in every wave was 8 x 64 L2 write-backs a
+  // request: + 7 us on a one-node request of the 729-control table.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (wave0) {
     if ((int64_t)blockIdx.x * A.npb < n_nodes) __threadfence_system();
@@ -545,7 +548,8 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A_kerna
   __syncthreads();
   }  // request loop
   if (!SVC && A.done.flag != nullptr) {  // see DoneSignal (mplx_internal.h); no barrier follows: one lane may act alone
-    __syncthreads();  // every wave's stores have been acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are acknowledged (the barrier waits for lgkmcnt only)
+    __syncthreads();
     if (tid == 0) {
       __threadfence_system();
       if (__hip_atomic_fetch_add(A.done.count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {

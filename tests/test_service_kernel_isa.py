@@ -51,3 +51,28 @@ def test_service_instantiations_have_the_barriers_of_the_source(tmp_path):
         assert "sc0 sc1" in window and re.search(r"s_cbranch_(vccz|vccnz|scc0|scc1)", window), (d, k, one)
         assert "s_dcache_inv" in body and "buffer_wbl2 sc0 sc1" in body
         assert "s_memrealtime" not in plain and "s_dcache_inv" not in plain
+
+
+@pytest.mark.skipif(_hipcc() is None, reason="hipcc not available")
+def test_every_wave_drains_its_stores_before_the_completion_barrier(tmp_path):
+    """Round-3 advice: `done` (service form) and the DoneSignal word (ordinary form) are published by wave 0 after a
+    barrier, and the host reads the landing block as soon as the word appears.  On gfx9 the barrier's workgroup-scope
+    release waits for lgkmcnt only, so every wave has to drain its own vmcnt first: each instantiation carries an explicit
+    `s_waitcnt vmcnt(0)` (inline asm, kept verbatim by the compiler) whose next memory-or-barrier instruction is the
+    s_barrier in front of the publication -- no store of the wave can slip in between."""
+    out = tmp_path / "tile.s"
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
+           SRC, "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, cwd=os.path.dirname(SRC))
+    text = out.read_text()
+    drain = re.compile(r";;#ASMSTART\s*\n\s*s_waitcnt vmcnt\(0\)\s*\n\s*;;#ASMEND")
+    n = 0
+    for m in re.finditer(r"^(_ZN4mplx\S*expand_tile_kernelILi(\d)ELi(\d)ELb([01])ELb([01])E\S*):\s*;", text, re.M):
+        body = text[m.end():text.index("s_endpgm", m.end())]
+        hits = list(drain.finditer(body))
+        assert len(hits) >= 1, m.group(1)
+        for h in hits:
+            nxt = re.search(r"^\s*(global_\w+|buffer_\w+|flat_\w+|s_barrier)", body[h.end():], re.M)
+            assert nxt and nxt.group(1) == "s_barrier", (m.group(1), nxt.group(1) if nxt else None)
+        n += 1
+    assert n == 32
