@@ -393,13 +393,13 @@ def main():
                          "the W warm-up steps: the workload is generated on the host for seconds while the GPU idles at "
                          "its lowest clocks, and the first ~25 ms of launches after that run up to 25 %% slower "
                          "(profiles/micro/c4_ramp.py: 0.60, 0.54, 0.50, 0.48 ms ... steady 0.476); 0 = off")
-    ap.add_argument("--placement-trials", type=int, default=8,
-                    help="The C4 kernel's time depends on WHERE in HBM the 5.4 GB of state rows landed: per allocation "
-                         "either 0.49 - 0.50 or 0.56 - 0.57 ms, for the allocation's lifetime, whatever the row skew, "
-                         "node stride, contiguity flag or memory type (profiles/micro/c4_placement*.py, c4_skew.py, "
-                         "c4_stride.py, c4_alloc_flags.py).  A long-lived output pool is allocated once, so the bench does "
-                         "what a deployment would: up to this many allocations (held while probing), a 20-launch probe of each, the fastest "
-                         "is kept -- before the warm-up and timed steps, and reported in config.output_placement.  1 = off")
+    ap.add_argument("--placement-trials", type=int, default=1,
+                    help="DIAGNOSTIC (default 1 = off since round 4).  The C4 kernel's time is the WRITE bandwidth of the "
+                         "memory its 5.4 GB of state rows landed in: per allocation 0.49 ... 0.565 ms, and pure stores into "
+                         "the same allocation show the same modes (5.9 against 5.15 TB/s, profiles/r04_store_layouts_vs_kernel.txt); "
+                         "no layout, skew, stride or allocation flag moves it.  `value` is what a process that allocates its "
+                         "output once measures.  > 1: up to this many allocations (held while probing), a 20-launch probe of "
+                         "each, the fastest kept -- listed in config.output_placement; never at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip e2e / wavefront / other_configs / plan (N = 1 only)")
     ap.add_argument("--frontier", default="random", choices=["random", "wavefront"],
@@ -570,7 +570,7 @@ def main():
                 break
         spin["ms"] = (time.perf_counter() - t_spin) * 1e3
     placement = {"probe_ms": [], "chosen": 0}
-    if args.placement_trials > 1:  # see --placement-trials (every rank probes its own shard's lists; no collective inside)
+    if args.placement_trials > 1 and world == 1:  # see --placement-trials (diagnostic; a rank of an N > 1 run never probes)
         def probe():
             env.timer_begin()
             for _ in range(20):
@@ -704,7 +704,9 @@ def main():
         ms_wall = elapsed / args.steps * 1e3
         # N = 1: the contract's wall clock around the K steps.  N > 1: the slowest rank's K steps on its stream (HIP
         # events, max over ranks) -- see timed(); the barrier-inclusive wall figure is kept beside it.
-        ms_per_step = kernel_ms_slowest if world > 1 else ms_wall
+        # `value` is the wall clock for every N (round-3 advice: the HIP-event figure of N > 1 was not comparable with the
+        # N = 1 definition or with earlier rounds); the slowest rank's HIP-event time is reported beside it.
+        ms_per_step = ms_wall
         out_kernel = KERNEL_NAME[route]
         achieved = b_alg / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -714,9 +716,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "ms_per_step_wall": ms_wall, "value_wall": float(N) * nU * args.steps / elapsed,
-            "timing": ("K steps between barrier + synchronize on both sides; N = 1: host clock; N > 1: `value` from the "
-                       "slowest rank's HIP-event time of its K steps (max over ranks), `value_wall` from the host clock "
-                       "including both barriers (max over ranks)"),
+            "ms_per_step_events": kernel_ms_slowest, "value_events": float(N) * nU / (kernel_ms_slowest * 1e-3),
+            "timing": ("K steps between barrier + synchronize on both sides, host clock, max over ranks = `value` for every "
+                       "N; `value_events` / `ms_per_step_events`: the slowest rank's HIP-event time of its K steps on the "
+                       "engine's stream (no barrier, no launch gaps)"),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

@@ -636,6 +636,42 @@ hipError_t launch_make_tables(double T, double res, double *ttab, unsigned char 
   return hipGetLastError();
 }
 
+// Workgroups of the service form of (dim, control, a.npb) the whole device keeps resident at once with a's LDS size, as
+// the runtime accounts registers, LDS granules and wave slots (0: it cannot tell).  The resident kernel's workgroups wait
+// for each other, so svc_launch asks before it launches more than that.
+template <int D, int K>
+int tile_svc_resident(const TileArgs &a) {
+  const size_t lds = tile_lds_bytes(a.tile_pairs, a.npb, a.wl_cap, a.n_max, 4 * D + 2, a.nU * a.udim, nullptr);
+  const void *fn = a.npb == 1 ? (const void *)expand_tile_kernel<D, K, true, true> : (const void *)expand_tile_kernel<D, K, false, true>;
+  int dev = 0, cus = 0, nb = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, kBT, lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return nb * cus;
+}
+
+int tile_service_resident_workgroups(int dim, int control, const TileArgs &a) {
+  if (dim == 2) {
+    switch (control) {
+      case 0x01: return tile_svc_resident<2, 1>(a);
+      case 0x03: return tile_svc_resident<2, 2>(a);
+      case 0x07: return tile_svc_resident<2, 3>(a);
+      case 0x0f: return tile_svc_resident<2, 4>(a);
+    }
+  } else if (dim == 3) {
+    switch (control) {
+      case 0x01: return tile_svc_resident<3, 1>(a);
+      case 0x03: return tile_svc_resident<3, 2>(a);
+      case 0x07: return tile_svc_resident<3, 3>(a);
+      case 0x0f: return tile_svc_resident<3, 4>(a);
+    }
+  }
+  return 0;
+}
+
 hipError_t launch_expand_tile(int dim, int control, const TileArgs &a, hipStream_t s) {
   if (dim == 2) {
     switch (control) {

@@ -447,6 +447,8 @@ class Planner {
     pool.clear();
     if (spec.cap) spec.clear();  // (the map may have changed since the last plan)
     spec_now = spec_cfg();
+    spec_keys.clear();  // (states a plan with batch > 1 assembled must not ride along in this plan's launches)
+    spec_states.clear();
     preds.clear();
     all_blobs.clear();
     free_blobs.clear();
@@ -782,6 +784,9 @@ class Planner {
 
   int run_batch(const std::vector<NodePtr> &group) {
     const int f = F();
+    // (speculated states only ever ride along into a store of their own shape: a control table or state size that
+    // changed since they were assembled would index the store's arrays with the wrong strides)
+    if (!spec_keys.empty() && (spec.cap == 0 || spec.nU != nU || spec.F != f)) { spec_keys.clear(); spec_states.clear(); }
     const int64_t ng = (int64_t)group.size(), ns = (int64_t)spec_keys.size();
     const int64_t n = ng + ns;  // the launch: the nodes of the group, then the speculated states
     std::vector<double> &nodes = nodes_buf;

@@ -890,6 +890,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
       p.g = a;
       p.g.live = nullptr;  // the fix pass walks its own node list
       p.g.live_n = nullptr;
+      p.g.done = {};       // ... and is not the launch a caller waits for on the completion word
       c->yaw_pending.push_back(p);
     }
     c->last_route = MPLX_ROUTE_GRID;
@@ -1154,6 +1155,14 @@ int svc_launch(mplx_ctx *c, const TilePlan &tp, uint32_t seq_served) {
   a.svc_dev = (uint64_t *)sv.dev.p;
   a.svc_seq0 = seq_served;  // the kernel waits for the request after this one
   a.svc_idle = (uint64_t)c->tune.service_idle_us * 100ull;  // ticks of the 100 MHz clock
+  // every workgroup of the resident form waits for the others: the runtime's own occupancy figure has to cover the grid
+  // (tp.grid is an LDS estimate; a register-limited instantiation or a smaller device would otherwise hang the handshake
+  // until the 2 s give-up).  Fewer than asked for: this context serves its small batches with launches.
+  const int resident = mplx::tile_service_resident_workgroups(c->dim, c->prm.control, a);
+  if (resident > 0 && resident < (int)g) {
+    sv.disabled = true;
+    return MPLX_OK;
+  }
   *(volatile uint32_t *)&sv.mb->quit = 0;
   *(volatile uint32_t *)&sv.mb->alive = 1;
   std::atomic_thread_fence(std::memory_order_seq_cst);
@@ -1220,6 +1229,7 @@ int svc_request(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t nod
       if (sv.mb) *(volatile uint64_t *)&sv.mb->doorbell = 0;
     }
     if (int rc = svc_launch(c, tp, sv.seq)) return rc;
+    if (!sv.running) return MPLX_OK;  // (not resident on this device: see svc_launch)
   }
   const ArenaLayout L = arena_layout(F, sv.cap, sv.S, sv.rows);
   arena_put_nodes(sv.block, L, F, h_nodes, n_nodes, node_stride);
@@ -1240,6 +1250,7 @@ int svc_request(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t nod
       sv.running = false;
       relaunches++;
       if (int rc = svc_launch(c, tp, seq - 1)) return rc;
+      if (!sv.running) return MPLX_OK;
     } else if (now - t0 > 2e6) {
       // no answer: give the batch to an ordinary launch and never try again in this context
       sv.failures++;

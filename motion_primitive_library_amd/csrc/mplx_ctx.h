@@ -70,7 +70,7 @@ struct mplx_ctx {
     double yaw_margin = 0;     // MPLX_YAW_MARGIN: detection band (tests widen it to drive many nodes through the fix pass)
     int done_flag = 1;         // MPLX_DONE_FLAG=0: small synchronous launches end with hipStreamSynchronize (DoneSignal)
     int service = 1;           // MPLX_SERVICE=0: every small batch is its own launch (mplx_service)
-    int service_idle_us = 2000;   // MPLX_SERVICE_IDLE_US: the resident kernel leaves after this long without a request
+    int service_idle_us = 500;    // MPLX_SERVICE_IDLE_US: the resident kernel leaves after this long without a request
     int service_max_nodes = 256;  // MPLX_SERVICE_MAX_NODES: larger batches are launches of their own
   } tune;
   int lists_route = MPLX_ROUTE_AUTO;

@@ -135,6 +135,7 @@ size_t tile_lds_bytes(int tile_pairs, int npb, int wl_cap, int n_max, int n_fiel
 hipError_t launch_make_tables(double T, double res, double *ttab, unsigned char *tcnt, double *recips,
                               hipStream_t stream);
 hipError_t launch_expand_tile(int dim, int control, const TileArgs &args, hipStream_t stream);
+int tile_service_resident_workgroups(int dim, int control, const TileArgs &a);  // 0: unknown
 
 // Arguments of the factorised list-producing kernel (expand_grid_kernel.hip):
 // the control table is given per axis as its distinct values plus, per control,

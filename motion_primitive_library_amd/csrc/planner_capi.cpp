@@ -163,6 +163,9 @@ int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, 
     p->err = "mplx_planner_plan: unexpected exception";
     return MPLX_ERR_NOMEM;
   }
+  // the search is over: its resident expansion kernel (if one served the batches) leaves now instead of polling until its
+  // idle time-out -- anything else in the process that synchronises the device would wait for it
+  if (p->ctx) (void)mplx_detail::svc_stop(p->ctx);
   if (rc != 0) {
     p->err = "successor provider failed";
     if (p->ctx) p->err += std::string(": ") + mplx_last_error(p->ctx);

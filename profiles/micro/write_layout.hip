@@ -6,6 +6,8 @@
 //   Rn  record-major, lane = successor: eight 16-byte stores per lane at a 128-byte lane stride (naive)
 //   Rt  record-major, transposed: store i of a 64-successor block writes bytes [1024 i, 1024 i + 1024) -- every
 //       instruction covers eight whole lines (what an LDS transpose in the real kernel would produce)
+//   F2  field-major, lane = two consecutive successors: 16-byte stores, 1 KB contiguous per row and instruction
+//   fill a linear fill of the same number of bytes with 16-byte stores (the ceiling of this allocation)
 //   R7  Rt with 112-byte records (state only; hash, cost, action stay field-major rows): 7 stores of 1 KB per block
 // All stores `sc1 nt` like the kernel's; counts per node 150 .. 470 (mean ~311) rounded up to 16; one wave per node,
 // 1024 workgroups of 4 waves, nodes strided.
@@ -57,7 +59,18 @@ __global__ __launch_bounds__(256) void stores(char *buf, long stride, int n_node
           if (off < live * 128) st16(d2v{(double)node, (double)i}, blk + off);
         }
         if (e < cpad) st4(e, &act[base + e]);
-      } else {
+      } else if (layout == 4) {
+        // F2: field-major rows, a lane owns TWO consecutive successors of a 128-successor block: one 16-byte store per row
+        // and lane = 1 KB contiguous per row-store (and half the store instructions of F)
+        if ((e0 & 64) == 0) {
+          const int e2 = e0 + 2 * lane;
+          if (e2 < cpad) {
+#pragma unroll
+            for (int f = 0; f < 16; f++) st16(d2v{(double)(node + f), 1.0}, &rows[f * stride + base + e2]);
+            asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" ::"v"(&act[base + e2]), "v"(d2v{1.0, 2.0}.x) : "memory");
+          }
+        }
+      } else if (layout == 3) {
         // 112-byte records of the block back to back (block start = (base + e0) * 112: 16-byte aligned since base and e0
         // are multiples of 16), hash + cost as two field-major rows behind the record area
         char *blk = buf + (base + e0) * 112;
@@ -77,6 +90,10 @@ __global__ __launch_bounds__(256) void stores(char *buf, long stride, int n_node
   }
 }
 
+__global__ __launch_bounds__(256) void fill16(char *buf, long n16) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) st16(d2v{1.0, 2.0}, buf + i * 16);
+}
+
 int main(int argc, char **argv) {
   const int n_nodes = 65536, S = 736;
   const int allocs = argc > 1 ? atoi(argv[1]) : 8;
@@ -90,15 +107,20 @@ int main(int argc, char **argv) {
     h ^= h >> 15;
     bytes += (double)(((150 + (int)(h % 321u)) + 15) & ~15) * 132.0;
   }
-  const char *name[4] = {"F", "Rn", "Rt", "R7"};
+  const char *name[6] = {"F", "Rn", "Rt", "R7", "F2", "fill"};
   for (int al = 0; al < allocs; al++) {
     char *buf;
     if (hipMalloc(&buf, stride * (16 * 8 + 4)) != hipSuccess) { printf("alloc failed\n"); return 1; }
     printf("alloc %d:", al);
-    for (int layout = 0; layout < 4; layout++) {
-      for (int rep = 0; rep < 40; rep++) stores<<<256 * 4, 256>>>(buf, stride, n_nodes, S, layout);  // clocks
+    for (int layout = 0; layout < 6; layout++) {
+      if (layout == 1) continue;  // (Rn: 8.4 ms, measured once)
+      auto go = [&]() {
+        if (layout == 5) fill16<<<256 * 8, 256>>>(buf, (long)(bytes / 16));
+        else stores<<<256 * 4, 256>>>(buf, stride, n_nodes, S, layout);
+      };
+      for (int rep = 0; rep < 40; rep++) go();  // clocks
       (void)hipEventRecord(a);
-      for (int rep = 0; rep < 20; rep++) stores<<<256 * 4, 256>>>(buf, stride, n_nodes, S, layout);
+      for (int rep = 0; rep < 20; rep++) go();
       (void)hipEventRecord(b);
       (void)hipEventSynchronize(b);
       float ms;

@@ -68,7 +68,7 @@ def test_every_wave_drains_its_stores_before_the_completion_barrier(tmp_path):
     drain = re.compile(r";;#ASMSTART\s*\n\s*s_waitcnt vmcnt\(0\)\s*\n\s*;;#ASMEND")
     n = 0
     for m in re.finditer(r"^(_ZN4mplx\S*expand_tile_kernelILi(\d)ELi(\d)ELb([01])ELb([01])E\S*):\s*;", text, re.M):
-        body = text[m.end():text.index("s_endpgm", m.end())]
+        body = text[m.end():re.compile(r"^\.Lfunc_end\d+:", re.M).search(text, m.end()).start()]  # (s_endpgm also ends early exits)
         hits = list(drain.finditer(body))
         assert len(hits) >= 1, m.group(1)
         for h in hits:
