@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MPLX_ABI_VERSION 5
+#define MPLX_ABI_VERSION 6
 
 typedef struct mplx_ctx mplx_ctx;
 
@@ -477,6 +477,12 @@ enum { MPLX_ROUTE_AUTO = 0, MPLX_ROUTE_DENSE = 1, MPLX_ROUTE_TILE = 2, MPLX_ROUT
 int mplx_set_lists_route(mplx_ctx *ctx, int route);
 /* Route taken by the last mplx_expand_lists* call (MPLX_ROUTE_*).            */
 int mplx_last_lists_route(const mplx_ctx *ctx);
+/* ABI v6.  The GRID route has two kernels with identical results: the general factorised one, and one for the
+ * control tables the reference's programs build -- the nested-loop (lexicographic) enumeration of per-axis values,
+ * no yaw, occupancy map (expand_lex_kernel.hip; MPLX_GRID_LEX=0 sends those to the general kernel too).  Which one
+ * the last mplx_expand_lists* call ran: MPLX_KERNEL_NONE when the route was not GRID.                              */
+enum { MPLX_KERNEL_NONE = 0, MPLX_KERNEL_GRID = 1, MPLX_KERNEL_LEX = 2 };
+int mplx_last_grid_kernel(const mplx_ctx *ctx);
 /* The service: how mplx_expand_lists (and mplx_get_succ, which calls it) serves
  * the small synchronous batches of a search -- at most MPLX_SERVICE_MAX_NODES
  * (256) nodes, control tables without yaw, no potential map, bounded velocity.

@@ -126,6 +126,7 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
     c->tune.grid_blocks = env_int("MPLX_GRID_BLOCKS");
     c->tune.grid_waves_per_cu = env_int("MPLX_GRID_WAVES_PER_CU");
     c->tune.grid_static = getenv("MPLX_GRID_STATIC") != nullptr;
+    if (getenv("MPLX_GRID_LEX")) c->tune.grid_lex = env_int("MPLX_GRID_LEX") != 0;
     c->tune.grid_chunk = env_int("MPLX_GRID_CHUNK");
     c->tune.grid_blocked = env_int("MPLX_GRID_BLOCKED");
     c->tune.grid_gather = getenv("MPLX_GRID_GATHER") ? env_int("MPLX_GRID_GATHER") : -1;
@@ -488,6 +489,7 @@ struct GridPlan {
   bool ok = false;
   int ndp = 1, n_max = 0, rmax = 0, boxcap = 0, grid = 0, order = 0;
   bool gather = false, use_sat = true;
+  bool lex = false;  // expand_lex_kernel.hip serves it (lexicographic table, no yaw, occupancy map)
 };
 
 // Does the factorised kernel cover the current configuration, and how is it sized?
@@ -533,25 +535,33 @@ GridPlan plan_grid(const mplx_ctx *c) {
   if (c->tune.grid_boxcap > 0) boxcap = c->tune.grid_boxcap;
   if (rmax < 1) rmax = 1;
   const int ulex = (c->u_lex && !c->tune.no_lex) ? 1 : 0;  // = GridArgs::ulex
-  while (rmax > 1 && mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rmax, boxcap, ym, ndy, ulex) > 80 * 1024) rmax--;
+  // the lexicographic kernel: same plan, its own LDS carve-up and occupancy
+  g.lex = ulex && !yaw && !c->has_pot && !g.gather && c->tune.grid_lex && mplx::lex_covers(c->dim, p.control);
+  auto lds_of = [&](int rm) -> size_t {
+    return g.lex ? mplx::lex_lds_bytes(c->dim, order, ndp, n_max, rm, boxcap)
+                 : mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rm, boxcap, ym, ndy, ulex);
+  };
+  while (rmax > 1 && lds_of(rmax) > 80 * 1024) rmax--;
   const int wpb = mplx::grid_waves_per_block();
   // The launch is persistent: every workgroup must be RESIDENT (a workgroup that waits for a slot starts its first,
   // statically assigned node only after another one has drained the whole queue).  What fits is the runtime's answer
   // for this instantiation (registers, LDS granules), not LDS bytes alone.
   auto resident = [&](int rm, size_t *lds_out) -> int {
-    const size_t lds = mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rm, boxcap, ym, ndy, ulex);
+    const size_t lds = lds_of(rm);
     *lds_out = lds;
     if (lds > 160 * 1024) return 0;
     int nb = -1;
+    // (the cache key tells the two kernels apart through its control word: bit 8 = the lexicographic kernel)
+    const int key = p.control | (g.lex ? 0x100 : 0);
     for (const auto &e : c->grid_occ)
-      if (e.control == p.control && e.pot == c->has_pot && e.lds == lds) nb = e.nb;
+      if (e.control == key && e.pot == c->has_pot && e.lds == lds) nb = e.nb;
     if (nb < 0) {
-      nb = mplx::grid_resident_blocks(c->dim, p.control, c->has_pot, lds);
+      nb = g.lex ? mplx::lex_resident_blocks(c->dim, p.control, lds) : mplx::grid_resident_blocks(c->dim, p.control, c->has_pot, lds);
       if (c->grid_occ.size() >= 8) c->grid_occ.clear();
-      c->grid_occ.push_back({p.control, c->has_pot, lds, nb});
+      c->grid_occ.push_back({key, c->has_pot, lds, nb});
       if (getenv("MPLX_GRID_VERBOSE"))
-        fprintf(stderr, "mplx: grid kernel control 0x%x pot %d rows/pass %d: LDS %zu B per workgroup, %d workgroups resident per CU\n",
-                p.control, (int)c->has_pot, rm, lds, nb);
+        fprintf(stderr, "mplx: %s kernel control 0x%x pot %d rows/pass %d: LDS %zu B per workgroup, %d workgroups resident per CU\n",
+                g.lex ? "lex" : "grid", p.control, (int)c->has_pot, rm, lds, nb);
     }
     const int by_lds = (int)((160 * 1024) / lds);
     return (nb > 0 && nb < by_lds) ? nb : by_lds;
@@ -615,7 +625,9 @@ int grid_work(mplx_ctx *c, mplx::GridArgs *a) {
 // has not zeroed the other set, so the sets are dropped and made afresh (zeroed) on the next use.
 int launch_grid(mplx_ctx *c, mplx::GridArgs *a) {
   if (int rc = grid_work(c, a)) return rc;
-  const hipError_t e = mplx::launch_expand_grid(c->dim, c->prm.control, *a, c->stream);
+  const hipError_t e = a->lex ? mplx::launch_expand_lex(c->dim, c->prm.control, *a, c->stream)
+                              : mplx::launch_expand_grid(c->dim, c->prm.control, *a, c->stream);
+  c->last_grid_lex = a->lex != 0;
   if (e != hipSuccess) {
     if (a->work) {
       (void)hipStreamSynchronize(c->stream);
@@ -855,6 +867,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.nU = c->nU;
     a.nodes = d_nodes; a.n_nodes = n_nodes; a.node_stride = node_stride;
     a.n_max = gp.n_max; a.rmax = gp.rmax; a.boxcap = gp.boxcap; a.grid_limit = gp.grid;
+    a.lex = gp.lex ? 1 : 0;
     a.dbg = c->tune.dbg;  // timing ablations, 0 in production
     a.ttab = (const double *)c->tables.p;
     a.tcnt = (const unsigned char *)c->tables.p + 64 * 64 * 8;
@@ -1510,6 +1523,10 @@ int mplx_set_lists_route(mplx_ctx *c, int route) {
 }
 
 int mplx_last_lists_route(const mplx_ctx *c) { return c ? c->last_route : MPLX_ERR_ARG; }
+int mplx_last_grid_kernel(const mplx_ctx *c) {
+  if (!c) return MPLX_ERR_ARG;
+  return c->last_route != MPLX_ROUTE_GRID ? MPLX_KERNEL_NONE : (c->last_grid_lex ? MPLX_KERNEL_LEX : MPLX_KERNEL_GRID);
+}
 
 int mplx_service(mplx_ctx *c, int mode, int64_t stats[4]) {
   if (!c) return MPLX_ERR_ARG;

@@ -58,6 +58,7 @@ struct mplx_ctx {
     int grid_rmax = 0, grid_boxcap = 0, grid_blocks = 0;  // MPLX_GRID_RMAX / _BOXCAP / _BLOCKS (0 = automatic)
     int grid_waves_per_cu = 0;                            // MPLX_GRID_WAVES_PER_CU: occupancy cap (0 = automatic)
     int grid_gather = -1, grid_sat = -1;                  // MPLX_GRID_GATHER / MPLX_GRID_SAT: force 0 / 1 (-1 = automatic)
+    bool grid_lex = true;                                 // MPLX_GRID_LEX=0: lexicographic tables run expand_grid_kernel like every other table
     bool grid_static = false;                             // MPLX_GRID_STATIC: static node striding instead of the work counters
     int grid_chunk = 0;                                   // MPLX_GRID_CHUNK: nodes per claim (0 = automatic)
     int grid_blocked = 0;                                 // MPLX_GRID_BLOCKED: contiguous shares per counter (A/B)
@@ -75,6 +76,7 @@ struct mplx_ctx {
   } tune;
   int lists_route = MPLX_ROUTE_AUTO;
   int last_route = MPLX_ROUTE_AUTO;
+  bool last_grid_lex = false;  // the last factorised launch went to expand_lex_kernel.hip (mplx_debug_last_kernel)
   int n_cus = 256;
 
   // tables of the tiled kernel (sample times, loop counts, reciprocals)

@@ -166,6 +166,7 @@ struct GridArgs {
   int32_t rmax;          // sample counts handled per round (rows of cell codes per axis entry)
   int32_t boxcap;        // dwords of LDS per wave for the staged blocked bits
   int32_t gather;        // 1: no box staging, the sample loops read the blocked-bit map directly (small control tables)
+  int32_t lex;           // host side only: 1 = this launch goes to expand_lex_kernel.hip (same arguments, its own LDS carve-up)
   // Dynamic node assignment (work == null: static striding).  Nodes differ a lot in work (dead at t = 0, free box, one
   // or several passes), and with a static assignment the waves lived only 46 % (C5) - 83 % (C4) of the kernel's
   // duration (SQ_WAVE_CYCLES against SQ_BUSY_CYCLES).  Chunks of work_chunk nodes: chunk w < W (the waves launched)
@@ -224,6 +225,13 @@ int grid_waves_per_block();
 // workgroups of the (dim, control, potential) instantiation resident per CU with `lds` bytes each; 0 = unknown
 int grid_resident_blocks(int dim, int control, bool pot, size_t lds);
 hipError_t launch_expand_grid(int dim, int control, const GridArgs &args, hipStream_t stream);
+// expand_lex_kernel.hip: the same function for lexicographic control tables without yaw on an occupancy map (GridArgs
+// with ulex == 1, pot == null, live == null, yaw unused); its own LDS carve-up
+bool lex_covers(int dim, int control);
+size_t lex_lds_bytes(int dim, int order, int ndp, int n_max, int rmax, int boxcap);
+int lex_waves_per_block();
+int lex_resident_blocks(int dim, int control, size_t lds);
+hipError_t launch_expand_lex(int dim, int control, const GridArgs &args, hipStream_t stream);
 // Blocked-bit map: 1 bit per cell in map order, 1 = occupied or outside the search
 // region; (n_cells + 31) / 32 dwords.
 // Summed-area table of the blocked bits: (d0+1)(d1+1)(d2+1) uint32 (2D: (d0+1)(d1+1)*2).

@@ -703,6 +703,11 @@ class EnvMap:
         return {_abi.ROUTE_AUTO: "none", _abi.ROUTE_DENSE: "dense", _abi.ROUTE_TILE: "tile",
                 _abi.ROUTE_GRID: "grid"}[code]
 
+    def last_grid_kernel(self):
+        """Which kernel of the GRID route the last expand_lists* call ran: "lex" (expand_lex_kernel.hip: lexicographic
+        control table, no yaw, occupancy map), "grid" (expand_grid_kernel.hip), "none" (another route)."""
+        return {0: "none", 1: "grid", 2: "lex"}[_abi.lib().mplx_last_grid_kernel(self._ctx)]
+
     def yaw_pin_stats(self):
         """(nodes re-expanded with the host libm's trig values, fix passes launched) since the context was made."""
         a, b = C.c_int64(), C.c_int64()
