@@ -290,7 +290,92 @@ def extra_plan(m):
             p3["speedup_engine_vs_reference_cpu"] = cpu["wall_ms"] / p3["engine_host_search"]["wall_ms"]
         return p3
 
+    def distance_3d(edge, batch):
+        """BASELINE config 5's planner as the reference's test_distance_map_planner_2d_with_yaw.cpp:48-104 runs it, on a voxel
+        map: plan (ACC, 27 controls); then a DistanceMapPlanner -- updatePotentialMap around the start, ACCxYAW with 3 yaw
+        rates (81 controls), yaw_max 0.5, iterativePlan inside the tunnel around the first trajectory (map_planner.cpp:394-430)."""
+        res = 0.1
+        grid = W.box_map([edge] * 3, res, 0.08, 4242, side_m=(0.5, 2.5))
+        flat = grid.ravel()
+        vals = [-1.0, 0.0, 1.0]
+        U3, U3y = W.grid_controls(vals, 3), W.grid_controls(vals, 3, yaw_rates=[-0.5, 0.0, 0.5])
+
+        def free_near(p):
+            cc = np.array([int(x / res) for x in p])
+            for r in range(0, 30):
+                for d in np.ndindex(2 * r + 1, 2 * r + 1, 2 * r + 1):
+                    q = cc + np.array(d) - r
+                    if np.all(q >= 0) and np.all(q < edge) and flat[q[0] + edge * (q[1] + edge * q[2])] == 0:
+                        return [(q[i] + 0.5) * res for i in range(3)]
+            raise RuntimeError("no free cell")
+
+        ps, pg = free_near([1.0, 1.0, 1.0]), free_near([edge * res - 1.0, edge * res - 1.2, edge * res - 1.5])
+        d = {"problem": "DistanceMapPlanner, 3D %d^3 voxels: plan (ACC, |U| = 27), then updatePotentialMap + ACCxYAW |U| = 81 + "
+                        "iterativePlan in the tunnel around the first trajectory (test_distance_map_planner_2d_with_yaw.cpp:48-104)" % edge}
+
+        def make(table):
+            pl = m.MapPlanner(3, device=0)
+            mu = m.MapUtil(3)
+            mu.setMap([0.0] * 3, [edge] * 3, flat.copy(), res)
+            pl.setMapUtil(mu)
+            pl.setVmax(2.0)
+            pl.setAmax(2.0)
+            pl.setDt(1.0)
+            pl.setU(table)
+            pl.setBatch(batch)
+            return pl
+
+        best = None
+        for _ in range(2):
+            first = make(U3)
+            t0 = time.perf_counter()
+            ok1 = first.plan(m.Waypoint(3, m.ACC, pos=ps), m.Waypoint(3, m.ACC, pos=pg))
+            t1 = time.perf_counter()
+            traj = first.getTraj()
+            s1 = first.summary()
+            first.close()
+            pl = make(U3y)
+            pl.setEpsilon(1.0)
+            pl.setSearchRadius([0.5] * 3)
+            pl.setPotentialRadius([1.0] * 3)
+            pl.setPotentialWeight(0.5)
+            pl.setGradientWeight(0)
+            t2 = time.perf_counter()
+            pl.updatePotentialMap(ps)
+            t3 = time.perf_counter()
+            pl.setYawmax(0.5)
+            ok2 = pl.iterativePlan(m.Waypoint(3, m.ACCxYAW, pos=ps), m.Waypoint(3, m.ACC, pos=pg), traj, 10)
+            t4 = time.perf_counter()
+            s2 = pl.summary()
+            pl.close()
+            rec = {"first_plan_ms": (t1 - t0) * 1e3, "potential_map_ms": (t3 - t2) * 1e3, "wall_ms": (t4 - t3) * 1e3,
+                   "ok": bool(ok1 and ok2), "cost": s2["cost"], "expansions": s2["expansions"], "closed": s2["closed"],
+                   "launches": s2["device_launches"], "first_plan_expansions": s1["expansions"], "batch": batch}
+            if best is None or rec["wall_ms"] < best["wall_ms"]:
+                best = rec
+        d["engine_host_search"] = best
+        if have_ref:
+            oenv = O.Env(3, O.ACC, U3, flat, [edge] * 3, [0.0] * 3, res, v_max=2.0, a_max=2.0, dt=1.0)
+            srow, grow = m.Waypoint(3, m.ACC, pos=ps).to_row(), m.Waypoint(3, m.ACC, pos=pg).to_row()
+            keys = ("wall_ms", "ok", "cost", "expansions", "closed", "potential_map_ms")
+            cpu = O.ref_scenario(oenv, srow, grow, "distance_yaw")
+            ad = min((O.ref_scenario(oenv, srow, grow, "distance_yaw", use_gpu=batch) for _ in range(2)), key=lambda r: r[1]["wall_ms"])
+            d["reference_cpu"] = dict({k: cpu[1][k] for k in keys}, first_plan_ms=cpu[0]["wall_ms"])
+            d["reference_planner_gpu_adapter"] = dict({k: ad[1][k] for k in keys}, first_plan_ms=ad[0]["wall_ms"],
+                                                      launches=ad[1]["device_launches"])
+            close = lambda a, b: abs(a - b) <= 1e-9 * abs(b)  # the per-sample heading cost uses cos / sin (glibc vs OCML)
+            d["agree"] = bool(cpu[1]["expansions"] == ad[1]["expansions"] == best["expansions"] and
+                              cpu[1]["closed"] == ad[1]["closed"] == best["closed"] and
+                              close(ad[1]["cost"], cpu[1]["cost"]) and close(best["cost"], cpu[1]["cost"]) and
+                              ad[1]["potential_sum"] == cpu[1]["potential_sum"])
+            d["speedup_engine_vs_reference_cpu"] = cpu[1]["wall_ms"] / best["wall_ms"]
+            d["speedup_adapter_vs_reference_cpu"] = cpu[1]["wall_ms"] / ad[1]["wall_ms"]
+            d["speedup_whole_stage_engine_vs_reference_cpu"] = ((cpu[1]["wall_ms"] + cpu[1]["potential_map_ms"]) /
+                                                                (best["wall_ms"] + best["potential_map_ms"]))
+        return d
+
     out["3D"] = problem_3d(120, True, 64, 2)
+    out["distance_map_3D"] = distance_3d(120, 64)
     # the larger problem: the reference's search alone takes ~20 s of one host core here, so one run each and no adapter leg
     # (its 2.8 x is the 120^3 figure: most of the adapter's time is the reference's own StateSpace, not get_succ)
     if os.environ.get("MPLX_BENCH_SKIP_PLAN_160") != "1":

@@ -1270,8 +1270,9 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
 template <int D, int K>
 __global__ __launch_bounds__(256) void grid_prescreen_kernel(const double *nodes, int64_t n_nodes, int64_t node_stride,
                                                              double yaw_max, YawPin yaw, int32_t *l_count, int32_t *live,
-                                                             uint32_t *live_n) {
+                                                             uint32_t *live_n, uint32_t *live_zero) {
   __shared__ uint32_t s_wave[4], s_base;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *live_zero = 0u;  // the counter of the next pre-screen launch of the stream
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   bool alive = false;
@@ -1512,13 +1513,12 @@ hipError_t launch_expand_grid(int dim, int control, const GridArgs &a, hipStream
   });
 }
 
-hipError_t launch_grid_prescreen(int dim, int control, const GridArgs &a, int32_t *live, uint32_t *live_n, hipStream_t s) {
-  if (a.n_nodes == 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(live_n, 0, 4, s);
-  if (e != hipSuccess) return e;
+hipError_t launch_grid_prescreen(int dim, int control, const GridArgs &a, int32_t *live, uint32_t *live_n, uint32_t *live_zero,
+                                 hipStream_t s) {
+  if (a.n_nodes == 0) return hipErrorInvalidValue;  // (the caller only pre-screens large frontiers; the counters must change hands)
   const unsigned blocks = (unsigned)((a.n_nodes + 255) / 256);
 #define MPLX_PS(D, K) hipLaunchKernelGGL((grid_prescreen_kernel<D, K>), dim3(blocks), dim3(256), 0, s, a.nodes, a.n_nodes, \
-                                         a.node_stride, a.yaw_max, a.yaw, a.l_count, live, live_n)
+                                         a.node_stride, a.yaw_max, a.yaw, a.l_count, live, live_n, live_zero)
   if (dim == 2 && control == 0x13) MPLX_PS(2, 2);
   else if (dim == 2 && control == 0x17) MPLX_PS(2, 3);
   else if (dim == 3 && control == 0x13) MPLX_PS(3, 2);

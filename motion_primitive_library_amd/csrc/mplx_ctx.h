@@ -137,7 +137,9 @@ struct mplx_ctx {
   std::vector<double> h_U;          // host copy of the control table (the fix pass needs the yaw rates)
   double h_uyaw[16] = {0};          // ... and of its distinct yaw rates, in the factorisation's order
   int64_t yaw_flagged = 0, yaw_fix_passes = 0;  // statistics (mplx_yaw_pin_stats)
-  mplx_detail::DevBuf live_list;          // pre-screen of yaw controls: surviving nodes (int32 each) + their number (last word)
+  mplx_detail::DevBuf live_list;          // pre-screen of yaw controls: surviving nodes (int32 each)
+  mplx_detail::DevBuf live_ctr;           // ... and their number: two counters used alternately (live_parity), zero between launches
+  int live_parity = 0;
   mplx_detail::DevBuf work_counter;       // dynamic node assignment of the factorised kernel (GridArgs::work)
   int work_parity = 0;                    // which of the two counter sets the next launch uses
   // workgroups of the factorised kernel resident per CU (grid_resident_blocks), cached per (control, potential, LDS)

@@ -202,7 +202,9 @@ struct GridArgs {
 };
 constexpr int kWorkCounters = 64;
 // lane-per-node validate_yaw(t = 0) over a whole frontier (expand_grid_kernel.hip); fills live / live_n of `a`'s launch
-hipError_t launch_grid_prescreen(int dim, int control, const GridArgs &a, int32_t *live, uint32_t *live_n, hipStream_t s);
+// (live_n is zero when the launch begins; the launch zeroes live_zero, the counter of the NEXT pre-screen of the stream)
+hipError_t launch_grid_prescreen(int dim, int control, const GridArgs &a, int32_t *live, uint32_t *live_n, uint32_t *live_zero,
+                                 hipStream_t s);
 // Packing of the used list prefixes for the copy back to the host (pack_kernel.hip).
 constexpr int kPackRows = 24;
 struct PackArgs {

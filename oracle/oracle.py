@@ -275,7 +275,8 @@ def ref_scenario(env, start_row, goal_row, scenario, use_gpu=False, via_base=Fal
     """The scenarios of the reference's own test programs end to end, on the reference's MapPlanner:
     "distance" (test_distance_map_planner_2d.cpp), "distance_yaw" (..._with_yaw.cpp), "distance_iterative"
     (..._iterative.cpp), "yaw" (test_planner_2d_with_yaw.cpp; one stage), "prior_traj"
-    (test_planner_2d_with_prior_traj.cpp).  env.U must be the {-0.5, 0, 0.5}^2 table.  use_gpu: MPL::GpuMapPlanner
+    (test_planner_2d_with_prior_traj.cpp).  env.U must be a {-u, 0, u}^D table (the tests': {-0.5, 0, 0.5}^2); Dim 3 runs
+    the same flows on a voxel map.  use_gpu: MPL::GpuMapPlanner
     instead of MPL::MapPlanner in every stage (> 1: speculative batch size).  Returns the two stages' summaries."""
     lib = _LIBS.setdefault("ref_planner", C.CDLL(REF_PLANNER_SO))
     for fn in (lib.mpl_ref_scenario, lib.mpl_ref_scenario_via_base):
@@ -302,6 +303,9 @@ def ref_scenario(env, start_row, goal_row, scenario, use_gpu=False, via_base=Fal
                     "segments": o.segments, "cost": o.cost, "total_time": o.total_time, "J": list(o.J),
                     "wall_ms": o.wall_ms, "device_launches": o.hm_size, "traj_checksum": chk[i]})
     res[1]["region_cells"], res[1]["potential_sum"] = region.value, pot.value
+    if hasattr(lib, "mpl_ref_last_prep_ms"):
+        lib.mpl_ref_last_prep_ms.restype = C.c_double
+        res[1]["potential_map_ms"] = float(lib.mpl_ref_last_prep_ms())  # wall time of updatePotentialMap (stage 2)
     return res
 
 

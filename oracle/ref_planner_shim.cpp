@@ -149,6 +149,8 @@ void fill_out(MPL::MapPlanner<D> &pl, bool ok, double ms, int launches, mpl_ref_
   *checksum = c;
 }
 
+double g_last_prep_ms = 0;  // wall time of the last stage-2 updatePotentialMap (mpl_ref_last_prep_ms)
+
 /* mode: 0 test_distance_map_planner_2d, 1 ..._with_yaw, 2 ..._iterative, 3 test_planner_2d_with_yaw (one stage),
  *       4 test_planner_2d_with_prior_traj (VEL plan, then JRK-state plan guided by it) */
 template <int D, class PlannerT>
@@ -265,7 +267,9 @@ int run_scenario(const mpl_oracle_env *e, const double *start_row, const double 
   second.setPotentialRadius(rad);
   second.setPotentialWeight(0.5);
   second.setGradientWeight(0);
+  t0 = now();
   second.updatePotentialMap(start.pos);
+  g_last_prep_ms = ms_since(t0);
   t0 = now();
   if (with_yaw) {
     start.use_yaw = true;
@@ -333,7 +337,14 @@ void set_batch(MPL::GpuMapPlanner<D> &p, int b) { p.setBatch(b > 1 ? b : 1); }
 extern "C" int mpl_ref_scenario(const mpl_oracle_env *env, const double *start, const double *goal, int use_gpu,
                                 int mode, mpl_ref_plan_out *out2, double *checksum2, int64_t *region_cells,
                                 int64_t *potential_sum) {
-  if (!env || !start || !goal || !out2 || env->dim != 2 || mode < 0 || mode > 4) return -1;
+  if (!env || !start || !goal || !out2 || (env->dim != 2 && env->dim != 3) || mode < 0 || mode > 4) return -1;
+  if (env->dim == 3) {
+    // the same flows on a voxel map (BASELINE config 5's planner: potential map + ACCxYAW, 3^3 x 3 yaw rates = 81 controls)
+    if (use_gpu)
+      return run_scenario<3, MPL::GpuMapPlanner<3>>(env, start, goal, mode, use_gpu, out2, checksum2, region_cells,
+                                                    potential_sum);
+    return run_scenario<3, MPL::MapPlanner<3>>(env, start, goal, mode, 1, out2, checksum2, region_cells, potential_sum);
+  }
   if (use_gpu)
     return run_scenario<2, MPL::GpuMapPlanner<2>>(env, start, goal, mode, use_gpu, out2, checksum2, region_cells,
                                                   potential_sum);
@@ -588,6 +599,9 @@ extern "C" int mpl_ref_lpastar(const mpl_oracle_env *env, const double *start, c
 }
 
 /* the same scenarios with the drop-in held through a MapPlanner<D> base pointer (ViaBase above) */
+/* wall time (ms) of updatePotentialMap in the last mpl_ref_scenario* call of this process (modes 0 - 2) */
+extern "C" double mpl_ref_last_prep_ms(void) { return g_last_prep_ms; }
+
 extern "C" int mpl_ref_scenario_via_base(const mpl_oracle_env *env, const double *start, const double *goal, int batch,
                                          int mode, mpl_ref_plan_out *out2, double *checksum2, int64_t *region_cells,
                                          int64_t *potential_sum) {

@@ -2,7 +2,7 @@
 # round 4: dynamic instructions per node of the two factorised kernels (MPLX_GRID_LEX=1: expand_lex_kernel, 0: expand_grid_kernel)
 # on the BASELINE configurations; MPLX_TILE_DBG ablations as in valu_phase_split.sh.  Run through gpurun.
 OUT=$PWD/gpurun_out/valu_r04; mkdir -p $OUT; export TMPDIR=/tmp
-for W in ${WL:-C2 C3 C4}; do for LEX in 1 0; do for DBG in ${DBGS:-0}; do
+for W in ${WL:-C2 C3 C4}; do for LEX in ${LEXS:-1 0}; do for DBG in ${DBGS:-0}; do
   MPLX_GRID_LEX=$LEX MPLX_TILE_DBG=$DBG timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -f csv -d $OUT/${W}_${LEX}_$DBG -o p -- python bench.py --no-extras --no-cpu-baseline --workload $W --steps 3 --warmup 1 --placement-trials 1 --spinup-ms 0 > $OUT/${W}_${LEX}_$DBG.log 2>&1
   python - $OUT/${W}_${LEX}_$DBG $W $LEX $DBG <<'PY'
 import csv, collections, glob, sys

@@ -1,5 +1,6 @@
 """GPU: BASELINE config C1 end to end on the engine -- MapPlanner.plan() with
 get_succ served by the MI355X -- against the README pins and the oracle run."""
+import os
 import time
 
 import numpy as np
@@ -278,3 +279,72 @@ def test_state_mismatch_counter_counts(engine, monkeypatch):
     s = pl.summary()
     pl.close()
     assert s["state_mismatches"] == 1, s
+
+
+def test_distance_map_planner_3d_with_yaw_three_ways(engine):
+    """BASELINE config 5's planner (DistanceMapPlanner: potential map + ACCxYAW) as the reference's
+    test_distance_map_planner_2d_with_yaw.cpp:48-104 runs it, on a VOXEL map: plan, then updatePotentialMap + 81 controls +
+    iterativePlan in the tunnel (map_planner.cpp:394-430) -- the reference's MapPlanner on the CPU, the same planner with
+    the drop-in adapter, and the engine's planner must agree on expansions, closed set, cost and the potential map."""
+    from oracle import oracle as O
+    if not os.path.exists(O.REF_PLANNER_SO):
+        pytest.skip("oracle/_ref/libmpl_ref_planner.so not built")
+    m = engine
+    W = m.workloads
+    edge, res = 60, 0.1
+    grid = W.box_map([edge] * 3, res, 0.08, 4242, side_m=(0.5, 2.5))
+    flat = grid.ravel()
+    vals = [-1.0, 0.0, 1.0]
+    U3, U3y = W.grid_controls(vals, 3), W.grid_controls(vals, 3, yaw_rates=[-0.5, 0.0, 0.5])
+
+    def free_near(p):
+        cc = np.array([int(x / res) for x in p])
+        for r in range(0, 30):
+            for d in np.ndindex(2 * r + 1, 2 * r + 1, 2 * r + 1):
+                q = cc + np.array(d) - r
+                if np.all(q >= 0) and np.all(q < edge) and flat[q[0] + edge * (q[1] + edge * q[2])] == 0:
+                    return [(q[i] + 0.5) * res for i in range(3)]
+
+    ps, pg = free_near([1.0, 1.0, 1.0]), free_near([edge * res - 1.0, edge * res - 1.2, edge * res - 1.5])
+    oenv = O.Env(3, O.ACC, U3, flat, [edge] * 3, [0.0] * 3, res, v_max=2.0, a_max=2.0, dt=1.0)
+    srow, grow = m.Waypoint(3, m.ACC, pos=ps).to_row(), m.Waypoint(3, m.ACC, pos=pg).to_row()
+    cpu = O.ref_scenario(oenv, srow, grow, "distance_yaw")
+    assert cpu[0]["ok"] and cpu[1]["ok"] and cpu[1]["expansions"] > 100
+    for batch in (1, 64):
+        gpu = O.ref_scenario(oenv, srow, grow, "distance_yaw", use_gpu=batch)
+        for stage in (0, 1):
+            for k in ("ok", "closed", "opened", "expansions", "segments", "total_time", "J"):
+                assert gpu[stage][k] == cpu[stage][k], (batch, stage, k, gpu[stage][k], cpu[stage][k])
+            assert abs(gpu[stage]["cost"] - cpu[stage]["cost"]) <= 1e-9 * abs(cpu[stage]["cost"])
+        assert gpu[1]["region_cells"] == cpu[1]["region_cells"] and gpu[1]["potential_sum"] == cpu[1]["potential_sum"]
+
+    def make(table):
+        pl = m.MapPlanner(3, device=0)
+        mu = m.MapUtil(3)
+        mu.setMap([0.0] * 3, [edge] * 3, flat.copy(), res)
+        pl.setMapUtil(mu)
+        pl.setVmax(2.0)
+        pl.setAmax(2.0)
+        pl.setDt(1.0)
+        pl.setU(table)
+        pl.setBatch(64)
+        return pl
+
+    first = make(U3)
+    assert first.plan(m.Waypoint(3, m.ACC, pos=ps), m.Waypoint(3, m.ACC, pos=pg))
+    assert first.summary()["expansions"] == cpu[0]["expansions"]
+    traj = first.getTraj()
+    first.close()
+    pl = make(U3y)
+    pl.setEpsilon(1.0)
+    pl.setSearchRadius([0.5] * 3)
+    pl.setPotentialRadius([1.0] * 3)
+    pl.setPotentialWeight(0.5)
+    pl.setGradientWeight(0)
+    pl.updatePotentialMap(ps)
+    pl.setYawmax(0.5)
+    assert pl.iterativePlan(m.Waypoint(3, m.ACCxYAW, pos=ps), m.Waypoint(3, m.ACC, pos=pg), traj, 10)
+    s = pl.summary()
+    pl.close()
+    assert s["expansions"] == cpu[1]["expansions"] and s["closed"] == cpu[1]["closed"]
+    assert abs(s["cost"] - cpu[1]["cost"]) <= 1e-9 * cpu[1]["cost"]
