@@ -57,6 +57,13 @@ FRONTIER_KW = {"C2": (2.0, 0.5), "C3": (3.0, 0.5, 2.0, 1.0), "C4": (2.0, 0.5), "
 KERNEL_NAME = {"grid": "expand_grid_kernel", "tile": "expand_tile_kernel", "dense": "expand_kernel", "none": "expand_kernel"}
 
 
+def kernel_name(env, route):
+    """The kernel the last lists launch ran: the GRID route has two (mplx_last_grid_kernel)."""
+    if route == "grid" and env.last_grid_kernel() == "lex":
+        return "expand_lex_kernel"
+    return KERNEL_NAME[route]
+
+
 def algorithmic_bytes(wl, n_nodes, n_emit, n_samples):
     """B_alg = N*S_wp + |U|*udim*8 + samples*(1 + r/8) + N_emit*(S_wp + 8 + 4)."""
     s_wp = (4 * wl.dim + 2) * 8
@@ -68,7 +75,7 @@ def measured_traffic(workload, kernel):
     """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, each its own
     run; profiles/README.md): bench.py cannot collect counters itself, so it reports the figure measured for
     this workload + kernel, or None when no such profile is committed."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (rnd, workload.lower()))
         try:
             rec = json.load(open(path))
@@ -129,13 +136,14 @@ def run_config(m, wl, steps, warmup, device=0, route=None):
     spin_up(env, fr, lists, 9 if route else 30)
     ms = time_lists(env, fr, lists, steps, warmup)
     route = env.last_lists_route()
+    kname = kernel_name(env, route)
     lists.free()
     fr.free()
     env.close()
     b_alg = algorithmic_bytes(wl, wl.n_nodes, n_emit, n_samples)
     return {"kernel_ms": ms, "pairs_per_s": wl.n_pairs / (ms * 1e-3), "algorithmic_bytes_per_launch": b_alg,
             "achieved_GBps": b_alg / (ms * 1e-3) / 1e9, "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "pairs": wl.n_pairs, "emitted": n_emit, "finite": n_fin, "map_samples": n_samples, "kernel": KERNEL_NAME[route]}
+            "pairs": wl.n_pairs, "emitted": n_emit, "finite": n_fin, "map_samples": n_samples, "kernel": kname}
 
 
 def cpu_baseline(wl, target_seconds=12.0):
@@ -179,21 +187,22 @@ def cpu_baseline(wl, target_seconds=12.0):
 
 
 # ------------------------------------------------------------------ extras (N = 1)
-def extra_e2e(m, wl, reps=3):
+def extra_e2e(m, wl, reps=3, want_state=True):
     """The same batch through host pointers (mplx_expand_lists): H2D of the frontier, kernel, D2H of the used list
-    prefixes into the caller's pageable arrays -- SURVEY 8(d) "end-to-end incl. H2D + D2H"."""
+    prefixes into the caller's pageable arrays -- SURVEY 8(d) "end-to-end incl. H2D + D2H".  want_state=False: the
+    edges-only output (action + cost + hash, 20 B per successor), what the engine's own search asks for."""
     env = m.EnvMap(wl.dim, 0)
     wl.apply(env)
-    out = env.expand_lists(wl.nodes, want_iters=False)  # warm-up: code object, device scratch, page faults
+    out = env.expand_lists(wl.nodes, want_state=want_state, want_iters=False)  # warm-up: code object, device scratch, page faults
     emitted = int(out["count"].sum(dtype=np.int64))
     times = []
     for _ in range(reps):
         t0 = time.perf_counter()
-        out = env.expand_lists(wl.nodes, want_iters=False, out=out)  # buffers reused, as a C caller would
+        out = env.expand_lists(wl.nodes, want_state=want_state, want_iters=False, out=out)  # buffers reused, as a C caller would
         times.append(time.perf_counter() - t0)
     env.close()
     F = 4 * wl.dim + 2
-    bytes_out = wl.n_nodes * 4 + emitted * (4 + 8 + 8 + F * 8)
+    bytes_out = wl.n_nodes * 4 + emitted * (4 + 8 + 8 + (F * 8 if want_state else 0))
     best = min(times)
     return {"e2e_ms_per_step": best * 1e3, "e2e_pairs_per_s": wl.n_pairs / best, "bytes_copied_back": bytes_out,
             "copy_back_GBps": bytes_out / best / 1e9, "calls_ms": [round(t * 1e3, 2) for t in times],
@@ -410,8 +419,12 @@ def extras(m, args, wl, out):
         lists.free()
         fr.free()
         env.close()
+        e2e = extra_e2e(m, wl, want_state=False)
         return {"kernel_ms": ms, "value": wl.n_pairs / (ms * 1e-3), "unit": "pairs/s",
-                "what": "resident lists without the Waypoint rows (action + cost + hash: 20 B per successor instead of 132)"}
+                "e2e_ms_per_step": e2e["e2e_ms_per_step"], "e2e_pairs_per_s": e2e["e2e_pairs_per_s"],
+                "e2e_bytes_copied_back": e2e["bytes_copied_back"], "e2e_calls_ms": e2e["calls_ms"],
+                "what": "resident lists without the Waypoint rows (action + cost + hash: 20 B per successor instead of 132); "
+                        "e2e_*: the same through mplx_expand_lists on host pointers"}
     leg("edges_only", edges_only)
 
     def wavefront():
@@ -428,6 +441,7 @@ def extras(m, args, wl, out):
         spin_up(env, fr_w, lists)
         rounds = [(time_lists(env, fr_r, lists, args.steps, 2), time_lists(env, fr_w, lists, args.steps, 2)) for _ in range(3)]
         ms_r, ms_w = sorted(r[0] for r in rounds)[1], sorted(r[1] for r in rounds)[1]
+        kname = kernel_name(env, env.last_lists_route())
         lists.free()
         fr_w.free()
         fr_r.free()
@@ -437,7 +451,7 @@ def extras(m, args, wl, out):
                 "ratio_to_random": ms_w / ms_r, "kernel_ms_cold": cold, "rounds_ms": [[round(a, 4), round(b, 4)] for a, b in rounds],
                 "algorithmic_bytes_per_launch": b_alg, "achieved_GBps": b_alg / (ms_w * 1e-3) / 1e9,
                 "frac": b_alg / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, "pairs": wl.n_pairs, "emitted": n_emit, "finite": n_fin,
-                "map_samples": n_samples, "kernel": KERNEL_NAME["grid"],
+                "map_samples": n_samples, "kernel": kname,
                 "what": "same workload, frontier = the first %d open-list nodes of an eps = 0 search from the map centre; "
                         "median of 3 alternating rounds against the random frontier on the same allocation of the lists "
                         "(kernel_ms_cold: %d launches straight after set-up, no clock spin-up)" % (wl.n_nodes, args.steps)}
@@ -792,7 +806,7 @@ def main():
         # `value` is the wall clock for every N (round-3 advice: the HIP-event figure of N > 1 was not comparable with the
         # N = 1 definition or with earlier rounds); the slowest rank's HIP-event time is reported beside it.
         ms_per_step = ms_wall
-        out_kernel = KERNEL_NAME[route]
+        out_kernel = kernel_name(env, route)
         achieved = b_alg / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "node-expansions/s (frontier x |U| pair evaluations per second)",
@@ -824,7 +838,7 @@ def main():
                 "output_placement": {"probe_ms": [round(x, 4) for x in placement["probe_ms"]], "chosen": placement["chosen"],
                                      "what": "allocations of the output lists probed before the warm-up, fastest kept "
                                              "(see --placement-trials)"},
-                "kernel": {"grid": "expand_grid_kernel (per-axis factorised tables in LDS)", "tile": "expand_tile_kernel",
+                "kernel": "expand_lex_kernel (per-axis factorised tables in LDS, lexicographic control table)" if out_kernel == "expand_lex_kernel" else {"grid": "expand_grid_kernel (per-axis factorised tables in LDS)", "tile": "expand_tile_kernel",
                            "dense": "expand_kernel + compact_lists_kernel", "none": "expand_kernel"}[route],
             },
             "roofline": {
@@ -879,6 +893,10 @@ def main():
                 # BASELINE's ">= 100 x the CPU" holds for lists that stay in HBM (`value`) and for an on-device consumer;
                 # through host pointers the PCIe link is the bound and the ratio is this one
                 out["speedup_vs_cpu_all_cores_e2e_host_pointers"] = out["e2e"]["e2e_pairs_per_s"] / out["cpu_baseline"]["value"]
+                if isinstance(out.get("edges_only"), dict) and "e2e_pairs_per_s" in out["edges_only"]:
+                    out["speedup_vs_cpu_all_cores_e2e_edges_only"] = out["edges_only"]["e2e_pairs_per_s"] / out["cpu_baseline"]["value"]
+                if isinstance(out.get("wavefront"), dict) and "ratio_to_random" in out["wavefront"]:
+                    out["wavefront_ratio_to_random"] = out["wavefront"]["ratio_to_random"]
                 out["speedup_note"] = ("speedup_vs_cpu_all_cores: HBM-resident lists (the metric's configuration); "
                                        "..._e2e_host_pointers: the same batch through mplx_expand_lists on pageable host "
                                        "arrays, bound by the PCIe link (2.8 GB of list entries per step)")

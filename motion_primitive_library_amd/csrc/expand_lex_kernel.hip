@@ -49,47 +49,52 @@ constexpr int kLexUB = 8;          // samples per step of the sample loop
 // shared tables at compile-time offsets
 constexpr int kShUval = 0;     // double[3][16]
 constexpr int kShTc = 384;     // uchar[64]
-constexpr int kShTt = 448;     // double[n_max + 1][tts]
+constexpr int kShTt = 448;     // double[(n_max + 1)(n_max + 2) / 2]: row nn at nn (nn + 1) / 2 (see lex_tt_entries)
 
 // bytes of the fixed-size per-wave tables = offset of the first run-time sized one (the prefix-hash table)
-__host__ __device__ constexpr int lex_fixed_bytes(int D, int K) {
+// (TS = table stride: entries reserved per axis, 8 or 16 -- the LANE layout is one 16-lane DPP row per axis either way)
+__host__ __device__ constexpr int lex_fixed_bytes(int D, int K, int TS) {
   const int F = 4 * D + 2, KQ = K == 3 ? 4 : K;
-  int w = (F * 8 + 15) & ~15;                                                                        // node
-  w += 128 + D * 64 + D * 64 * KQ + D * 128 * (K - 1) + (K == 3 ? D * 128 : 0) + D * 16 + D * 16;  // misc .. vlc
-  w = (w + 128 + 7) & ~7;                                                                            // rowmap
-  return w + 128;                                                                                    // drop
+  int w = (F * 8 + 15) & ~15;                                                                                  // node
+  w += 128 + D * TS * 4 + D * TS * 4 * KQ + D * TS * 8 * (K - 1) + (K == 3 ? D * TS * 8 : 0) + D * TS + D * TS;  // misc .. vlc
+  w = (w + 15) & ~15;
+  return (w + 128 + 7) & ~7;                                                                                   // rowmap
 }
+// the accumulated sample times of count nn (tc[nn] <= nn + 1 of them) start at entry nn (nn + 1) / 2 of the shared table
+__host__ __device__ constexpr int lex_tt_entries(int n_max) { return (n_max + 1) * (n_max + 2) / 2; }
 
 // per-wave tables at compile-time offsets from the wave's block
-template <int D, int K>
+template <int D, int K, int TS>
 struct LexW {
   static constexpr int F = 4 * D + 2;
   static constexpr int KQ = K == 3 ? 4 : K;
   static constexpr int NODE = 0;                                   // double[F]
   static constexpr int MISC = (F * 8 + 15) & ~15;                  // int[32]
-  static constexpr int EFLAG = MISC + 128;                         // int[D][16]
-  static constexpr int EQ = EFLAG + D * 64;                        // int[D][16][KQ]
-  static constexpr int EST = EQ + D * 64 * KQ;                     // double[D][16][K - 1]
-  static constexpr int UQ = EST + D * 128 * (K - 1);               // double[D][16] (K = 3)
-  static constexpr int VL = UQ + (K == 3 ? D * 128 : 0);           // uchar[D][16]: values inside the limits, in order
-  static constexpr int VLC = VL + D * 16;                          // uchar[D][16]: ... whose row the current count needs
-  static constexpr int ROWMAP = VLC + D * 16;                      // ushort[64]
-  static constexpr int DROP = (ROWMAP + 128 + 7) & ~7;             // uint64[16]: per step of phase D, the dropped lanes
-  static constexpr int HP = DROP + 128;                            // uint64[PN]; then the cell rows, then the box
-  static_assert(HP == lex_fixed_bytes(D, K), "LexLds sizes the workgroup's LDS from lex_fixed_bytes");
+  static constexpr int EFLAG = MISC + 128;                         // int[D][TS]
+  static constexpr int EQ = EFLAG + D * TS * 4;                    // int[D][TS][KQ]
+  static constexpr int EST = EQ + D * TS * 4 * KQ;                 // double[D][TS][K - 1]
+  static constexpr int UQ = EST + D * TS * 8 * (K - 1);            // double[D][TS] (K = 3)
+  static constexpr int VL = UQ + (K == 3 ? D * TS * 8 : 0);        // uchar[D][TS]: values inside the limits, in order
+  static constexpr int VLC = VL + D * TS;                          // uchar[D][TS]: ... whose row the current count needs
+  static constexpr int ROWMAP = (VLC + D * TS + 15) & ~15;         // ushort[64]
+  static constexpr int HP = (ROWMAP + 128 + 7) & ~7;               // uint64[PN]; then (run-time sized) the dropped lanes
+                                                                   // per step of phase D, the cell rows, the box
+  static_assert(HP == lex_fixed_bytes(D, K, TS), "LexLds sizes the workgroup's LDS from lex_fixed_bytes");
 };
 enum { LM_BASE = 0, LM_NODEQ = 4 };  // misc words: cell of the node per axis [3]; lattice integers of the node [D][4]
 
 // run-time part of the carve-up, shared by host (size) and device (offsets)
 struct LexLds {
-  int tts, rowcap, o_wave0, w_cell, w_box, wave_bytes, total;
-  __host__ __device__ LexLds(int D, int K, int waves, int ndp, int n_max, int rmax, int boxcap) {
+  int tts, rowcap, o_wave0, w_drop, w_cell, w_box, wave_bytes, total;
+  __host__ __device__ LexLds(int D, int K, int waves, int ndp, int nU, int n_max, int rmax, int boxcap) {
     tts = n_max + 1;
     rowcap = rmax * tts;
-    o_wave0 = (kShTt + (n_max + 1) * tts * 8 + 15) & ~15;
-    int w = lex_fixed_bytes(D, K);
+    o_wave0 = (kShTt + lex_tt_entries(n_max) * 8 + 15) & ~15;
+    int w = lex_fixed_bytes(D, K, ndp <= 8 ? 8 : 16);
     const int PN = (D == 3) ? ndp * ndp : ndp;
     w += PN * 8;
+    w_drop = w;
+    w += ((nU + 63) >> 6) * 8;  // uint64 per step of phase D: the lanes whose successor equals the node (dropped)
     w_cell = w;
     w += D * ndp * rowcap + 8;  // + 8: the sample loop reads up to 7 codes past a row
     w = (w + 3) & ~3;
@@ -158,7 +163,7 @@ __device__ __forceinline__ void lex_fold_entry(uint64_t &h, const int *eq, int e
   }
 }
 
-template <int D, int K>
+template <int D, int K, int TS>
 __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   // the argument block is read where it lies (scalar loads next to their uses), see expand_grid_kernel.hip
@@ -166,10 +171,10 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
   KernargPtr Ak = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
   (void)A_kernarg;
 #define A (*Ak)
-  typedef LexW<D, K> W;
+  typedef LexW<D, K, TS> W;
   constexpr int F = W::F, KQ = W::KQ;
   const int ndp = A.ndp, RM = A.rmax;
-  const LexLds L(D, K, kLexWPB, ndp, A.n_max, RM, A.boxcap);
+  const LexLds L(D, K, kLexWPB, ndp, A.nU, A.n_max, RM, A.boxcap);
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const double *s_uval = (const double *)(smem + kShUval);
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
   unsigned char *s_vl = wb + W::VL;
   unsigned char *s_vlc = wb + W::VLC;
   unsigned short *s_rowmap = (unsigned short *)(wb + W::ROWMAP);
-  uint64_t *s_drop = (uint64_t *)(wb + W::DROP);
+  uint64_t *s_drop = (uint64_t *)(wb + L.w_drop);
   uint64_t *s_hp = (uint64_t *)(wb + W::HP);
   unsigned char *s_cell = wb + L.w_cell;
   unsigned int *s_box = (unsigned int *)(wb + L.w_box);
@@ -231,13 +236,12 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
   // ---- once per (persistent) workgroup: shared read-only tables
   {
     double *uv = (double *)(smem + kShUval);
-    if (threadIdx.x < D * 16) uv[threadIdx.x] = A.uvals[threadIdx.x];
+    if (threadIdx.x < D * TS) uv[threadIdx.x] = A.uvals[(threadIdx.x / TS) * 16 + threadIdx.x % TS];
     if (threadIdx.x < 64) smem[kShTc + threadIdx.x] = A.tcnt[threadIdx.x];
     double *tt = (double *)(smem + kShTt);
-    const int ntt = (A.n_max + 1) * tts;
-    for (int i = threadIdx.x; i < ntt; i += kLexBT) {
+    for (int i = threadIdx.x; i < (A.n_max + 1) * tts; i += kLexBT) {
       const int nn = i / tts, k = i - nn * tts;
-      tt[i] = A.ttab[nn * kLexTabStride + k];
+      if (k <= nn) tt[((nn * (nn + 1)) >> 1) + k] = A.ttab[nn * kLexTabStride + k];  // (tc[nn] <= nn + 1)
     }
   }
   __syncthreads();  // the only workgroup barrier
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
   const int ax_l = lane >> 4, jv_l = lane & 15;
   const bool ent_lane = lane < D * 16 && jv_l < (ax_l == 0 ? nd[0] : (ax_l == 1 ? nd[1] : nd[2]));
   const unsigned int below16 = (1u << jv_l) - 1u;
+  const int ti_l = ax_l * TS + jv_l;  // this lane's entry in the tables
   int it_next = 0;
 
   for (int it = it0; it < NN; it = it_next) {
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
       const double p = s_node[0 * D + ax];
       const double v = (K >= 2) ? s_node[1 * D + ax] : 0.0;
       const double a = (K >= 3) ? s_node[2 * D + ax] : 0.0;
-      const double u = s_uval[lane];
+      const double u = s_uval[ti_l];
       const double org = ax == 0 ? A.org0 : (ax == 1 ? A.org1 : A.org2);
       Ax<K> q;
       q.init(p, v, a, 0.0, u);
@@ -291,12 +296,12 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
       const double nv_ = q.template vel<true>(T);
       const double na_ = q.template acc<true>(T);
       // fields of order < K - 1; order K - 1 is (0.0 + u*T) + x0, order K is 0.0 + u, higher ones are 0
-      if (K >= 3) s_uq[lane] = q.top_quotient();
-      if (K >= 2) s_est[lane * (K - 1) + 0] = np_;
-      if (K >= 3) s_est[lane * (K - 1) + 1] = nv_;
-      s_eq[lane * KQ + 0] = quantise(np_, 0.01, A.R001);
-      if (K >= 2) s_eq[lane * KQ + 1] = quantise(nv_, 0.1, A.R01);
-      if (K >= 3) s_eq[lane * KQ + 2] = quantise(na_, 0.1, A.R01);
+      if (K >= 3) s_uq[ti_l] = q.top_quotient();
+      if (K >= 2) s_est[ti_l * (K - 1) + 0] = np_;
+      if (K >= 3) s_est[ti_l * (K - 1) + 1] = nv_;
+      s_eq[ti_l * KQ + 0] = quantise(np_, 0.01, A.R001);
+      if (K >= 2) s_eq[ti_l * KQ + 1] = quantise(nv_, 0.1, A.R01);
+      if (K >= 3) s_eq[ti_l * KQ + 2] = quantise(na_, 0.1, A.R01);
       flag = (valid ? 1 : 0) | ((p == np_) ? 2 : 0) | (n << 8);
       if (A.sat != nullptr && valid) {
         // range of p(t) over [0, T] of this entry, as cells with one cell of slack on both sides;
@@ -326,14 +331,14 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
         s_misc[LM_NODEQ + i * 4 + f] = f == 0 ? quantise(x, 0.01, A.R001) : quantise(x, 0.1, A.R01);
       }
     }
-    if (lane < D * 16) s_eflag[lane] = flag;
+    if (lane < D * 16 && jv_l < TS) s_eflag[ti_l] = flag;
     // per axis, the values that pass the limits, in order: 16-bit fields of one ballot
     const unsigned long long vm = __ballot((flag & 1) != 0);
     const unsigned int vm_lo = (unsigned int)vm, vm_hi = (unsigned int)(vm >> 32);
     const int nv0 = __popc(vm_lo & 0xffffu), nv1 = __popc(vm_lo >> 16), nv2 = (D == 3) ? __popc(vm_hi & 0xffffu) : 1;
     if (flag & 1) {
       const unsigned int m16 = (ax_l == 0 ? vm_lo : (ax_l == 1 ? (vm_lo >> 16) : vm_hi)) & 0xffffu;
-      s_vl[ax_l * 16 + __popc(m16 & below16)] = (unsigned char)jv_l;
+      s_vl[ax_l * TS + __popc(m16 & below16)] = (unsigned char)jv_l;
     }
     // the sets of sample counts per axis (bit n of a 64-bit word, as two halves) by row reduction
     unsigned long long nm = 0;
@@ -364,10 +369,10 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
       for (int x = lane; x < n01; x += 64) {
         const int a_ = (int)(((float)x + 0.5f) * r1);
         const int b_ = x - a_ * nv1;
-        const int j0 = s_vl[a_], j1 = s_vl[16 + b_];
+        const int j0 = s_vl[a_], j1 = s_vl[TS + b_];
         uint64_t h = 0;
         lex_fold_entry<K>(h, s_eq, j0);
-        lex_fold_entry<K>(h, s_eq, 16 + j1);
+        lex_fold_entry<K>(h, s_eq, TS + j1);
         s_hp[__umul24(j0, ndp) + j1] = h;
       }
     } else {
@@ -466,14 +471,14 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
           const int nn = __ffsll((long long)t) - 1;
           const int cn = (int)s_tc[nn];
           const float inv_cn = __builtin_amdgcn_rcpf((float)cn);
-          const double *trow = s_tt + nn * tts;
+          const double *trow = s_tt + ((nn * (nn + 1)) >> 1);
           // the row of (entry, count nn) is only read by pairs whose count IS nn, i.e. by entries with n_entry <= nn
           const unsigned long long fm = __ballot((flag & 1) && (flag >> 8) <= nn);
           const unsigned int fm_lo = (unsigned int)fm, fm_hi = (unsigned int)(fm >> 32);
           lex_sync();  // (the previous count's list has been read)
           if ((fm >> lane) & 1ull) {
             const unsigned int m16 = (ax_l == 0 ? fm_lo : (ax_l == 1 ? (fm_lo >> 16) : fm_hi)) & 0xffffu;
-            s_vlc[ax_l * 16 + __popc(m16 & below16)] = (unsigned char)jv_l;
+            s_vlc[ax_l * TS + __popc(m16 & below16)] = (unsigned char)jv_l;
           }
           lex_sync();
 #pragma unroll
@@ -487,11 +492,11 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
             for (int x = lane; x < nv * cn; x += 64) {
               const int vi = (int)(((float)x + 0.5f) * inv_cn);  // exact: x < 2^12
               const int k = x - __umul24(vi, cn);
-              const int jv = (int)s_vlc[ax * 16 + vi];
+              const int jv = (int)s_vlc[ax * TS + vi];
               Ax<K> q;
-              q.init(p0, v0, a0, 0.0, s_uval[ax * 16 + jv]);
+              q.init(p0, v0, a0, 0.0, s_uval[ax * TS + jv]);
               // map_util.h:103-108: cell = round((pos - origin) / res - 0.5)
-              const double qd = div_by(q.pos_q(trow[k], K >= 3 ? s_uq[ax * 16 + jv] : 0.0) - org, A.res, A.Rres);
+              const double qd = div_by(q.pos_q(trow[k], K >= 3 ? s_uq[ax * TS + jv] : 0.0) - org, A.res, A.Rres);
               const int c = (qd - 0.5 > -0.5) ? (int)qd : -1;
               const int code = c + shift;  // 0 < code < 2 * half for an entry inside the limits (exact maxima for K <= 3)
               s_cell[__umul24(ax * ndp + jv, rowcap) + row + k] = (unsigned char)code;
@@ -576,11 +581,11 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
             c_ = ra - b_ * in1;
           }
           j0 = s_vl[a_];
-          j1 = s_vl[16 + b_];
-          if (D == 3) j2 = s_vl[32 + c_];
+          j1 = s_vl[TS + b_];
+          if (D == 3) j2 = s_vl[2 * TS + c_];
         }
         const int ci = (D == 3) ? (int)__umul24(__umul24(j0, nd[1]) + j1, nd[2]) + j2 : (int)__umul24(j0, nd[1]) + j1;
-        const int en[3] = {j0, 16 + j1, 32 + j2};
+        const int en[3] = {j0, TS + j1, 2 * TS + j2};
         const int px = (D == 3) ? (int)__umul24(j0, ndp) + j1 : j0;
         int n, fl;
         {
@@ -751,45 +756,53 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
 #undef A
 }
 
-template <int D, int K>
+template <int D, int K, int TS>
 hipError_t lex_inst_attr() {
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
   if (!attr_set[dev] || dev == 63) {
-    hipError_t e = hipFuncSetAttribute((const void *)expand_lex_kernel<D, K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void *)expand_lex_kernel<D, K, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
   return hipSuccess;
 }
 
-template <int D, int K>
-hipError_t launch_lex_inst(const GridArgs &a, hipStream_t stream) {
+template <int D, int K, int TS>
+hipError_t launch_lex_ts(const GridArgs &a, hipStream_t stream) {
   if (a.n_nodes == 0) return hipSuccess;
   const int64_t n_wg = (a.n_nodes + kLexWPB - 1) / kLexWPB;
   const int64_t blocks = n_wg < (int64_t)a.grid_limit ? n_wg : (int64_t)a.grid_limit;
-  const size_t lds = lex_lds_bytes(D, K, a.ndp, a.n_max, a.rmax, a.boxcap);
-  if (hipError_t e = lex_inst_attr<D, K>()) return e;
-  hipLaunchKernelGGL((expand_lex_kernel<D, K>), dim3((unsigned)blocks), dim3(kLexBT), lds, stream, a);
+  const size_t lds = lex_lds_bytes(D, K, a.ndp, a.nU, a.n_max, a.rmax, a.boxcap);
+  if (hipError_t e = lex_inst_attr<D, K, TS>()) return e;
+  hipLaunchKernelGGL((expand_lex_kernel<D, K, TS>), dim3((unsigned)blocks), dim3(kLexBT), lds, stream, a);
   return hipGetLastError();
 }
-
 template <int D, int K>
-int lex_resident_inst(size_t lds) {
-  if (lex_inst_attr<D, K>() != hipSuccess) return 0;
+hipError_t launch_lex_inst(const GridArgs &a, hipStream_t stream) {
+  return a.ndp <= 8 ? launch_lex_ts<D, K, 8>(a, stream) : launch_lex_ts<D, K, 16>(a, stream);
+}
+
+template <int D, int K, int TS>
+int lex_resident_ts(size_t lds) {
+  if (lex_inst_attr<D, K, TS>() != hipSuccess) return 0;
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)expand_lex_kernel<D, K>, kLexBT, lds) != hipSuccess) {
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)expand_lex_kernel<D, K, TS>, kLexBT, lds) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
   return nb;
 }
+template <int D, int K>
+int lex_resident_inst(size_t lds, int ndp) {
+  return ndp <= 8 ? lex_resident_ts<D, K, 8>(lds) : lex_resident_ts<D, K, 16>(lds);
+}
 
 }  // namespace
 
-size_t lex_lds_bytes(int dim, int order, int ndp, int n_max, int rmax, int boxcap) {
-  return (size_t)LexLds(dim, order, kLexWPB, ndp, n_max, rmax, boxcap).total;
+size_t lex_lds_bytes(int dim, int order, int ndp, int nU, int n_max, int rmax, int boxcap) {
+  return (size_t)LexLds(dim, order, kLexWPB, ndp, nU, n_max, rmax, boxcap).total;
 }
 int lex_waves_per_block() { return kLexWPB; }
 
@@ -816,18 +829,18 @@ hipError_t launch_expand_lex(int dim, int control, const GridArgs &a, hipStream_
   return hipErrorInvalidValue;
 }
 
-int lex_resident_blocks(int dim, int control, size_t lds) {
+int lex_resident_blocks(int dim, int control, int ndp, size_t lds) {
   if (dim == 2) {
     switch (control) {
-      case 0x01: return lex_resident_inst<2, 1>(lds);
-      case 0x03: return lex_resident_inst<2, 2>(lds);
-      case 0x07: return lex_resident_inst<2, 3>(lds);
+      case 0x01: return lex_resident_inst<2, 1>(lds, ndp);
+      case 0x03: return lex_resident_inst<2, 2>(lds, ndp);
+      case 0x07: return lex_resident_inst<2, 3>(lds, ndp);
     }
   } else if (dim == 3) {
     switch (control) {
-      case 0x01: return lex_resident_inst<3, 1>(lds);
-      case 0x03: return lex_resident_inst<3, 2>(lds);
-      case 0x07: return lex_resident_inst<3, 3>(lds);
+      case 0x01: return lex_resident_inst<3, 1>(lds, ndp);
+      case 0x03: return lex_resident_inst<3, 2>(lds, ndp);
+      case 0x07: return lex_resident_inst<3, 3>(lds, ndp);
     }
   }
   return 0;

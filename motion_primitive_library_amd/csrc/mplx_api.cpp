@@ -538,7 +538,7 @@ GridPlan plan_grid(const mplx_ctx *c) {
   // the lexicographic kernel: same plan, its own LDS carve-up and occupancy
   g.lex = ulex && !yaw && !c->has_pot && !g.gather && c->tune.grid_lex && mplx::lex_covers(c->dim, p.control);
   auto lds_of = [&](int rm) -> size_t {
-    return g.lex ? mplx::lex_lds_bytes(c->dim, order, ndp, n_max, rm, boxcap)
+    return g.lex ? mplx::lex_lds_bytes(c->dim, order, ndp, c->nU, n_max, rm, boxcap)
                  : mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rm, boxcap, ym, ndy, ulex);
   };
   while (rmax > 1 && lds_of(rmax) > 80 * 1024) rmax--;
@@ -556,7 +556,7 @@ GridPlan plan_grid(const mplx_ctx *c) {
     for (const auto &e : c->grid_occ)
       if (e.control == key && e.pot == c->has_pot && e.lds == lds) nb = e.nb;
     if (nb < 0) {
-      nb = g.lex ? mplx::lex_resident_blocks(c->dim, p.control, lds) : mplx::grid_resident_blocks(c->dim, p.control, c->has_pot, lds);
+      nb = g.lex ? mplx::lex_resident_blocks(c->dim, p.control, ndp, lds) : mplx::grid_resident_blocks(c->dim, p.control, c->has_pot, lds);
       if (c->grid_occ.size() >= 8) c->grid_occ.clear();
       c->grid_occ.push_back({key, c->has_pot, lds, nb});
       if (getenv("MPLX_GRID_VERBOSE"))
@@ -568,10 +568,23 @@ GridPlan plan_grid(const mplx_ctx *c) {
   };
   // 16 waves per CU (4 per SIMD): what the register allocation of every instantiation allows, and the measured
   // optimum where more would fit (profiles/README.md)
-  const int cap = c->tune.grid_waves_per_cu > 0 ? c->tune.grid_waves_per_cu : 16;
+  // (the lexicographic kernel is leaner and latency-bound: C4 edges-only 0.353 / 0.302 / 0.278 ms at 12 / 16 / 20 waves per
+  // CU, profiles/r04_lex_occupancy.txt -- it takes what its registers and LDS allow, up to 24)
+  const int cap = c->tune.grid_waves_per_cu > 0 ? c->tune.grid_waves_per_cu : (g.lex ? 24 : 16);
   size_t lds = 0;
   int per_cu = resident(rmax, &lds);
   if (per_cu < 1) return g;
+  // A slightly smaller box budget when that admits another workgroup (lexicographic kernel, Dim 3): the staged box of a
+  // node is (n_max + 3)^2 words at most and far smaller for nearly every node (the rare larger one reads the blocked-bit
+  // map directly).  C3: 1024 -> 800 words = 4 instead of 3 workgroups per CU, 71.5 -> 65.4 us.
+  if (g.lex && c->dim == 3 && c->tune.grid_boxcap <= 0 && per_cu * wpb < cap) {
+    const int keep = boxcap;
+    boxcap = (boxcap * 25 / 32) & ~31;
+    size_t lds_b = 0;
+    const int per_cu_b = boxcap >= 256 ? resident(rmax, &lds_b) : 0;
+    if (per_cu_b > per_cu) { per_cu = per_cu_b; lds = lds_b; }
+    else boxcap = keep;
+  }
   // One row less per pass when that is what lets another workgroup in (the heading-cost tables of ACCxYAW with
   // wyaw > 0: 45 KB per workgroup = 3 resident, 35 KB = 4; C5 0.108 -> 0.103 ms, a second pass is rare)
   if (c->tune.grid_rmax <= 0 && rmax == 4 && per_cu * wpb < cap) {

@@ -230,9 +230,9 @@ hipError_t launch_expand_grid(int dim, int control, const GridArgs &args, hipStr
 // expand_lex_kernel.hip: the same function for lexicographic control tables without yaw on an occupancy map (GridArgs
 // with ulex == 1, pot == null, live == null, yaw unused); its own LDS carve-up
 bool lex_covers(int dim, int control);
-size_t lex_lds_bytes(int dim, int order, int ndp, int n_max, int rmax, int boxcap);
+size_t lex_lds_bytes(int dim, int order, int ndp, int nU, int n_max, int rmax, int boxcap);
 int lex_waves_per_block();
-int lex_resident_blocks(int dim, int control, size_t lds);
+int lex_resident_blocks(int dim, int control, int ndp, size_t lds);
 hipError_t launch_expand_lex(int dim, int control, const GridArgs &args, hipStream_t stream);
 // Blocked-bit map: 1 bit per cell in map order, 1 = occupied or outside the search
 // region; (n_cells + 31) / 32 dwords.
