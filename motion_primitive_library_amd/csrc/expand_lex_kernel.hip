@@ -46,13 +46,15 @@ constexpr int kLexBT = 64 * kLexWPB;
 constexpr int kLexTabStride = 64;  // row stride of the global time table (launch_make_tables)
 constexpr int kLexUB = 8;          // samples per step of the sample loop
 
-// shared tables at compile-time offsets
-constexpr int kShUval = 0;     // double[3][16]
-constexpr int kShTc = 384;     // uchar[64]
-constexpr int kShTt = 448;     // double[(n_max + 1)(n_max + 2) / 2]: row nn at nn (nn + 1) / 2 (see lex_tt_entries)
+// shared tables at compile-time offsets (given the table stride TS)
+constexpr int kShUval = 0;                                                             // double[3][TS]
+__host__ __device__ constexpr int lex_sh_tc(int TS) { return TS == 32 ? 768 : 384; }   // uchar[64]
+__host__ __device__ constexpr int lex_sh_tt(int TS) { return lex_sh_tc(TS) + 64; }     // double[(n_max + 1)(n_max + 2) / 2]: row nn at nn (nn + 1) / 2
+__host__ __device__ constexpr int lex_ts(int ndp) { return ndp <= 8 ? 8 : (ndp <= 16 ? 16 : 32); }
 
 // bytes of the fixed-size per-wave tables = offset of the first run-time sized one (the prefix-hash table)
-// (TS = table stride: entries reserved per axis, 8 or 16 -- the LANE layout is one 16-lane DPP row per axis either way)
+// (TS = table stride: entries reserved per axis, 8, 16 or 32 -- the LANE layout is one 16-lane DPP row per axis for 8 and
+// 16, two rows per axis for 32, where a 3D node's 96 entries take two rounds of phase T1)
 __host__ __device__ constexpr int lex_fixed_bytes(int D, int K, int TS) {
   const int F = 4 * D + 2, KQ = K == 3 ? 4 : K;
   int w = (F * 8 + 15) & ~15;                                                                                  // node
@@ -89,8 +91,8 @@ struct LexLds {
   __host__ __device__ LexLds(int D, int K, int waves, int ndp, int nU, int n_max, int rmax, int boxcap) {
     tts = n_max + 1;
     rowcap = rmax * tts;
-    o_wave0 = (kShTt + lex_tt_entries(n_max) * 8 + 15) & ~15;
-    int w = lex_fixed_bytes(D, K, ndp <= 8 ? 8 : 16);
+    o_wave0 = (lex_sh_tt(lex_ts(ndp)) + lex_tt_entries(n_max) * 8 + 15) & ~15;
+    int w = lex_fixed_bytes(D, K, lex_ts(ndp));
     const int PN = (D == 3) ? ndp * ndp : ndp;
     w += PN * 8;
     w_drop = w;
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const double *s_uval = (const double *)(smem + kShUval);
+  constexpr int kShTc = lex_sh_tc(TS), kShTt = lex_sh_tt(TS);
   const unsigned char *s_tc = smem + kShTc;
   const double *s_tt = (const double *)(smem + kShTt);
   unsigned char *wb = smem + L.o_wave0 + wv * L.wave_bytes;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
   // ---- once per (persistent) workgroup: shared read-only tables
   {
     double *uv = (double *)(smem + kShUval);
-    if (threadIdx.x < D * TS) uv[threadIdx.x] = A.uvals[(threadIdx.x / TS) * 16 + threadIdx.x % TS];
+    if (threadIdx.x < D * TS) uv[threadIdx.x] = A.uvals[(threadIdx.x / TS) * A.uval_stride + threadIdx.x % TS];
     if (threadIdx.x < 64) smem[kShTc + threadIdx.x] = A.tcnt[threadIdx.x];
     double *tt = (double *)(smem + kShTt);
     for (int i = threadIdx.x; i < (A.n_max + 1) * tts; i += kLexBT) {
@@ -247,11 +250,47 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
   __syncthreads();  // the only workgroup barrier
   asm volatile("" ::"v"(nxt));
 
-  // which 16-bit field of a ballot is this lane's axis
-  const int ax_l = lane >> 4, jv_l = lane & 15;
-  const bool ent_lane = lane < D * 16 && jv_l < (ax_l == 0 ? nd[0] : (ax_l == 1 ? nd[1] : nd[2]));
-  const unsigned int below16 = (1u << jv_l) - 1u;
-  const int ti_l = ax_l * TS + jv_l;  // this lane's entry in the tables
+  // Lane layout of the axis entries: LS lanes per axis (one DPP row of 16, or two for tables of up to 32 values per axis);
+  // entry e = lane + 64 r of round r is (axis e / LS, value index e % LS).  NR = 1 except for Dim 3 with 32 values per axis.
+  constexpr int LS = TS == 32 ? 32 : 16;
+  constexpr int NR = (D * LS + 63) / 64;
+  const int jv_l = lane & (LS - 1);
+  const unsigned int below_l = (1u << jv_l) - 1u;
+  int ax_r[NR], ti_r[NR];
+  bool ent_r[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    ax_r[r] = (lane + 64 * r) / LS;
+    ent_r[r] = ax_r[r] < D && jv_l < (ax_r[r] == 0 ? nd[0] : (ax_r[r] == 1 ? nd[1] : nd[2]));
+    ti_r[r] = ax_r[r] * TS + jv_l;  // the entry's place in the tables
+  }
+  // the field of axis i in the ballots of the rounds (LS = 16: 16-bit fields of one ballot; LS = 32: halves of two)
+  auto amask = [&](const unsigned long long (&b)[NR], int i) -> unsigned int {
+    if (LS == 16) return (unsigned int)(b[0] >> (16 * i)) & 0xffffu;
+    return (unsigned int)(b[i >> 1] >> (32 * (i & 1)));
+  };
+  // ... and of this lane's own axis in round r
+  auto amask_lane = [&](const unsigned long long (&b)[NR], int r) -> unsigned int {
+    const unsigned int lo = (unsigned int)b[r], hi = (unsigned int)(b[r] >> 32);
+    if (LS == 16) return ((lane < 16) ? lo : (lane < 32) ? (lo >> 16) : (lane < 48) ? hi : (hi >> 16)) & 0xffffu;
+    return lane < 32 ? lo : hi;
+  };
+  // the per-axis result of a row reduction done in every round (lane 15 of each 16-lane row holds its row's)
+  auto axis_or = [&](const unsigned int (&x)[NR], int i) -> unsigned int {
+    if (LS == 16) return (unsigned int)__builtin_amdgcn_readlane((int)x[0], 16 * i + 15);
+    return (unsigned int)__builtin_amdgcn_readlane((int)x[i >> 1], 32 * (i & 1) + 15) |
+           (unsigned int)__builtin_amdgcn_readlane((int)x[i >> 1], 32 * (i & 1) + 31);
+  };
+  auto axis_min = [&](const int (&x)[NR], int i) -> int {
+    if (LS == 16) return __builtin_amdgcn_readlane(x[0], 16 * i + 15);
+    const int a = __builtin_amdgcn_readlane(x[i >> 1], 32 * (i & 1) + 15), b = __builtin_amdgcn_readlane(x[i >> 1], 32 * (i & 1) + 31);
+    return a < b ? a : b;
+  };
+  auto axis_max = [&](const int (&x)[NR], int i) -> int {
+    if (LS == 16) return __builtin_amdgcn_readlane(x[0], 16 * i + 15);
+    const int a = __builtin_amdgcn_readlane(x[i >> 1], 32 * (i & 1) + 15), b = __builtin_amdgcn_readlane(x[i >> 1], 32 * (i & 1) + 31);
+    return a > b ? a : b;
+  };
   int it_next = 0;
 
   for (int it = it0; it < NN; it = it_next) {
@@ -273,11 +312,16 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
     if (it_next < NN && lane < F) nxt = A.nodes[(int64_t)lane * A.node_stride + it_next];
     lex_sync();
 
-    // ---- phase T1: axis entries (lane = axis * 16 + value index); the node's own lattice integers (lanes 48 ..)
-    int flag = 0;
-    int rb_lo = 0x7fffffff, rb_hi = (int)0x80000000;  // cells this entry's p(t) spans (free-box query)
-    if (ent_lane) {
-      const int ax = ax_l;
+    // ---- phase T1: axis entries (lane layout above); the node's own lattice integers (lanes 48 .. where they are free)
+    int flag[NR], rb_lo[NR], rb_hi[NR];  // rb: cells this entry's p(t) spans (free-box query)
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+    flag[r] = 0;
+    rb_lo[r] = 0x7fffffff;
+    rb_hi[r] = (int)0x80000000;
+    const int ti_l = ti_r[r];
+    if (ent_r[r]) {
+      const int ax = ax_r[r];
       const double p = s_node[0 * D + ax];
       const double v = (K >= 2) ? s_node[1 * D + ax] : 0.0;
       const double a = (K >= 3) ? s_node[2 * D + ax] : 0.0;
@@ -302,7 +346,7 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
       s_eq[ti_l * KQ + 0] = quantise(np_, 0.01, A.R001);
       if (K >= 2) s_eq[ti_l * KQ + 1] = quantise(nv_, 0.1, A.R01);
       if (K >= 3) s_eq[ti_l * KQ + 2] = quantise(na_, 0.1, A.R01);
-      flag = (valid ? 1 : 0) | ((p == np_) ? 2 : 0) | (n << 8);
+      flag[r] = (valid ? 1 : 0) | ((p == np_) ? 2 : 0) | (n << 8);
       if (A.sat != nullptr && valid) {
         // range of p(t) over [0, T] of this entry, as cells with one cell of slack on both sides;
         // K = 1, 2: exact extrema; K = 3: |p - p0| <= max_vel * T
@@ -316,42 +360,54 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
           }
         }
         if (K >= 3) { pmin = p - mv * T; pmax = p + mv * T; }
-        rb_lo = (int)floor(div_by(pmin - org, A.res, A.Rres)) - 1;
-        rb_hi = (int)floor(div_by(pmax - org, A.res, A.Rres)) + 1;
+        rb_lo[r] = (int)floor(div_by(pmin - org, A.res, A.Rres)) - 1;
+        rb_hi[r] = (int)floor(div_by(pmax - org, A.res, A.Rres)) + 1;
       }
       if (jv_l == 0) {
         // the node's own cell on this axis (map_util.h:103-108); -1 stands for every negative cell
         const double qd = div_by(p - org, A.res, A.Rres);
         s_misc[LM_BASE + ax] = (qd - 0.5 > -0.5) ? (int)qd : -1;
       }
-    } else if (lane >= 48 && lane < 48 + 4 * D) {
+    } else if (LS == 16 && r == 0 && lane >= 48 && lane < 48 + 4 * D) {
       const int i = (lane - 48) >> 2, f = (lane - 48) & 3;
       if (f < K) {
         const double x = s_node[f * D + i];
         s_misc[LM_NODEQ + i * 4 + f] = f == 0 ? quantise(x, 0.01, A.R001) : quantise(x, 0.1, A.R01);
       }
     }
-    if (lane < D * 16 && jv_l < TS) s_eflag[ti_l] = flag;
-    // per axis, the values that pass the limits, in order: 16-bit fields of one ballot
-    const unsigned long long vm = __ballot((flag & 1) != 0);
-    const unsigned int vm_lo = (unsigned int)vm, vm_hi = (unsigned int)(vm >> 32);
-    const int nv0 = __popc(vm_lo & 0xffffu), nv1 = __popc(vm_lo >> 16), nv2 = (D == 3) ? __popc(vm_hi & 0xffffu) : 1;
-    if (flag & 1) {
-      const unsigned int m16 = (ax_l == 0 ? vm_lo : (ax_l == 1 ? (vm_lo >> 16) : vm_hi)) & 0xffffu;
-      s_vl[ax_l * TS + __popc(m16 & below16)] = (unsigned char)jv_l;
+    if (ax_r[r] < D && jv_l < TS) s_eflag[ti_l] = flag[r];
+    }  // rounds of T1
+    if (LS == 32 && lane < 4 * D) {  // (no lanes to spare beside the entries: the node's lattice integers in a step of their own)
+      const int i = lane >> 2, f = lane & 3;
+      if (f < K) {
+        const double x = s_node[f * D + i];
+        s_misc[LM_NODEQ + i * 4 + f] = f == 0 ? quantise(x, 0.01, A.R001) : quantise(x, 0.1, A.R01);
+      }
     }
+    // per axis, the values that pass the limits, in order: fields of the rounds' ballots
+    unsigned long long vm[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) vm[r] = __ballot((flag[r] & 1) != 0);
+    const int nv0 = __popc(amask(vm, 0)), nv1 = __popc(amask(vm, 1)), nv2 = (D == 3) ? __popc(amask(vm, 2)) : 1;
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+      if (flag[r] & 1) s_vl[ax_r[r] * TS + __popc(amask_lane(vm, r) & below_l)] = (unsigned char)jv_l;
     // the sets of sample counts per axis (bit n of a 64-bit word, as two halves) by row reduction
     unsigned long long nm = 0;
     {
-      const int n_l = flag >> 8;
-      const unsigned int b_lo = ((flag & 1) && n_l < 32) ? (1u << n_l) : 0u, b_hi = ((flag & 1) && n_l >= 32) ? (1u << (n_l - 32)) : 0u;
-      const unsigned int r_lo = row_reduce_or(b_lo), r_hi = row_reduce_or(b_hi);
+      unsigned int r_lo[NR], r_hi[NR];
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+        const int n_l = flag[r] >> 8;
+        const unsigned int b_lo = ((flag[r] & 1) && n_l < 32) ? (1u << n_l) : 0u, b_hi = ((flag[r] & 1) && n_l >= 32) ? (1u << (n_l - 32)) : 0u;
+        r_lo[r] = row_reduce_or(b_lo);
+        r_hi[r] = row_reduce_or(b_hi);
+      }
       unsigned long long uni = 0;
       int lmin = 0;
 #pragma unroll
       for (int i = 0; i < D; i++) {
-        const unsigned long long mi = (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)r_lo, 16 * i + 15) |
-                                      ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)r_hi, 16 * i + 15) << 32);
+        const unsigned long long mi = (unsigned long long)axis_or(r_lo, i) | ((unsigned long long)axis_or(r_hi, i) << 32);
         uni |= mi;
         const int lo_i = mi ? __ffsll((long long)mi) - 1 : 64;
         lmin = lo_i > lmin ? lo_i : lmin;
@@ -369,7 +425,7 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
       for (int x = lane; x < n01; x += 64) {
         const int a_ = (int)(((float)x + 0.5f) * r1);
         const int b_ = x - a_ * nv1;
-        const int j0 = s_vl[a_], j1 = s_vl[TS + b_];
+        const int j0 = s_vl[a_], j1 = s_vl[TS + b_];  // (exact quotient: x < 2^10)
         uint64_t h = 0;
         lex_fold_entry<K>(h, s_eq, j0);
         lex_fold_entry<K>(h, s_eq, TS + j1);
@@ -396,13 +452,18 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
     unsigned int sat_v = 0;
     bool sat_inside = false;
     if (A.sat != nullptr) {
-      const int r_lo = row_reduce_minmax<false>(rb_lo), r_hi = row_reduce_minmax<true>(rb_hi);
+      int r_lo[NR], r_hi[NR];
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+        r_lo[r] = row_reduce_minmax<false>(rb_lo[r]);
+        r_hi[r] = row_reduce_minmax<true>(rb_hi[r]);
+      }
       int rlo[3] = {0, 0, 0}, rhi[3] = {0, 0, 0};
       bool inside = true;
 #pragma unroll
       for (int i = 0; i < D; i++) {
-        rlo[i] = __builtin_amdgcn_readlane(r_lo, 16 * i + 15);
-        rhi[i] = __builtin_amdgcn_readlane(r_hi, 16 * i + 15);
+        rlo[i] = axis_min(r_lo, i);
+        rhi[i] = axis_max(r_hi, i);
         inside = inside && rhi[i] >= rlo[i] && rlo[i] >= 0 && rhi[i] < dims[i];
       }
       sat_inside = inside;
@@ -473,13 +534,13 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
           const float inv_cn = __builtin_amdgcn_rcpf((float)cn);
           const double *trow = s_tt + ((nn * (nn + 1)) >> 1);
           // the row of (entry, count nn) is only read by pairs whose count IS nn, i.e. by entries with n_entry <= nn
-          const unsigned long long fm = __ballot((flag & 1) && (flag >> 8) <= nn);
-          const unsigned int fm_lo = (unsigned int)fm, fm_hi = (unsigned int)(fm >> 32);
+          unsigned long long fm[NR];
+#pragma unroll
+          for (int r = 0; r < NR; r++) fm[r] = __ballot((flag[r] & 1) && (flag[r] >> 8) <= nn);
           lex_sync();  // (the previous count's list has been read)
-          if ((fm >> lane) & 1ull) {
-            const unsigned int m16 = (ax_l == 0 ? fm_lo : (ax_l == 1 ? (fm_lo >> 16) : fm_hi)) & 0xffffu;
-            s_vlc[ax_l * TS + __popc(m16 & below16)] = (unsigned char)jv_l;
-          }
+#pragma unroll
+          for (int r = 0; r < NR; r++)
+            if ((fm[r] >> lane) & 1ull) s_vlc[ax_r[r] * TS + __popc(amask_lane(fm, r) & below_l)] = (unsigned char)jv_l;
           lex_sync();
 #pragma unroll
           for (int ax = 0; ax < D; ax++) {
@@ -488,7 +549,7 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
             const double a0 = (K >= 3) ? s_node[2 * D + ax] : 0.0;
             const double org = ax == 0 ? A.org0 : (ax == 1 ? A.org1 : A.org2);
             const int shift = half - base_c[ax];
-            const int nv = __popc((ax == 0 ? fm_lo : (ax == 1 ? (fm_lo >> 16) : fm_hi)) & 0xffffu);
+            const int nv = __popc(amask(fm, ax));
             for (int x = lane; x < nv * cn; x += 64) {
               const int vi = (int)(((float)x + 0.5f) * inv_cn);  // exact: x < 2^12
               const int k = x - __umul24(vi, cn);
@@ -781,7 +842,7 @@ hipError_t launch_lex_ts(const GridArgs &a, hipStream_t stream) {
 }
 template <int D, int K>
 hipError_t launch_lex_inst(const GridArgs &a, hipStream_t stream) {
-  return a.ndp <= 8 ? launch_lex_ts<D, K, 8>(a, stream) : launch_lex_ts<D, K, 16>(a, stream);
+  return a.ndp <= 8 ? launch_lex_ts<D, K, 8>(a, stream) : (a.ndp <= 16 ? launch_lex_ts<D, K, 16>(a, stream) : launch_lex_ts<D, K, 32>(a, stream));
 }
 
 template <int D, int K, int TS>
@@ -796,7 +857,7 @@ int lex_resident_ts(size_t lds) {
 }
 template <int D, int K>
 int lex_resident_inst(size_t lds, int ndp) {
-  return ndp <= 8 ? lex_resident_ts<D, K, 8>(lds) : lex_resident_ts<D, K, 16>(lds);
+  return ndp <= 8 ? lex_resident_ts<D, K, 8>(lds) : (ndp <= 16 ? lex_resident_ts<D, K, 16>(lds) : lex_resident_ts<D, K, 32>(lds));
 }
 
 }  // namespace

@@ -309,9 +309,11 @@ int mplx_set_controls(mplx_ctx *c, const double *U, int32_t nU, int32_t udim) {
       const double a = std::fabs(U[(size_t)i * udim + k]);
       if (a > c->u_absmax) c->u_absmax = a;
     }
-  // distinct values per spatial axis (compared bit-for-bit so that signed zeros stay apart)
+  // distinct values per spatial axis (compared bit-for-bit so that signed zeros stay apart): up to 16 per axis for the
+  // factorised kernels at large, up to 32 for the lexicographic one (`wide`: expand_lex_kernel.hip alone takes it)
   c->u_factored = true;
-  double vals[4][16] = {};
+  c->u_wide = false;
+  double vals32[4][32] = {};
   std::vector<uint32_t> packed((size_t)nU, 0u);
   c->u_nd[3] = 0;
   for (int k = 0; k < udim && c->u_factored; k++) {
@@ -321,15 +323,18 @@ int mplx_set_controls(mplx_ctx *c, const double *U, int32_t nU, int32_t udim) {
       const double x = U[(size_t)i * udim + k];
       int j = 0;
       for (; j < n; j++)
-        if (std::memcmp(&vals[slot][j], &x, sizeof x) == 0) break;
+        if (std::memcmp(&vals32[slot][j], &x, sizeof x) == 0) break;
       if (j == n) {
-        if (n == 16) { c->u_factored = false; break; }
-        vals[slot][n++] = x;
+        if (n == 32) { c->u_factored = false; break; }
+        vals32[slot][n++] = x;
       }
       packed[(size_t)i] |= (uint32_t)j << (8 * slot);
     }
     c->u_nd[slot] = n;
+    if (n > 16) c->u_wide = true;
   }
+  double vals[4][16] = {};
+  for (int a4 = 0; a4 < 4; a4++) std::memcpy(vals[a4], vals32[a4], sizeof vals[a4]);
   c->u_lex = false;
   if (c->u_factored) {
     for (int k = c->dim; k < 3; k++) c->u_nd[k] = 0;
@@ -348,10 +353,15 @@ int mplx_set_controls(mplx_ctx *c, const double *U, int32_t nU, int32_t udim) {
         c->u_lex = want == packed[(size_t)i];
       }
     }
+    // a wide table is only of use to the lexicographic kernel: no yaw column, nested-loop order
+    if (c->u_wide && (!c->u_lex || udim != c->dim)) c->u_factored = false;
+  }
+  if (c->u_factored) {
     std::memcpy(c->h_uyaw, vals[3], sizeof c->h_uyaw);
-    if (int rc = ensure(c, c->uvals, sizeof vals)) return rc;
+    if (int rc = ensure(c, c->uvals, sizeof vals + sizeof vals32)) return rc;  // [4][16], then [4][32]
     if (int rc = ensure(c, c->uidx, (size_t)nU * 4)) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->uvals.p, vals, sizeof vals, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync((char *)c->uvals.p + sizeof vals, vals32, sizeof vals32, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->uidx.p, packed.data(), (size_t)nU * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
@@ -498,7 +508,12 @@ GridPlan plan_grid(const mplx_ctx *c) {
   const mplx_params &p = c->prm;
   const bool yaw = (p.control & 0x10) != 0;
   if (yaw && (c->udim != c->dim + 1 || c->u_nd[3] < 1)) return g;
-  if (!c->u_factored || c->nU > 1024 || c->nU < 1) return g;
+  if (!c->u_factored || c->nU < 1) return g;
+  // (control tables of more than 1 024 entries or more than 16 values on an axis: the lexicographic kernel alone, up to 8 192)
+  const bool lex_only = c->u_wide || c->nU > 1024;
+  if (lex_only && (c->nU > 8192 || !c->u_lex || c->tune.no_lex || !c->tune.grid_lex || yaw || c->has_pot ||
+                   !mplx::lex_covers(c->dim, p.control)))
+    return g;
   double vbound;
   if ((p.control & 0x0f) == MPLX_VEL) vbound = c->u_absmax;
   else if (p.v_max > 0) vbound = p.v_max;
@@ -537,6 +552,7 @@ GridPlan plan_grid(const mplx_ctx *c) {
   const int ulex = (c->u_lex && !c->tune.no_lex) ? 1 : 0;  // = GridArgs::ulex
   // the lexicographic kernel: same plan, its own LDS carve-up and occupancy
   g.lex = ulex && !yaw && !c->has_pot && !g.gather && c->tune.grid_lex && mplx::lex_covers(c->dim, p.control);
+  if (lex_only && !g.lex) return GridPlan();
   auto lds_of = [&](int rm) -> size_t {
     return g.lex ? mplx::lex_lds_bytes(c->dim, order, ndp, c->nU, n_max, rm, boxcap)
                  : mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rm, boxcap, ym, ndy, ulex);
@@ -872,7 +888,8 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.res = c->res;
     a.dt = c->prm.dt; a.w = c->prm.w;
     a.v_max = c->prm.v_max; a.a_max = c->prm.a_max; a.j_max = c->prm.j_max;
-    a.uvals = (const double *)c->uvals.p;
+    a.uvals = (const double *)c->uvals.p + (c->u_wide ? 4 * 16 : 0);
+    a.uval_stride = c->u_wide ? 32 : 16;
     a.uidx = (const uint32_t *)c->uidx.p;
     a.nd0 = c->u_nd[0]; a.nd1 = c->u_nd[1]; a.nd2 = c->u_nd[2];
     a.ndp = gp.ndp;

@@ -50,6 +50,7 @@ struct mplx_ctx {
   mplx_detail::DevBuf prep_lut, prep_a, prep_b;  // map preprocessing scratch (map_prep_api.cpp)
   bool blk_ok = false;   // blocked-bit map matches the current map + region
   bool u_factored = false;
+  bool u_wide = false;   // 17 .. 32 distinct values on some axis: only the lexicographic kernel (expand_lex_kernel.hip) takes the table
   bool u_lex = false;    // the table is the full Cartesian product of its per-axis values in lexicographic order
   int32_t u_nd[4] = {0, 0, 0, 0};  // distinct control values per axis; [3] = yaw rates
   // Diagnostic knobs, read from the environment once per context (mplx_create): ablations and forced code paths

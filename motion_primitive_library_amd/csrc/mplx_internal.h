@@ -153,7 +153,8 @@ struct GridArgs {
   double dt, w;
   double v_max, a_max, j_max;
   double yaw_max, wyaw;  // yaw controls only
-  const double *uvals;   // [4][16] distinct control values of each axis; row 3 = yaw rates
+  const double *uvals;   // [4][16] distinct control values of each axis; row 3 = yaw rates (expand_lex_kernel: [3][uval_stride])
+  int32_t uval_stride;   // 16, or 32 for the wide tables only expand_lex_kernel.hip takes (17 .. 32 values on an axis)
   const uint32_t *uidx;  // [nU] packed per-axis value indices
   int32_t nd0, nd1, nd2; // number of distinct values per axis
   int32_t ndy;           // distinct yaw rates (yaw controls)

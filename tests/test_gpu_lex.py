@@ -137,3 +137,29 @@ def test_lex_kernel_single_node_calls_and_empty_lists(engine, oracle_lib):
         assert_lists_equal(got, oracle_lib.expand(oenv, one, threads=1), 1, wl.U.shape[0], what="single node %d" % k)
     assert env.expand_lists(np.ascontiguousarray(wl.nodes[:, 5:6]))["count"][0] == 0
     env.close()
+
+
+@pytest.mark.parametrize("dim,control,n_vals,n_nodes", [(2, 0x03, 17, 200), (2, 0x07, 25, 120), (3, 0x03, 17, 60), (3, 0x01, 20, 40),
+                                                         (3, 0x03, 11, 80), (2, 0x03, 32, 64)])
+def test_lex_kernel_wide_control_tables(engine, oracle_lib, dim, control, n_vals, n_nodes):
+    """Lattices finer than the tests' du = u / 2: 17 .. 32 values per axis (one or two DPP rows per axis, a 3D node's 96
+    entries in two rounds of phase T1) and tables of more than 1 024 controls (11^3, 17^3, 20^3) -- only the lexicographic
+    kernel takes those; before round 4 they ran the 3.4 x slower workgroup-per-node kernel."""
+    wl = _small_world(engine, dim, control, seed=9100 + n_vals + dim, n_nodes=n_nodes)
+    vals = np.linspace(-1.0, 1.0, n_vals)
+    wl.U = engine.workloads.grid_controls(list(vals), dim)
+    wl.nodes[dim:4 * dim, ::9] = 0.0  # nodes at rest: the zero control (odd n_vals) reproduces them
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+    env = engine_env(engine, wl)
+    env.set_lists_route("grid")  # (AUTO sends batches of <= 512 nodes with >= 512 controls to the workgroup-per-node kernel)
+    got = env.expand_lists(wl.nodes)
+    assert env.last_lists_route() == "grid" and env.last_grid_kernel() == "lex"
+    env.set_lists_route("tile")
+    try:
+        tile = env.expand_lists(wl.nodes)
+    except Exception:  # the tiled kernel's own scope may end below this table size
+        tile = None
+    env.close()
+    assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="lex %dD ctrl0x%x %d values per axis" % (dim, control, n_vals))
+    if tile is not None:
+        _same_lists(got, tile, "lex vs tile, %d values per axis" % n_vals)

@@ -203,17 +203,25 @@ def test_node_stride_smaller_than_the_control_table_is_rejected(engine):
 
 
 def test_control_tables_larger_than_a_workgroup_tile(engine, oracle_lib):
-    """|U| = 11^3 = 1331 > 1024: neither list kernel tiles it, the dense kernel + compaction serves it;
-    |U| = 1024 = 32 x 32 (2D) is the largest table the factorised kernel takes."""
+    """|U| = 11^3 = 1331 > 1024 in nested-loop order: the lexicographic kernel (round 4; up to 8 192 controls); the same
+    table shuffled: neither list kernel tiles it, the dense kernel + compaction serves it;
+    |U| = 1024 = 32 x 32 (2D) is the largest table the general factorised kernel takes."""
     W = engine.workloads
     wl = _small_world(engine, 3, 0x03, seed=8100, n_nodes=40)
     wl.U = W.grid_controls(np.linspace(-1.0, 1.0, 11), 3)
     ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
     env = engine_env(engine, wl)
     got = env.expand_lists(wl.nodes)
-    assert env.last_lists_route() == "dense"
+    assert env.last_lists_route() == "grid" and env.last_grid_kernel() == "lex"
     env.close()
     assert_lists_equal(got, ref, wl.n_nodes, 1331, what="|U| = 1331")
+    wl.U = np.ascontiguousarray(wl.U[np.random.default_rng(8103).permutation(1331)])
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+    env = engine_env(engine, wl)
+    got = env.expand_lists(wl.nodes)
+    assert env.last_lists_route() == "dense"
+    env.close()
+    assert_lists_equal(got, ref, wl.n_nodes, 1331, what="|U| = 1331, shuffled")
     wl2 = _small_world(engine, 2, 0x03, seed=8101, n_nodes=40)
     rng = np.random.default_rng(8102)
     vals = np.linspace(-1.0, 1.0, 16)
@@ -403,9 +411,11 @@ def test_lexicographic_enumeration_equals_the_table_walk(engine, monkeypatch, na
 
 
 def test_forcing_a_route_outside_its_scope_fails_loudly(engine):
-    # 17 distinct control values per axis: past the factorised kernel's 16 -- the workgroup-per-node kernel covers it
+    # 17 distinct control values per axis in an order that is NOT the nested loops': past the general factorised kernel's
+    # 16 (the lexicographic kernel takes up to 32, in nested-loop order only) -- the workgroup-per-node kernel covers it
     wl = _small_world(engine, 2, 0x03, seed=5, n_nodes=8)
     wl.U = engine.workloads.grid_controls(list(np.linspace(-1.0, 1.0, 17)), 2)
+    wl.U = np.ascontiguousarray(wl.U[np.random.default_rng(6).permutation(wl.U.shape[0])])
     env = engine_env(engine, wl)
     env.set_lists_route("grid")
     with pytest.raises(engine._abi.MplxError) as e:
