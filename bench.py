@@ -468,6 +468,19 @@ def extras(m, args, wl, out):
             r.update(stats)
             r["workload"] = WORKLOAD_DESC[name]
             res[name] = r
+        # a lattice twice as fine as C4's on every axis (du = u / 8: 17 values per axis, 4 913 controls): the lexicographic
+        # kernel's since round 4 (before: the general routes below); 8 192 nodes keep the lists at 5.3 GB
+        try:
+            import copy
+            w17 = copy.copy(wl)
+            w17.U = m.workloads.grid_controls(np.linspace(-2.0, 2.0, 17), 3)
+            w17.nodes = np.ascontiguousarray(wl.nodes[:, :8192])
+            for tag, route in (("C4_17cubed", None), ("C4_17cubed_dense_route", "dense")):
+                r = run_config(m, w17, max(3, args.steps // 4), 1, route=route)
+                r["workload"] = "C4's map, 17^3 = 4 913 ACC controls, 8 192-node frontier" + (" through the dense route" if route else "")
+                res[tag] = r
+        except Exception as e:  # noqa: BLE001
+            res["C4_17cubed"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # the general kernels on the headline workload: what a control table outside the factorised kernel's scope
         # (more than 16 distinct values per axis, gradient_weight != 0, SNP with yaw ...) costs at this size
         for route in ("tile", "dense"):
