@@ -448,9 +448,21 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
       if (K >= 2) fold(hcur, __builtin_amdgcn_readfirstlane(q.y));
       if (K >= 3) fold(hcur, __builtin_amdgcn_readfirstlane(q.z));
     }
+    int base_c[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) base_c[i] = (i < D) ? __builtin_amdgcn_readfirstlane(s_misc[LM_BASE + i]) : 0;
     // ---- free-box shortcut (summed-area table of the blocked-bit map): is the whole box the node can reach in T free?
     unsigned int sat_v = 0;
     bool sat_inside = false;
+    // Dim 2: the blocked bits of the node's REACH box (one row of <= 32 cells per lane, known here) are requested together
+    // with the free-box query and land in LDS when the rows of cell codes exist -- a frontier of one node per wave (C2,
+    // the batches of a 2D search) is bound by its dependent round trips to memory: node -> query -> box; this takes the
+    // third off the chain (and the four wave reductions of the sampled box with it).  Every sample of an entry inside the
+    // limits lies in that box (exact extrema of p(t), one cell of slack; K <= 2: the query's precondition).
+    bool eager = false;
+    int e_lo[2] = {0, 0}, e_nb[2] = {1, 1};
+    unsigned int e_a0 = 0, e_a1 = 0, e_shf = 0, e_mask = 0;
+    bool e_in = false;
     if (A.sat != nullptr) {
       int r_lo[NR], r_hi[NR];
 #pragma unroll
@@ -467,6 +479,31 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
         inside = inside && rhi[i] >= rlo[i] && rlo[i] >= 0 && rhi[i] < dims[i];
       }
       sat_inside = inside;
+      if (D == 2 && base_c[0] >= 0 && base_c[1] >= 0 && rhi[0] >= rlo[0] && rhi[1] >= rlo[1]) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          e_lo[i] = rlo[i] - base_c[i] + half;
+          const int hi = rhi[i] - base_c[i] + half;
+          ok = ok && e_lo[i] >= 0 && hi <= 255;
+          e_nb[i] = hi - e_lo[i] + 1;
+        }
+        eager = ok && e_nb[0] <= 32 && e_nb[1] <= 64 && e_nb[1] <= A.boxcap;
+        if (eager) {
+          const int xw = rlo[0], ay = rlo[1] + lane;
+          const int vlo = xw < 0 ? -xw : 0;
+          const int vhi = (dims[0] - xw) < 32 ? (dims[0] - xw) : 32;
+          e_mask = (vhi >= 32 ? 0xffffffffu : ((1u << (vhi > 0 ? vhi : 0)) - 1u)) & ~((1u << vlo) - 1u);
+          e_in = lane < e_nb[1] && vhi > vlo && ay >= 0 && ay < dims[1];
+          const int64_t off = e_in ? (int64_t)ay * (int64_t)dims[0] + xw : 0;
+          const int64_t wi = off >> 5;
+          e_shf = (unsigned)(off & 31);
+          const int64_t w0 = wi < 0 ? 0 : wi;
+          const int64_t w1 = wi + 1 >= A.blk_words ? A.blk_words - 1 : wi + 1;
+          e_a0 = A.blk[w0];
+          e_a1 = A.blk[w1 < 0 ? 0 : w1];
+        }
+      }
       if (inside && lane < (1 << D)) {
         const int cx = (lane & 1) ? rhi[0] + 1 : rlo[0];
         const int cy = (lane & 2) ? rhi[1] + 1 : rlo[1];
@@ -476,9 +513,6 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
       }
     }
     const double node_t = s_node[4 * D + 1];
-    int base_c[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) base_c[i] = (i < D) ? __builtin_amdgcn_readfirstlane(s_misc[LM_BASE + i]) : 0;
     if (A.dbg & 1) nm = 0;  // timing ablation: no sampling
     asm volatile("" ::"v"(nxt));  // the next node's state has arrived: no wait behind this node's stores
     bool safe = false;
@@ -571,7 +605,10 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
       // the box of codes the valid entries reach
       int lo[3] = {0, 0, 0}, nb[3] = {1, 1, 1};
       bool have_box = !safe && sub != 0ull;
-      if (have_box) {
+      if (D == 2 && eager) {
+        lo[0] = e_lo[0]; lo[1] = e_lo[1];
+        nb[0] = e_nb[0]; nb[1] = e_nb[1];
+      } else if (have_box) {
 #pragma unroll
         for (int i = 0; i < D; i++) {
           lo[i] = wave_reduce_minmax<false>(lo_l[i]);
@@ -585,7 +622,13 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
       const int n_rows = nb[1] * nb[2];
       const bool fits = have_box && n_rows * WX <= A.boxcap;
       const int rot = (WX == 1) ? (lo[0] & 31) : 0;  // WX == 1: the word is rotated so that code ex sits at bit (ex & 31)
-      if (fits) {
+      if (D == 2 && eager) {
+        if (fits && pass == 0 && lane < nb[1]) {  // (the reach box serves every pass of the node)
+          unsigned int val = e_in ? (__builtin_amdgcn_alignbit(e_a1, e_a0, e_shf) | ~e_mask) : 0xffffffffu;
+          val = __builtin_amdgcn_alignbit(val, val, (32 - rot) & 31);
+          s_box[lane] = val;
+        }
+      } else if (fits) {
         const float inv_ny = __builtin_amdgcn_rcpf((float)nb[1]);
         const int ax0 = base_c[0] + lo[0] - half;
         constexpr int SU = 4;  // rows per lane with their loads in flight together
