@@ -23,8 +23,22 @@ for seed in range(first, first + count):
     n_nodes = int(rng.choice([700, 1500, 2311, 5000]))
     os.environ["MPLX_GRID_BLOCKS"] = str(int(rng.choice([3, 8, 40, 256])))
     os.environ["MPLX_GRID_CHUNK"] = str(int(rng.choice([0, 1, 2, 5])))
+    # round 4 (expand_lex_kernel): starved row / box budgets now and then (several passes per node, samples straight from the
+    # blocked-bit map), nodes at rest (the dropped successor), tables of 17 .. 25 values per axis
+    for var, choices in (("MPLX_GRID_RMAX", [0, 0, 0, 1, 2]), ("MPLX_GRID_BOXCAP", [0, 0, 0, 8, 64])):
+        v = int(rng.choice(choices))
+        if v:
+            os.environ[var] = str(v)
+        else:
+            os.environ.pop(var, None)
     try:
         wl, control, pot = odd_world(m, seed, n_nodes)
+        if seed % 3 == 0:
+            wl.nodes[wl.dim:4 * wl.dim, ::int(rng.choice([3, 7, 50]))] = 0.0
+        if seed % 5 == 0 and not (control & 0x10) and wl.dim == 2:
+            nv = int(rng.choice([17, 21, 25]))
+            lo, hi = wl.U[:, 0].min(), wl.U[:, 0].max()
+            wl.U = m.workloads.grid_controls(list(np.linspace(lo, hi, nv)), 2)
         ref = O.expand(oracle_env(wl), wl.nodes, threads=os.cpu_count())
         env = engine_env(m, wl)
         rtol = 1e-6 if control & 0x10 else 0.0
@@ -35,7 +49,7 @@ for seed in range(first, first + count):
             env.synchronize()
             assert_lists_equal(lists.download(), ref, n_nodes, wl.U.shape[0], cost_rtol=rtol,
                                what="seed %d launch %d route %s" % (seed, launch, env.last_lists_route()))
-        route = env.last_lists_route()
+        route = env.last_lists_route() + ("/" + env.last_grid_kernel() if env.last_lists_route() == "grid" else "")
         lists.free()
         fr.free()
         env.close()
