@@ -716,6 +716,20 @@ def main():
 
     # ---- parity of the TIMED output: the lists the timed launches wrote, against the oracle
     timed_head = slots.download_nodes(0, min(n_loc, 512)) if rank == 0 else None
+    # ---- the list stores of that launch on their own, into the SAME allocation (mplx_debug_store_model overwrites the
+    # entries: the head has just been taken): what the launch costs when its arithmetic is free
+    store_only_ms = None
+    if rank == 0 and not distributed:  # (at N > 1 the gather leg still reads these lists)
+        try:
+            for _ in range(5):
+                env.debug_store_model(slots, n_loc)
+            env.synchronize()
+            env.timer_begin()
+            for _ in range(args.steps):
+                env.debug_store_model(slots, n_loc)
+            store_only_ms = env.timer_end() / args.steps
+        except Exception as e:  # noqa: BLE001 -- diagnostic only
+            note("store model not timed: %s" % e)
 
     weak = gather = None
     if distributed:
@@ -865,6 +879,10 @@ def main():
                 "ms_per_step_first_allocation": placement["probe_ms"][0] if placement["probe_ms"] else kernel_ms,
                 "frac_first_allocation": (b_alg / ((placement["probe_ms"][0] if placement["probe_ms"] else kernel_ms) * 1e-3)
                                           / 1e9 / HBM_PEAK_GBS),
+                # the same lists written by mplx_debug_store_model alone (every row, count[k] entries per node, same order and
+                # store policy): the launch cannot be shorter than this in this allocation
+                "store_only_ms": store_only_ms,
+                "kernel_over_store_only": (kernel_ms / store_only_ms) if store_only_ms else None,
                 "launch": "rank 0's launch: %d nodes" % n_loc,
                 "emitted": n_emit, "finite": n_finite, "map_samples": n_samples,
                 "emitted_all_ranks": n_emit_all, "map_samples_all_ranks": n_samples_all,

@@ -483,6 +483,13 @@ int mplx_last_lists_route(const mplx_ctx *ctx);
  * the last mplx_expand_lists* call ran: MPLX_KERNEL_NONE when the route was not GRID.                              */
 enum { MPLX_KERNEL_NONE = 0, MPLX_KERNEL_GRID = 1, MPLX_KERNEL_LEX = 2 };
 int mplx_last_grid_kernel(const mplx_ctx *ctx);
+/* ABI v6, diagnostic.  The list stores of an expansion launch on their own: for every node k the first count[k] entries
+ * (rounded up to whole 128-byte lines as the kernels do) of every row present in d_lists are written with UNSPECIFIED
+ * values, in the expansion kernels' order and with their store policy; count[] is read, not written.  A launch whose
+ * lists stay in HBM is bound by exactly this once its arithmetic is cheaper (C4: DESIGN.md 5), and how long it takes
+ * depends on the memory behind the allocation: bench.py times it on the lists of the timed launches
+ * (roofline.store_only_ms).  Asynchronous on the context's stream.  OVERWRITES the successor entries.               */
+int mplx_debug_store_model(mplx_ctx *ctx, const mplx_succ_lists *d_lists, int64_t n_nodes);
 /* The service: how mplx_expand_lists (and mplx_get_succ, which calls it) serves
  * the small synchronous batches of a search -- at most MPLX_SERVICE_MAX_NODES
  * (256) nodes, control tables without yaw, no potential map, bounded velocity.

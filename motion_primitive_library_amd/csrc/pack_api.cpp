@@ -57,3 +57,17 @@ extern "C" int mplx_pack_lists_device(mplx_ctx *c, const mplx_succ_lists *L, int
   HIP_TRY(c, mplx::launch_pack_rows(a, n_nodes, c->stream));
   return MPLX_OK;
 }
+
+// Diagnostic: the list stores of an expansion launch on their own (store_model_kernel.hip).  Overwrites the entries.
+extern "C" int mplx_debug_store_model(mplx_ctx *c, const mplx_succ_lists *L, int64_t n_nodes) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!L || n_nodes < 0 || !L->count) return fail(c, MPLX_ERR_ARG, "mplx_debug_store_model: need the lists' count");
+  if (!c->has_U) return fail(c, MPLX_ERR_STATE, "mplx_debug_store_model: controls not set");
+  if (int rc = bind_device(c)) return rc;
+  if (int rc = resolve_pending(c)) return rc;
+  const int64_t S = L->node_stride ? L->node_stride : c->nU;
+  const int pad = (S % 32 == 0 && !c->tune.no_line_pad) ? 1 : 0;
+  HIP_TRY(c, mplx::launch_store_model(L->count, n_nodes, S, L->action, L->cost, L->hash, L->state, L->state_stride,
+                                      4 * c->dim + 2, pad, c->n_cus * 5, c->stream));
+  return MPLX_OK;
+}

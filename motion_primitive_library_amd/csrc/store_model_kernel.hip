@@ -1,0 +1,54 @@
+// store_model_kernel.hip -- DIAGNOSTIC (mplx_debug_store_model, include/mplx.h): what do the list stores of an expansion
+// launch cost on their own, in THIS allocation of the lists?  Round 4 found that the headline launch (C4: 2.75 GB of list
+// entries) is exactly as long as writing them takes, and that this time is a property of the memory behind the allocation
+// (5.9 against 5.15 TB/s for the same pattern, profiles/r04_store_layouts_vs_kernel.txt).  This kernel writes, for every
+// node k, the first count[k] entries of every row present in the lists -- rounded up to whole 128-byte lines like the
+// expansion kernels do -- with unspecified values, in the same order (a wave per node, chunks of nodes dealt over the
+// waves, `sc1 nt` stores): bench.py reports its time next to the kernel's (`roofline.store_only_ms`).
+// It OVERWRITES the successor entries (count[] stays): call it when the results have been consumed.
+#include "mplx_internal.h"
+
+namespace mplx {
+namespace {
+
+template <typename T>
+__device__ __forceinline__ void sm_st(T v, T *p) {
+  if constexpr (sizeof(T) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+
+__global__ __launch_bounds__(256) void store_model_kernel(const int32_t *count, int64_t n_nodes, int64_t S, int32_t *action,
+                                                          double *cost, uint64_t *hash, double *state, int64_t state_stride,
+                                                          int n_fields, int pad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t W = (int64_t)gridDim.x * 4;
+  constexpr int kChunk = 4;
+  for (int64_t c0 = wave * kChunk; c0 < n_nodes; c0 += W * kChunk)
+    for (int64_t node = c0; node < c0 + kChunk && node < n_nodes; node++) {
+      const int E = count[node];
+      const int e16 = pad ? (E + 15) & ~15 : E, e32 = pad ? (E + 31) & ~31 : E;
+      const int64_t base = node * S;
+      for (int e = lane; e < e32; e += 64) {
+        if (action) sm_st((int32_t)e, &action[base + e]);
+        if (e < e16) {
+          if (hash) sm_st((uint64_t)node, &hash[base + e]);
+          if (state)
+            for (int f = 0; f < n_fields; f++) sm_st((double)f, &state[(int64_t)f * state_stride + base + e]);
+          if (cost) sm_st(1.0, &cost[base + e]);
+        }
+      }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_store_model(const int32_t *count, int64_t n_nodes, int64_t S, int32_t *action, double *cost, uint64_t *hash,
+                              double *state, int64_t state_stride, int n_fields, int pad, int blocks, hipStream_t s) {
+  if (n_nodes == 0) return hipSuccess;
+  hipLaunchKernelGGL(store_model_kernel, dim3((unsigned)blocks), dim3(256), 0, s, count, n_nodes, S, action, cost, hash, state,
+                     state_stride, n_fields, pad);
+  return hipGetLastError();
+}
+
+}  // namespace mplx

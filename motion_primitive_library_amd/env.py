@@ -703,6 +703,13 @@ class EnvMap:
         return {_abi.ROUTE_AUTO: "none", _abi.ROUTE_DENSE: "dense", _abi.ROUTE_TILE: "tile",
                 _abi.ROUTE_GRID: "grid"}[code]
 
+    def debug_store_model(self, lists, n_nodes=None):
+        """DIAGNOSTIC: the list stores of an expansion launch alone, into `lists` (mplx_debug_store_model): every node's first
+        count[k] entries of every row, unspecified values.  Overwrites the successor entries; asynchronous."""
+        self._flush()
+        s = lists.c_struct()
+        _abi.check(self._ctx, _abi.lib().mplx_debug_store_model(self._ctx, C.byref(s), lists.n_nodes if n_nodes is None else int(n_nodes)))
+
     def last_grid_kernel(self):
         """Which kernel of the GRID route the last expand_lists* call ran: "lex" (expand_lex_kernel.hip: lexicographic
         control table, no yaw, occupancy map), "grid" (expand_grid_kernel.hip), "none" (another route)."""
