@@ -244,7 +244,7 @@ hipError_t launch_build_blocked_bits(const int8_t *map, const uint32_t *region, 
 
 // store_model_kernel.hip (diagnostic): the list stores of a launch alone, into the lists themselves
 hipError_t launch_store_model(const int32_t *count, int64_t n_nodes, int64_t S, int32_t *action, double *cost, uint64_t *hash,
-                              double *state, int64_t state_stride, int n_fields, int pad, int blocks, hipStream_t s);
+                              double *state, int64_t state_stride, int n_fields, int pad, int blocks, int mode, hipStream_t s);
 
 // Batched edge re-validation (edge_kernel.hip).
 struct EdgeArgs {

@@ -4,6 +4,8 @@
 // The packed form is what the multi-GPU all-gather moves (comm_api.cpp) and what an on-device consumer reads.
 #include "mplx_ctx.h"
 
+#include <cstdlib>
+
 using namespace mplx_detail;
 
 extern "C" int mplx_pack_lists_device(mplx_ctx *c, const mplx_succ_lists *L, int64_t n_nodes, const mplx_packed_lists *o,
@@ -67,7 +69,10 @@ extern "C" int mplx_debug_store_model(mplx_ctx *c, const mplx_succ_lists *L, int
   if (int rc = resolve_pending(c)) return rc;
   const int64_t S = L->node_stride ? L->node_stride : c->nU;
   const int pad = (S % 32 == 0 && !c->tune.no_line_pad) ? 1 : 0;
+  // (experiments: MPLX_STORE_MODEL_MODE / _WGS vary the order inside a node, the nodes per chunk and the workgroups per CU)
+  const char *em = getenv("MPLX_STORE_MODEL_MODE"), *ew = getenv("MPLX_STORE_MODEL_WGS");
+  const int mode = em ? atoi(em) : 0, wgs = ew && atoi(ew) > 0 ? atoi(ew) : 5;
   HIP_TRY(c, mplx::launch_store_model(L->count, n_nodes, S, L->action, L->cost, L->hash, L->state, L->state_stride,
-                                      4 * c->dim + 2, pad, c->n_cus * 5, c->stream));
+                                      4 * c->dim + 2, pad, c->n_cus * wgs, mode, c->stream));
   return MPLX_OK;
 }
