@@ -1007,9 +1007,9 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
           const int pyr = YAW ? __umul24(jy, rowcap) + r : 0;
           auto heading_cost = [&](int k) {
             const double vx = s_vs[ptr[0] + k], vy = s_vs[ptr[1] + k];
-            const double sn = sqrt(vx * vx + vy * vy);
-            if (sn > 1e-5) {
-              const double v_value = 1 - (vx / sn * s_ycsr[(pyr + k) * 2] + vy / sn * s_ycsr[(pyr + k) * 2 + 1]);
+            double ux, uy;
+            if (heading_unit(vx, vy, ux, uy)) {
+              const double v_value = 1 - (ux * s_ycsr[(pyr + k) * 2] + uy * s_ycsr[(pyr + k) * 2 + 1]);
               csum += A.wyaw * v_value * sdt;
             }
           };
@@ -1143,11 +1143,11 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
                       }
                     }
                     if (YAW && ycost) {
-                      const double sn = sqrt(vk[0] * vk[0] + vk[1] * vk[1]);
-                      if (sn > 1e-5) {
+                      double ux, uy;
+                      if (heading_unit(vk[0], vk[1], ux, uy)) {
                         double sn_, cs_;
                         sincos(wrap_angle(uyaw_d * t_k + cyaw_d), &sn_, &cs_);
-                        const double v_value = 1 - (vk[0] / sn * cs_ + vk[1] / sn * sn_);
+                        const double v_value = 1 - (ux * cs_ + uy * sn_);
                         csum += A.wyaw * v_value * sdt;
                       }
                     }
@@ -1207,18 +1207,18 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
             if (go && k < cntl && direct) {
               const double t_k = A.ttab[n * kTabStride + k];
               const double vx = qx_d.template vel<false>(t_k), vy = qy_d.template vel<false>(t_k);
-              const double sn = sqrt(vx * vx + vy * vy);
-              if (sn > 1e-5) {
+              double ux, uy;
+              if (heading_unit(vx, vy, ux, uy)) {
                 double sn_, cs_;
                 sincos(wrap_angle(s_uyaw[jy] * t_k + s_node[4 * D]), &sn_, &cs_);
-                const double v_value = 1 - (vx / sn * cs_ + vy / sn * sn_);
+                const double v_value = 1 - (ux * cs_ + uy * sn_);
                 csum += A.wyaw * v_value * sdt;
               }
             } else if (go && k < cntl) {
               const double vx = s_vs[ptr[0] + k], vy = s_vs[ptr[1] + k];
-              const double sn = sqrt(vx * vx + vy * vy);
-              if (sn > 1e-5) {
-                const double v_value = 1 - (vx / sn * s_ycsr[(pyr + k) * 2] + vy / sn * s_ycsr[(pyr + k) * 2 + 1]);
+              double ux, uy;
+              if (heading_unit(vx, vy, ux, uy)) {
+                const double v_value = 1 - (ux * s_ycsr[(pyr + k) * 2] + uy * s_ycsr[(pyr + k) * 2 + 1]);
                 csum += A.wyaw * v_value * sdt;
               }
             }

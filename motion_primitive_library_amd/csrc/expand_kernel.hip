@@ -362,10 +362,10 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs A) {
           } else if (pv >= 100) { blocked = true; break; }
         } else if (A.map[idx] == 100) { blocked = true; break; }
         if (YAW && A.wyaw > 0) {
-          const double s = sqrt(vs[0] * vs[0] + vs[1] * vs[1]);
-          if (s > 1e-5) {
+          double ux, uy;
+          if (mplx::dev::heading_unit(vs[0], vs[1], ux, uy)) {  // (mplx_device_common.h: the same unit vector in every kernel)
             const double yw = wrap_angle(uyaw * t + cyaw);
-            const double v_value = 1 - (vs[0] / s * cos(yw) + vs[1] / s * sin(yw));
+            const double v_value = 1 - (ux * cos(yw) + uy * sin(yw));
             c += A.wyaw * v_value * sdt;
           }
         }

@@ -92,6 +92,29 @@ __device__ __forceinline__ void flag_node(int32_t *amb, int cap, int64_t node, i
   if (any_host) __hip_atomic_store(any_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- heading cost of one sample (env_map.h:121-129): v.normalized() of the sample's planar velocity, and whether
+// v.norm() > 1e-5.  The heading COST is the one quantity of this path held to north_star's 1e-6 and not to the bit (its
+// cos / sin are the device's, not glibc's: DESIGN.md 4.3), so the unit vector is v * rsqrt(v.v) -- v_rsq_f64 and two
+// Newton steps, within a few ulp of v / sqrt(v.v) -- instead of a square root and two divisions (~75 instructions per
+// pair and sample: a tenth of C5's launch).  The DECISION norm > 1e-5 stays the reference's: on v.v except within 1e-8
+// (relative) of the threshold, where the square root itself decides.  Every kernel that adds a heading cost calls this.
+__device__ __forceinline__ bool heading_unit(double vx, double vy, double &ux, double &uy) {
+  const double s2 = vx * vx + vy * vy;
+  bool go = s2 >= 1.00000001e-10;
+  const bool band = s2 > 0.99999999e-10 && !go;
+  // (a wave-uniform branch: the square root's ~25 instructions must be SKIPPED, not predicated, when no lane is in the band)
+  if (__builtin_expect(__ballot(band) != 0ull, 0)) {
+    if (band) go = sqrt(s2) > 1e-5;
+  }
+  if (!go) return false;
+  double y = __builtin_amdgcn_rsq(s2);
+  y = y * (1.5 - 0.5 * s2 * y * y);
+  y = y * (1.5 - 0.5 * s2 * y * y);
+  ux = vx * y;
+  uy = vy * y;
+  return true;
+}
+
 template <int D, int K>
 __device__ __forceinline__ uint64_t lattice_hash(const double *pos, const double *vel, const double *acc,
                                                  const double *jrk, double R001, double R01) {

@@ -139,3 +139,26 @@ def test_baseline_c5_needs_no_fix_pass(engine):
     env.expand_lists(wl.nodes, want_state=False)
     assert env.yaw_pin_stats() == (0, 0)
     env.close()
+
+
+def test_heading_cost_stays_within_a_few_ulp_of_the_reference(engine, oracle_lib):
+    """The per-sample heading cost (env_map.h:121-129) normalises the velocity with v_rsq_f64 + two Newton steps instead of
+    a square root and two divisions (mplx_device_common.h::heading_unit; its cos / sin are the device's anyway): the
+    north-star tolerance for costs is 1e-6 relative -- what the kernels deliver is 1e-13, on the lists and on the dense
+    slots alike (which share the function: they agree bit for bit, test_gpu_lists.py)."""
+    from helpers import engine_env, oracle_env
+    from test_gpu_parity import _small_world
+    worst = 0.0
+    for dim, control in ((2, 0x13), (3, 0x13), (2, 0x17), (3, 0x11)):
+        wl = _small_world(engine, dim, control, seed=6100 + dim + control, n_nodes=400)
+        wl.params["wyaw"] = 1.0
+        ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+        env = engine_env(engine, wl)
+        got = env.expand(wl.nodes)
+        env.close()
+        fin = ref["status"] == 1
+        assert np.array_equal(got["status"], ref["status"]) and fin.sum() > 100
+        rel = np.abs(got["cost"][fin] - ref["cost"][fin]) / np.abs(ref["cost"][fin])
+        worst = max(worst, float(rel.max()))
+    print("heading cost: worst relative difference to the reference arithmetic %.3g" % worst)
+    assert worst < 1e-13
