@@ -44,7 +44,7 @@ using namespace dev;
 constexpr int kLexWPB = 4;  // waves (= nodes in flight) per workgroup
 constexpr int kLexBT = 64 * kLexWPB;
 constexpr int kLexTabStride = 64;  // row stride of the global time table (launch_make_tables)
-constexpr int kLexUB = 8;          // samples per step of the sample loop
+constexpr int kLexUB8 = 8;         // samples per step of the sample loop (4 for JRK: see the kernel)
 
 // shared tables at compile-time offsets (given the table stride TS)
 constexpr int kShUval = 0;                                                             // double[3][TS]
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
 #define A (*Ak)
   typedef LexW<D, K, TS> W;
   constexpr int F = W::F, KQ = W::KQ;
+  constexpr int UB = (D == 3 && K == 3) ? 4 : kLexUB8;
   const int ndp = A.ndp, RM = A.rmax;
   const LexLds L(D, K, kLexWPB, ndp, A.nU, A.n_max, RM, A.boxcap);
   const int lane = threadIdx.x & 63;
@@ -763,10 +764,10 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
           if (fits) {
             if (WX == 1) {
               const unsigned int *bx = s_box - rowc;
-              for (int k0 = 0; __ballot(!done) != 0ull; k0 += kLexUB) {
+              for (int k0 = 0; __ballot(!done) != 0ull; k0 += UB) {
                 unsigned int m = 0;
 #pragma unroll
-                for (int q = 0; q < kLexUB; q++) {
+                for (int q = 0; q < UB; q++) {
                   const int k = k0 + q;
                   const unsigned int ex = s_cell[ptr[0] + k];
                   const int ey = s_cell[ptr[1] + k];
@@ -775,15 +776,15 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
                   m |= __builtin_amdgcn_ubfe(word, ex, 1u) << q;
                 }
                 const int left = cntl - k0;
-                if (left < kLexUB) m &= (1u << (left > 0 ? left : 0)) - 1u;
+                if (left < UB) m &= (1u << (left > 0 ? left : 0)) - 1u;
                 if (!done && m) { fb = k0 + __ffs((int)m) - 1; done = true; }
-                if (left <= kLexUB) done = true;
+                if (left <= UB) done = true;
               }
             } else {
-              for (int k0 = 0; __ballot(!done) != 0ull; k0 += kLexUB) {
+              for (int k0 = 0; __ballot(!done) != 0ull; k0 += UB) {
                 unsigned int m = 0;
 #pragma unroll
-                for (int q = 0; q < kLexUB; q++) {
+                for (int q = 0; q < UB; q++) {
                   const int k = k0 + q;
                   const int ex = s_cell[ptr[0] + k];
                   const int ey = s_cell[ptr[1] + k];
@@ -793,19 +794,19 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
                   m |= ((word >> (dx & 31)) & 1u) << q;
                 }
                 const int left = cntl - k0;
-                if (left < kLexUB) m &= (1u << (left > 0 ? left : 0)) - 1u;
+                if (left < UB) m &= (1u << (left > 0 ? left : 0)) - 1u;
                 if (!done && m) { fb = k0 + __ffs((int)m) - 1; done = true; }
-                if (left <= kLexUB) done = true;
+                if (left <= UB) done = true;
               }
             }
           } else {
             // a box too large for the LDS budget (per-step displacements far beyond the BASELINE configurations): the
-            // samples read the blocked-bit map directly, kLexUB look-ups in flight per step
-            for (int k0 = 0; __ballot(!done) != 0ull; k0 += kLexUB) {
-              unsigned int wd[kLexUB];
-              int sh[kLexUB];
+            // samples read the blocked-bit map directly, UB look-ups in flight per step
+            for (int k0 = 0; __ballot(!done) != 0ull; k0 += UB) {
+              unsigned int wd[UB];
+              int sh[UB];
 #pragma unroll
-              for (int q = 0; q < kLexUB; q++) {
+              for (int q = 0; q < UB; q++) {
                 int k = k0 + q;
                 k = k < cntl ? k : (cntl > 0 ? cntl - 1 : 0);
                 bool inside = !done;
@@ -821,10 +822,10 @@ __global__ __launch_bounds__(kLexBT) void expand_lex_kernel(const GridArgs A_ker
                 wd[q] = A.blk[inside ? (cell >> 5) : 0];
               }
 #pragma unroll
-              for (int q = 0; q < kLexUB; q++) {
+              for (int q = 0; q < UB; q++) {
                 if (!done && k0 + q < cntl && (sh[q] < 0 || ((wd[q] >> sh[q]) & 1u))) { fb = k0 + q; done = true; }
               }
-              if (k0 + kLexUB >= cntl) done = true;
+              if (k0 + UB >= cntl) done = true;
             }
           }
         }
