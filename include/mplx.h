@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MPLX_ABI_VERSION 6
+#define MPLX_ABI_VERSION 7
 
 typedef struct mplx_ctx mplx_ctx;
 
@@ -483,6 +483,12 @@ int mplx_last_lists_route(const mplx_ctx *ctx);
  * the last mplx_expand_lists* call ran: MPLX_KERNEL_NONE when the route was not GRID.                              */
 enum { MPLX_KERNEL_NONE = 0, MPLX_KERNEL_GRID = 1, MPLX_KERNEL_LEX = 2 };
 int mplx_last_grid_kernel(const mplx_ctx *ctx);
+/* ABI v7.  Which form of the node-identity pass the last mplx_post_*_device call with canon ran (all produce the
+ * same canon[]): the table in HBM (small batches), the claimed partition (buckets of fixed capacity, one host round
+ * trip to learn that none overflowed), the exact partition (histograms + prefix sums; MPLX_POST_CLAIMED=0), or the
+ * claimed one followed by the exact one because a bucket overflowed (heavy duplication of few lattice states).      */
+enum { MPLX_IDENTITY_TABLE = 0, MPLX_IDENTITY_CLAIMED = 1, MPLX_IDENTITY_EXACT = 2, MPLX_IDENTITY_CLAIMED_THEN_EXACT = 3 };
+int mplx_last_identity_form(const mplx_ctx *ctx);
 /* ABI v6, diagnostic.  The list stores of an expansion launch on their own: for every node k the first count[k] entries
  * (rounded up to whole 128-byte lines as the kernels do) of every row present in d_lists are written with UNSPECIFIED
  * values, in the expansion kernels' order and with their store policy; count[] is read, not written.  A launch whose

@@ -28,7 +28,7 @@ SYMBOLS = [
     "mplx_planner_create", "mplx_planner_destroy", "mplx_planner_attach_ctx", "mplx_planner_set_provider",
     "mplx_planner_set_map", "mplx_planner_set_controls", "mplx_planner_configure", "mplx_planner_plan",
     "mplx_planner_trajectory", "mplx_planner_trajectory_end", "mplx_planner_closed_set", "mplx_planner_open_set", "mplx_planner_last_error",
-    "mplx_selftest_math", "mplx_selftest_forward_state", "mplx_set_lists_route", "mplx_last_lists_route", "mplx_last_grid_kernel", "mplx_debug_store_model", "mplx_yaw_pin_stats", "mplx_service", "mplx_device_info",
+    "mplx_selftest_math", "mplx_selftest_forward_state", "mplx_set_lists_route", "mplx_last_lists_route", "mplx_last_grid_kernel", "mplx_last_identity_form", "mplx_debug_store_model", "mplx_yaw_pin_stats", "mplx_service", "mplx_device_info",
 ]
 
 ROUTE_AUTO, ROUTE_DENSE, ROUTE_TILE, ROUTE_GRID = 0, 1, 2, 3
@@ -185,6 +185,7 @@ def lib():
         "mplx_set_lists_route": (C.c_int, [vp, C.c_int]),
         "mplx_last_lists_route": (C.c_int, [vp]),
         "mplx_last_grid_kernel": (C.c_int, [vp]),
+        "mplx_last_identity_form": (C.c_int, [vp]),
         "mplx_debug_store_model": (C.c_int, [vp, C.POINTER(SuccLists), i64]),
         "mplx_yaw_pin_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "mplx_service": (C.c_int, [vp, C.c_int, C.POINTER(i64)]),

@@ -34,6 +34,7 @@ constexpr int kSlots = 2048;  // LDS table of one fine bucket: 24 KB, six workgr
 constexpr int kFill = 1500;   // distinct keys a round may hold before the bucket is split further (IdentityArgs::fill)
 constexpr int kMaxProbe = 192; // longest probe sequence of an insert before the round is declared overflowed
 constexpr int kChunk = 2048;  // pairs a workgroup has in flight at once in the table kernel (8 per thread)
+constexpr uint32_t kNoSlot = 0xffffffffu;
 
 __device__ __forceinline__ uint64_t mix(uint64_t h) {  // bucket / slot selection only; never leaves the device
   h ^= h >> 33;
@@ -378,60 +379,273 @@ __global__ __launch_bounds__(kBT) void id_ranges_kernel(const IdentityArgs A, ui
   A.range[b] = v;
 }
 
-// ---- one workgroup per fine bucket: identity table in LDS
-__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(6))) void id_tables_kernel(const IdentityArgs A) {
-  __shared__ unsigned long long keys[kSlots];
-  __shared__ uint32_t vals[kSlots];
-  __shared__ uint32_t nuniq, nseen, ovf, special;
-  const int64_t lo = A.range[blockIdx.x], hi = A.range[blockIdx.x + 1];
-  if (hi <= lo) return;
-  const uint64_t *hk = A.hk[A.b2 > 0 ? 1 : 0];
-  const uint32_t *gi = A.gi[A.b2 > 0 ? 1 : 0];
-  // Every sweep over the bucket has kChunk pairs (8 per thread) in flight at once, and the typical bucket IS one such
-  // chunk: it is loaded once and both sweeps (insert, look-up) run from registers.  Rounds over further hash bits when
-  // the bucket holds more distinct keys than the table takes.
-  constexpr int kPT = kChunk / kBT;
-  static_assert(kPT == 8, "the eight pairs of a thread are written out below");
-  const bool single = hi - lo <= kChunk;
-  // (eight scalars each, not arrays: hipcc kept an indexed array in scratch memory -- 200 MB of spill traffic per launch)
-  uint64_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0, h7 = 0;
-  uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, g6 = 0, g7 = 0;
-  uint32_t have = 0;  // bit i: pair i of the chunk exists
+// ---- the claimed form: no histogram passes.  Level-1 buckets are split into 8 shards (workgroup index & 7 = the XCD the
+// hardware's round-robin puts the workgroup on, and the eighth of the tiles xcd_tile() gives it): one cursor per (bucket,
+// shard), 64 bytes apart -- a single device-scope word takes ~88 returning atomics per microsecond, 12 k tiles on 64
+// words would queue for longer than the kernel runs.  A tile's pairs of one digit leave as one contiguous run at the
+// claimed offset; a run that does not fit its bucket raises the flags and is dropped (the caller falls back).
+constexpr int kShards = 8;
+constexpr int kCurPad = 16;
+
+__device__ __forceinline__ void raise_overflow(const IdentityArgs &A) {
+  *(volatile uint32_t *)A.ovf = 1u;
+  *(volatile int32_t *)A.ovf_host = 1;
+}
+
+// The pairs leave level 1 as (mix(hash), list index): the mix is a bijection, so equal keys stay equal and distinct ones
+// distinct, and level 2 and the tables take their digits, slots and round bits from the stored key -- the two 64-bit
+// multiplications of the mix (quarter-rate on this hardware; the kernels of the exact form spend most of their VALU
+// time on them, twice per pass and successor, dead list slots included) happen ONCE per successor: rows of 64 slots
+// without a successor skip them (58 % of C4's slots are padding), and the mixed key is staged through LDS (rounds of
+// 2 048 pairs: one round unless the lists are nearly full) instead of being recomputed on the way out.
+constexpr int kStage1 = 2048;
+
+__global__ __launch_bounds__(kBT) void id_part1_kernel(const IdentityArgs A) {
+  __shared__ uint32_t hist[64], lbase[64], gbase[64];
+  __shared__ uint64_t st_m[kStage1];
+  __shared__ unsigned short st_i[kStage1];
+  const TileSrc t = tile_of<1>(A, nullptr);
+  if (!t.ok) return;  // (uniform)
+  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t rk[kPer];  // rank inside the tile's share of the digit | digit << 16
+  uint64_t h[kPer];   // hash, then mixed key
+  const uint32_t ok = load_tile<1>(A, t, h);
+#pragma unroll
+  for (int i = 0; i < kPer; i++) {
+    rk[i] = 0;
+    const bool live = (ok >> i) & 1u;
+    if (__ballot(live) != 0ull) {  // (wave-uniform: a row of 64 padding slots costs nothing)
+      if (live) {
+        // every successor starts as its own first occurrence (coalesced, in list order); the table kernel only writes
+        // the duplicates
+        A.canon[t.lo + i * kBT + threadIdx.x] = (int32_t)(t.lo + i * kBT + threadIdx.x);
+        h[i] = mix(h[i]);
+        const uint32_t d = (uint32_t)((h[i] >> t.shift) & (uint64_t)(t.nb - 1));
+        rk[i] = atomicAdd(&hist[d], 1u) | (d << 16);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {  // wave 0: where the tile's share of every digit starts in LDS and in its bucket
+    const uint32_t v = hist[threadIdx.x];
+    uint32_t gb = 0xffffffffu;
+    if (v) {  // (issued before the scan: the claim's round trip overlaps it)
+      const uint32_t seg = threadIdx.x * kShards + (blockIdx.x & (kShards - 1));
+      const uint32_t o = atomicAdd(&A.cur1[seg * kCurPad], v);
+      if ((int64_t)o + (int64_t)v <= A.subcap1) gb = (uint32_t)((int64_t)seg * A.subcap1) + o;
+      else raise_overflow(A);
+    }
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+      if ((int)threadIdx.x >= d) inc += o;
+    }
+    lbase[threadIdx.x] = inc - v;
+    gbase[threadIdx.x] = gb;
+  }
+  __syncthreads();
+  const uint32_t total = lbase[63] + hist[63];
+  for (uint32_t base = 0; base < total; base += kStage1) {
+#pragma unroll
+    for (int i = 0; i < kPer; i++) {
+      if ((ok >> i) & 1u) {
+        const uint32_t p = lbase[rk[i] >> 16] + (rk[i] & 0xffffu) - base;
+        if (p < (uint32_t)kStage1) {
+          st_m[p] = h[i];
+          st_i[p] = (unsigned short)(i * kBT + threadIdx.x);
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t n = total - base < (uint32_t)kStage1 ? total - base : (uint32_t)kStage1;
+    for (uint32_t q = threadIdx.x; q < n; q += kBT) {  // consecutive lanes -> consecutive addresses inside a digit's run
+      const uint64_t m = st_m[q];
+      const uint32_t d = (uint32_t)((m >> t.shift) & (uint64_t)(t.nb - 1));
+      const uint32_t gb = gbase[d];
+      if (gb != 0xffffffffu) {
+        const uint32_t o = gb + (base + q - lbase[d]);
+        A.hk[0][o] = m;
+        A.gi[0][o] = (uint32_t)(t.lo + st_i[q]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// the (bucket, shard) segments of level 1 as tiles of level 2: tile_seg[0] = tiles, [1 + c] = pairs of segment c,
+// [1 + 512 + tile] = c << 20 | tile inside c.  One workgroup.
+__global__ __launch_bounds__(512) void id_seg_kernel(const IdentityArgs A) {
+  __shared__ uint32_t part[512];
+  const int nseg = (1 << A.b1) * kShards;
+  const int c = threadIdx.x;
+  uint32_t cnt = 0;
+  if (c < nseg) {
+    const uint32_t v = A.cur1[c * kCurPad];
+    cnt = (int64_t)v < A.subcap1 ? v : (uint32_t)A.subcap1;
+  }
+  const uint32_t nt = (cnt + kTile - 1) / kTile;
+  part[c] = nt;
+  __syncthreads();
+  for (int d = 1; d < 512; d <<= 1) {
+    const uint32_t o = c >= d ? part[c - d] : 0u;
+    __syncthreads();
+    part[c] += o;
+    __syncthreads();
+  }
+  const uint32_t before = part[c] - nt;
+  if (c == 511) A.tile_seg[0] = part[511];
+  A.tile_seg[1 + c] = cnt;
+  for (uint32_t k = 0; k < nt; k++) A.tile_seg[1 + 512 + before + k] = ((uint32_t)c << 20) | k;
+}
+
+__global__ __launch_bounds__(kBT) void id_part2_kernel(const IdentityArgs A) {
+  __shared__ uint32_t hist[256], lbase[256], gbase[256], wtot[4];
+  __shared__ uint64_t st_h[kTile];
+  __shared__ uint32_t st_g[kTile];
+  if (*A.ovf) return;  // (uniform)
+  const uint32_t n_tiles = A.tile_seg[0], tile = xcd_tile(n_tiles);
+  if (tile >= n_tiles || (blockIdx.x >> 3) >= ((n_tiles + 7u) >> 3)) return;
+  const uint32_t e = A.tile_seg[1 + 512 + tile];
+  const uint32_t c = e >> 20, tl = e & 0xfffffu;
+  const int64_t seg0 = (int64_t)c * A.subcap1;
+  const int64_t lo = seg0 + (int64_t)tl * kTile;
+  const int64_t end = seg0 + (int64_t)A.tile_seg[1 + c];
+  const int64_t hi = lo + kTile < end ? lo + kTile : end;
+  const int nb = 1 << A.b2, shift = 64 - A.b1 - A.b2;
+  const uint32_t d1 = c / kShards;
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t rk[kPer], g[kPer];
+  uint64_t h[kPer];
+  uint32_t ok = 0;
+#pragma unroll
+  for (int i = 0; i < kPer; i++) {
+    const int64_t p = lo + i * kBT + threadIdx.x;
+    ok |= (p < hi ? 1u : 0u) << i;
+    h[i] = A.hk[0][p < hi ? p : lo];
+    g[i] = A.gi[0][p < hi ? p : lo];
+  }
+#pragma unroll
+  for (int i = 0; i < kPer; i++) {
+    rk[i] = 0;
+    if ((ok >> i) & 1u) {
+      const uint32_t d = (uint32_t)((h[i] >> shift) & (uint64_t)(nb - 1));  // (the pairs carry the mixed key)
+      rk[i] = atomicAdd(&hist[d], 1u) | (d << 16);
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t v = hist[threadIdx.x];
+    uint32_t gb = 0xffffffffu;
+    if (v) {  // (issued before the scan: the claim's round trip overlaps it)
+      const uint32_t b = d1 * (uint32_t)nb + threadIdx.x;
+      const uint32_t o = atomicAdd(&A.cur2[b], v);
+      if ((int64_t)o + (int64_t)v <= A.cap2) gb = (uint32_t)((int64_t)b * A.cap2) + o;
+      else raise_overflow(A);
+    }
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+      if ((int)(threadIdx.x & 63) >= d) inc += o;
+    }
+    if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) before += wtot[w];
+    lbase[threadIdx.x] = before + inc - v;
+    gbase[threadIdx.x] = gb;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kPer; i++) {
+    if ((ok >> i) & 1u) {
+      const uint32_t p = lbase[rk[i] >> 16] + (rk[i] & 0xffffu);
+      st_h[p] = h[i];
+      st_g[p] = g[i];
+    }
+  }
+  __syncthreads();
+  // (staging in two rounds of half a tile -- 27 KB of LDS, five workgroups per CU instead of three -- measured slower,
+  // 105 -> 115 us: the kernel moves 490 MB at 4.7 TB/s and is not short of waves)
+  const uint32_t total = lbase[255] + hist[255];
+  for (uint32_t p = threadIdx.x; p < total; p += kBT) {  // consecutive lanes -> consecutive addresses inside a digit's run
+    const uint64_t hh = st_h[p];
+    const uint32_t d = (uint32_t)((hh >> shift) & (uint64_t)(nb - 1));
+    const uint32_t gb = gbase[d];
+    if (gb != 0xffffffffu) {
+      const uint32_t o = gb + (p - lbase[d]);
+      A.hk[1][o] = hh;
+      A.gi[1][o] = st_g[p];
+    }
+  }
+}
+
+// ---- the identity tables: one fine bucket per workgroup through an open-addressing table in LDS
+// the (up to) eight pairs of a thread: one chunk of a bucket.  (Eight scalars each, not arrays: hipcc kept an indexed
+// array in scratch memory -- 200 MB of spill traffic per launch.)
+struct Pairs8 {
+  uint64_t h0, h1, h2, h3, h4, h5, h6, h7;
+  uint32_t g0, g1, g2, g3, g4, g5, g6, g7;
+  uint32_t have;  // bit i: pair i of the chunk exists
+};
+struct TableCounters { uint32_t nuniq, nseen, ovf, special; };
+constexpr int kPT = kChunk / kBT;
+static_assert(kPT == 8, "the eight pairs of a thread are written out below");
+
 #define MPLX_ID_LOAD1(i_, base_)                                  \
   {                                                               \
     const int64_t p_ = (base_) + (i_) * kBT + threadIdx.x;        \
-    have |= (p_ < hi ? 1u : 0u) << (i_);                          \
-    h##i_ = hk[p_ < hi ? p_ : lo];                                \
-    g##i_ = gi[p_ < hi ? p_ : lo];                                \
+    P.have |= (p_ < hi ? 1u : 0u) << (i_);                        \
+    P.h##i_ = hk[p_ < hi ? p_ : lo];                              \
+    P.g##i_ = gi[p_ < hi ? p_ : lo];                              \
   }
 #define MPLX_ID_LOAD(base_)                                                                           \
   do {                                                                                                \
-    have = 0;                                                                                         \
+    P.have = 0;                                                                                       \
     MPLX_ID_LOAD1(0, base_) MPLX_ID_LOAD1(1, base_) MPLX_ID_LOAD1(2, base_) MPLX_ID_LOAD1(3, base_)   \
     MPLX_ID_LOAD1(4, base_) MPLX_ID_LOAD1(5, base_) MPLX_ID_LOAD1(6, base_) MPLX_ID_LOAD1(7, base_)   \
   } while (0)
-  if (single) MPLX_ID_LOAD(lo);
+
+// Barrier between phases that only hand LDS contents from wave to wave.  __syncthreads() is also a fence: the compiler
+// puts s_waitcnt vmcnt(0) in front of it, i.e. every global load in flight has to land first -- including the lines the
+// persistent kernel pulls for its NEXT bucket, whose HBM round trip would then sit in front of this bucket's first
+// barrier instead of behind its sweeps.  (The table kernels' global stores, canon[], are read by nobody in the launch.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One bucket [lo, hi) of the partitioned pairs through the workgroup's LDS table.  Every sweep over the bucket has
+// kChunk pairs (8 per thread) in flight at once, and the typical bucket IS one such chunk (`single`): the caller has it
+// in P already and both sweeps (insert, look-up) run from registers.  Rounds over further hash bits when the bucket
+// holds more distinct keys than the table takes.  PREMIXED: the pairs carry mix(hash) as their key (claimed form).
+// Ends with a barrier: the table may be reused at once.
+template <bool PREMIXED>
+__device__ __forceinline__ void table_bucket(const IdentityArgs &A, const int64_t lo, const int64_t hi, const uint64_t *hk, const uint32_t *gi,
+                                             unsigned long long *keys, uint32_t *vals, TableCounters &C, Pairs8 &P) {
+  constexpr bool premixed = PREMIXED;
+  const bool single = hi - lo <= kChunk;
   for (uint32_t R = 1;; R <<= 1) {
     bool split = false;
     for (uint32_t r = 0; r < R; r++) {
       for (int i = threadIdx.x; i < kSlots; i += kBT) { keys[i] = kEmpty; vals[i] = 0xffffffffu; }
-      if (threadIdx.x == 0) { nuniq = 0; nseen = 0; ovf = 0; special = 0xffffffffu; }
-      __syncthreads();
+      if (threadIdx.x == 0) { C.nuniq = 0; C.nseen = 0; C.ovf = 0; C.special = 0xffffffffu; }
+      lds_barrier();
       for (int64_t base = lo; base < hi; base += kChunk) {
-        if (ovf) break;  // (not uniform, no barrier inside this loop: the round is void anyway)
+        if (C.ovf) break;  // (not uniform, no barrier inside this loop: the round is void anyway)
         if (!single) MPLX_ID_LOAD(base);
         uint32_t fresh = 0;  // keys this thread put into the table | pairs it looked at << 16 (counted per wave below: one LDS atomic each per wave and chunk)
         auto insert = [&](const uint64_t hh, const uint32_t gg, const bool exists) {
-          const uint64_t m = mix(hh);
+          const uint64_t m = premixed ? hh : mix(hh);
           const bool mine = exists && ((uint32_t)(m >> 12) & (R - 1u)) == r;
           fresh += mine ? 0x10000u : 0u;
-          if (mine && hh == kEmpty) atomicMin(&special, gg);  // the one hash the key field cannot hold
+          if (mine && hh == kEmpty) atomicMin(&C.special, gg);  // the one key the key field cannot hold
           if (mine && hh != kEmpty) {
             uint32_t s = (uint32_t)m & (kSlots - 1);
             for (int probes = 0;; probes++) {
-              // plain reads first: LDS atomics are processed lane by lane, reads at full rate.  A key that is already
-              // in the table (every duplicate after the first) costs no CAS, and -- the partition keeps list order
-              // up to a tile's run -- its index is rarely smaller than the one recorded, so usually no atomicMin either.
+              // plain reads first: a key that is already in the table (every duplicate after the first) costs no CAS,
+              // and -- the partition keeps list order up to a tile's run -- its index is rarely smaller than the one
+              // recorded, so usually no atomicMin either
               unsigned long long k = keys[s];
               if (k == kEmpty) {
                 k = atomicCAS(&keys[s], (unsigned long long)kEmpty, (unsigned long long)hh);
@@ -444,36 +658,36 @@ __global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(6))) void i
               // a probe sequence this long means the table is (nearly) full: more distinct keys than `fill` are on
               // their way in; give up at once (the round is repeated with the bucket split further) instead of
               // walking a full table for every remaining pair
-              if (probes >= kMaxProbe) { ovf = 1; break; }
+              if (probes >= kMaxProbe) { C.ovf = 1; break; }
               s = (s + 1) & (kSlots - 1);
             }
           }
         };
-        insert(h0, g0, have & 1u); insert(h1, g1, have & 2u); insert(h2, g2, have & 4u); insert(h3, g3, have & 8u);
-        insert(h4, g4, have & 16u); insert(h5, g5, have & 32u); insert(h6, g6, have & 64u); insert(h7, g7, have & 128u);
+        insert(P.h0, P.g0, P.have & 1u); insert(P.h1, P.g1, P.have & 2u); insert(P.h2, P.g2, P.have & 4u); insert(P.h3, P.g3, P.have & 8u);
+        insert(P.h4, P.g4, P.have & 16u); insert(P.h5, P.g5, P.have & 32u); insert(P.h6, P.g6, P.have & 64u); insert(P.h7, P.g7, P.have & 128u);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) fresh += (uint32_t)__shfl_xor((int)fresh, d, 64);
         if ((threadIdx.x & 63) == 0 && fresh) {  // (8 pairs per lane x 64 lanes: both halves stay below 2^16)
-          if ((fresh & 0xffffu) && atomicAdd(&nuniq, fresh & 0xffffu) + (fresh & 0xffffu) > (uint32_t)A.fill) ovf = 1;
-          atomicAdd(&nseen, fresh >> 16);
+          if ((fresh & 0xffffu) && atomicAdd(&C.nuniq, fresh & 0xffffu) + (fresh & 0xffffu) > (uint32_t)A.fill) C.ovf = 1;
+          atomicAdd(&C.nseen, fresh >> 16);
         }
       }
-      __syncthreads();
-      const bool over = ovf != 0 && R < (1u << 20);  // (uniform)
+      lds_barrier();
+      const bool over = C.ovf != 0 && R < (1u << 20);  // (uniform)
       // as many keys as pairs: every pair of the round is the only one with its hash, and canon[g] = g is what the
       // level-1 pass wrote -- nothing to look up (a frontier without revisits: practically every bucket)
-      const bool all_first = nuniq == nseen && special == 0xffffffffu;
-      __syncthreads();                              // everyone has read the counters before the next round clears them
+      const bool all_first = C.nuniq == C.nseen && C.special == 0xffffffffu;
+      lds_barrier();                              // everyone has read the counters before the next round clears them
       if (over) { split = true; break; }            // split further and start the bucket over; canon writes are idempotent
       if (all_first) continue;
       for (int64_t base = lo; base < hi; base += kChunk) {
         if (!single) MPLX_ID_LOAD(base);
         auto lookup = [&](const uint64_t hh, const uint32_t gg, const bool exists) {
-          const uint64_t m = mix(hh);
+          const uint64_t m = premixed ? hh : mix(hh);
           if (exists && ((uint32_t)(m >> 12) & (R - 1u)) == r) {
             uint32_t c;
             if (hh == kEmpty) {
-              c = special;
+              c = C.special;
             } else {
               uint32_t s = (uint32_t)m & (kSlots - 1);
               int probes = 0;
@@ -483,16 +697,50 @@ __global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(6))) void i
             if (c != gg) A.canon[gg] = (int32_t)c;  // (first occurrences were written by the level-1 histogram pass)
           }
         };
-        lookup(h0, g0, have & 1u); lookup(h1, g1, have & 2u); lookup(h2, g2, have & 4u); lookup(h3, g3, have & 8u);
-        lookup(h4, g4, have & 16u); lookup(h5, g5, have & 32u); lookup(h6, g6, have & 64u); lookup(h7, g7, have & 128u);
+        lookup(P.h0, P.g0, P.have & 1u); lookup(P.h1, P.g1, P.have & 2u); lookup(P.h2, P.g2, P.have & 4u); lookup(P.h3, P.g3, P.have & 8u);
+        lookup(P.h4, P.g4, P.have & 16u); lookup(P.h5, P.g5, P.have & 32u); lookup(P.h6, P.g6, P.have & 64u); lookup(P.h7, P.g7, P.have & 128u);
       }
-      __syncthreads();
+      lds_barrier();
     }
     if (!split) break;
   }
+}
+
+// ---- exact form: one workgroup per fine bucket, the bucket's range from the prefix sums
+__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(6))) void id_tables_kernel(const IdentityArgs A) {
+  __shared__ unsigned long long keys[kSlots];
+  __shared__ uint32_t vals[kSlots];
+  __shared__ TableCounters C;
+  const int64_t lo = A.range[blockIdx.x], hi = A.range[blockIdx.x + 1];
+  if (hi <= lo) return;
+  const uint64_t *hk = A.hk[A.b2 > 0 ? 1 : 0];
+  const uint32_t *gi = A.gi[A.b2 > 0 ? 1 : 0];
+  Pairs8 P{};
+  if (hi - lo <= kChunk) MPLX_ID_LOAD(lo);
+  table_bucket<false>(A, lo, hi, hk, gi, keys, vals, C, P);
+}
+
+// ---- claimed form: one workgroup per fine bucket of fixed capacity, its pairs counted by the bucket's cursor.
+// (Persistent workgroups that fetch the next bucket's count and pull its lines into the L2 while this one is processed
+// were tried in round 4: the loads alone then take 52 us for C4, but the kernel got slower, 157 -> 198 us -- it is bound
+// by the instruction stream of the probe loops, ~25 passes of ~60 instructions per wave and bucket, not by its memory
+// round trips; profiles/README.md.)
+__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(6))) void id_tables_claimed_kernel(const IdentityArgs A) {
+  __shared__ unsigned long long keys[kSlots];
+  __shared__ uint32_t vals[kSlots];
+  __shared__ TableCounters C;
+  if (*A.ovf) return;  // (uniform) a bucket overflowed: the caller runs the exact form
+  const int64_t n = (int64_t)A.cur2[blockIdx.x];
+  const int64_t lo = (int64_t)blockIdx.x * A.cap2, hi = lo + (n < A.cap2 ? n : A.cap2);
+  if (hi <= lo) return;
+  const uint64_t *hk = A.hk[1];
+  const uint32_t *gi = A.gi[1];
+  Pairs8 P{};
+  if (hi - lo <= kChunk) MPLX_ID_LOAD(lo);
+  table_bucket<true>(A, lo, hi, hk, gi, keys, vals, C, P);
+}
 #undef MPLX_ID_LOAD1
 #undef MPLX_ID_LOAD
-}
 
 }  // namespace
 
@@ -514,6 +762,20 @@ void identity_sizes(int64_t n_slots, int b1, int b2, int64_t *tiles1, int64_t *t
 }
 
 int identity_default_fill() { return kFill; }
+
+// capacities of the claimed form: a (bucket, shard) segment of level 1 takes its even share of ALL slots + 1/8 (lists
+// are never more than full; the mixed hash spreads distinct keys evenly, so only heavy duplication of few keys overflows),
+// a fine bucket its even share + 1/4 + 512
+void identity_claimed_sizes(int64_t n_slots, int b1, int b2, int64_t *subcap1, int64_t *cap2, int64_t *pairs1, int64_t *pairs2,
+                            int64_t *tiles2_max, int64_t *cur_words) {
+  const int64_t nseg = ((int64_t)1 << b1) * kShards, buckets = (int64_t)1 << (b1 + b2);
+  *subcap1 = ((n_slots / nseg) * 9 / 8 + kTile + 15) & ~(int64_t)15;
+  *cap2 = (((n_slots >> (b1 + b2)) * 5) / 4 + 512 + 15) & ~(int64_t)15;
+  *pairs1 = nseg * *subcap1;
+  *pairs2 = buckets * *cap2;
+  *tiles2_max = *pairs1 / kTile + nseg + 1;  // (every segment: its whole tiles + one partial)
+  *cur_words = 512 * kCurPad + buckets + 64;  // level-1 cursors, level-2 cursors, the device flag
+}
 
 hipError_t launch_identity(const IdentityArgs &a, int64_t ctr1, int64_t ctr2, hipStream_t s) {
   if (a.n_slots <= 0) return hipSuccess;
@@ -537,6 +799,18 @@ hipError_t launch_identity(const IdentityArgs &a, int64_t ctr1, int64_t ctr2, hi
   }
   hipLaunchKernelGGL(id_ranges_kernel, dim3(buckets / kBT + 1), dim3(kBT), 0, s, a, buckets);
   hipLaunchKernelGGL(id_tables_kernel, dim3(buckets), dim3(kBT), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_identity_claimed(const IdentityArgs &a, int64_t cur_words, hipStream_t s) {
+  if (a.n_slots <= 0) return hipSuccess;
+  hipError_t e;
+  auto up8 = [](int64_t tiles) { return (unsigned)(((tiles + 7) / 8) * 8); };
+  if ((e = hipMemsetAsync(a.cur1, 0, (size_t)cur_words * 4, s)) != hipSuccess) return e;  // cursors of both levels + flag
+  hipLaunchKernelGGL(id_part1_kernel, dim3(up8(a.tiles1)), dim3(kBT), 0, s, a);
+  hipLaunchKernelGGL(id_seg_kernel, dim3(1), dim3(512), 0, s, a);
+  hipLaunchKernelGGL(id_part2_kernel, dim3(up8(a.tiles2_max)), dim3(kBT), 0, s, a);
+  hipLaunchKernelGGL(id_tables_claimed_kernel, dim3(1u << (a.b1 + a.b2)), dim3(kBT), 0, s, a);
   return hipGetLastError();
 }
 

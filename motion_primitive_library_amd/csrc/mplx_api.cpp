@@ -200,6 +200,7 @@ void mplx_destroy(mplx_ctx *c) {
   c->yaw_pending.clear();
   for (DevBuf *b : {&c->yaw_ring, &c->yaw_ids, &c->yaw_tab, &c->work_counter}) release(*b);
   if (c->yaw_any_host) (void)hipHostFree(c->yaw_any_host);
+  if (c->id_ovf_host) (void)hipHostFree(c->id_ovf_host);
   mplx_detail::release_copy_buffers(c);
   release(c->s_arena);
   if (c->h_arena) (void)hipHostFree(c->h_arena);
@@ -1572,6 +1573,8 @@ int mplx_last_grid_kernel(const mplx_ctx *c) {
   if (!c) return MPLX_ERR_ARG;
   return c->last_route != MPLX_ROUTE_GRID ? MPLX_KERNEL_NONE : (c->last_grid_lex ? MPLX_KERNEL_LEX : MPLX_KERNEL_GRID);
 }
+
+int mplx_last_identity_form(const mplx_ctx *c) { return c ? c->last_identity_form : MPLX_ERR_ARG; }
 
 int mplx_service(mplx_ctx *c, int mode, int64_t stats[4]) {
   if (!c) return MPLX_ERR_ARG;

@@ -303,11 +303,24 @@ struct IdentityArgs {
   int64_t n_slots, tiles1, tiles2_cap;
   int b1, b2;        // digit bits of the two levels (b2 = 0: one level)
   int fill;          // distinct keys one round of a bucket's LDS table takes (identity_default_fill(); tests lower it)
+  // claimed form (two levels only): buckets of fixed capacity, a tile claims its run of a bucket with one returning
+  // atomic on the bucket's cursor -- no histogram passes, no prefix sums.  A bucket that overflows sets *ovf_host (pinned)
+  // and the caller runs the exact form above instead.
+  int claimed;
+  uint32_t *cur1;      // [64 x 8 shards] level-1 cursors, kCurPad words apart
+  uint32_t *cur2;      // [buckets] level-2 cursors = pairs in every fine bucket
+  uint32_t *tile_seg;  // level-2 tiles: segment << 20 | tile inside the segment; [n_tiles2] behind the count at [0]
+  uint32_t *ovf;       // device copy of the overflow flag: the later launches of the same call return at once
+  int32_t *ovf_host;
+  int64_t subcap1, cap2, tiles2_max;
 };
+void identity_claimed_sizes(int64_t n_slots, int b1, int b2, int64_t *subcap1, int64_t *cap2, int64_t *pairs1, int64_t *pairs2,
+                            int64_t *tiles2_max, int64_t *cur_words);
 int identity_default_fill();
 void identity_plan(int64_t n_slots, int *b1, int *b2);
 void identity_sizes(int64_t n_slots, int b1, int b2, int64_t *tiles1, int64_t *tiles2_cap, int64_t *ctr1, int64_t *ctr2);
 hipError_t launch_identity(const IdentityArgs &a, int64_t ctr1, int64_t ctr2, hipStream_t s);
+hipError_t launch_identity_claimed(const IdentityArgs &a, int64_t cur_words, hipStream_t s);
 
 // Map preprocessing (map_prep_kernel.hip).  d, c1, c2: 3 entries (unused axes 1 / [0,1)).
 hipError_t launch_potential_passes(const int8_t *map, const int32_t *d, const int32_t *c1, const int32_t *c2, int rn,

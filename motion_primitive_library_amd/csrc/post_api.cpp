@@ -66,25 +66,79 @@ static int post_lists_impl(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t 
     int64_t ctr1 = 0, ctr2 = 0;
     mplx::identity_sizes(n, ia.b1, ia.b2, &ia.tiles1, &ia.tiles2_cap, &ctr1, &ctr2);
     const int levels = ia.b2 ? 2 : 1;
-    // one allocation: pairs of both levels, counters, block totals, segments
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    // workspace of the exact form: pairs of both levels, counters, block totals, segments
     const size_t sz_h = up((size_t)n * 8), sz_g = up((size_t)n * 4);
     const size_t sz_c1 = up((size_t)ctr1 * 4), sz_c2 = up((size_t)ctr2 * 4);
     const size_t sz_t1 = up((size_t)(ctr1 / 4096 + 1) * 4), sz_t2 = up((size_t)(ctr2 / 4096 + 1) * 4);
     const size_t sz_r = up(((size_t)1 << (ia.b1 + ia.b2)) * 4 + 4);
     const size_t total = levels * (sz_h + sz_g) + sz_c1 + sz_c2 + sz_t1 + sz_t2 + sz_r + 1024;
-    if (int rc = ensure(c, c->post_ws, total)) return rc;
-    char *w = (char *)c->post_ws.p;
-    for (int l = 0; l < levels; l++) { ia.hk[l] = (uint64_t *)w; w += sz_h; }
-    for (int l = 0; l < levels; l++) { ia.gi[l] = (uint32_t *)w; w += sz_g; }
-    ia.cnt[0] = (uint32_t *)w; w += sz_c1;
-    ia.cnt[1] = (uint32_t *)w; w += sz_c2;
-    ia.tot[0] = (uint32_t *)w; w += sz_t1;
-    ia.tot[1] = (uint32_t *)w; w += sz_t2;
-    ia.range = (uint32_t *)w; w += sz_r;
-    ia.seg = (uint32_t *)w;
-    HIP_TRY(c, mplx::launch_identity(ia, ctr1, ctr2, c->stream));
+    // ... and of the claimed form (two levels): buckets of fixed capacity, cursors, the tile table of level 2
+    const char *e_cl = getenv("MPLX_POST_CLAIMED"), *e_cap = getenv("MPLX_POST_CAP");
+    const bool claimed = levels == 2 && !(e_cl && atoi(e_cl) == 0);
+    int64_t subcap1 = 0, cap2 = 0, pairs1 = 0, pairs2 = 0, tiles2_max = 0, cur_words = 0;
+    size_t total_cl = 0, cl_h0 = 0, cl_h1 = 0, cl_g0 = 0, cl_g1 = 0, cl_cur = 0, cl_ts = 0;
+    if (claimed) {
+      mplx::identity_claimed_sizes(n, ia.b1, ia.b2, &subcap1, &cap2, &pairs1, &pairs2, &tiles2_max, &cur_words);
+      if (e_cap) {  // diagnostic: "subcap1,cap2" (smaller capacities: the overflow path)
+        long long x = 0, y = 0;
+        if (sscanf(e_cap, "%lld,%lld", &x, &y) == 2 && x >= 16 && y >= 16 && x <= subcap1 && y <= cap2) { subcap1 = x; cap2 = y; }
+      }
+      cl_h0 = up((size_t)pairs1 * 8); cl_g0 = up((size_t)pairs1 * 4);
+      cl_h1 = up((size_t)pairs2 * 8); cl_g1 = up((size_t)pairs2 * 4);
+      cl_cur = up((size_t)cur_words * 4); cl_ts = up((size_t)(1 + 512 + tiles2_max) * 4);
+      total_cl = cl_h0 + cl_g0 + cl_h1 + cl_g1 + cl_cur + cl_ts;
+    }
+    if (int rc = ensure(c, c->post_ws, total > total_cl ? total : total_cl)) return rc;
+    bool exact = !claimed;
+    c->last_identity_form = claimed ? 1 : 2;
+    if (claimed) {
+      if (!c->id_ovf_host) {
+        HIP_TRY(c, hipHostMalloc((void **)&c->id_ovf_host, 64, hipHostMallocCoherent));
+        *c->id_ovf_host = 0;
+      }
+      mplx::IdentityArgs ca = ia;
+      char *w = (char *)c->post_ws.p;
+      ca.hk[0] = (uint64_t *)w; w += cl_h0;
+      ca.hk[1] = (uint64_t *)w; w += cl_h1;
+      ca.gi[0] = (uint32_t *)w; w += cl_g0;
+      ca.gi[1] = (uint32_t *)w; w += cl_g1;
+      ca.cur1 = (uint32_t *)w;
+      ca.cur2 = ca.cur1 + 512 * 16;
+      ca.ovf = ca.cur2 + ((size_t)1 << (ia.b1 + ia.b2));
+      w += cl_cur;
+      ca.tile_seg = (uint32_t *)w;
+      ca.claimed = 1;
+      ca.ovf_host = c->id_ovf_host;
+      ca.subcap1 = subcap1;
+      ca.cap2 = cap2;
+      ca.tiles2_max = tiles2_max;
+      HIP_TRY(c, mplx::launch_identity_claimed(ca, cur_words, c->stream));
+      // heuristic and flags behind it at once (no idle GPU while the host learns the outcome), then the one host round
+      // trip of the pass: did every run fit its bucket?  Heavy duplication of few lattice states can fill one bucket
+      // beyond any fixed capacity; the exact form below has no capacities, and the (idempotent) heuristic / flags kernel
+      // runs again on its canon[].
+      HIP_TRY(c, mplx::launch_post_lists(D, a, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (*(volatile int32_t *)c->id_ovf_host == 0) return MPLX_OK;
+      *c->id_ovf_host = 0;
+      exact = true;
+      c->last_identity_form = 3;
+    }
+    if (exact) {
+      char *w = (char *)c->post_ws.p;
+      for (int l = 0; l < levels; l++) { ia.hk[l] = (uint64_t *)w; w += sz_h; }
+      for (int l = 0; l < levels; l++) { ia.gi[l] = (uint32_t *)w; w += sz_g; }
+      ia.cnt[0] = (uint32_t *)w; w += sz_c1;
+      ia.cnt[1] = (uint32_t *)w; w += sz_c2;
+      ia.tot[0] = (uint32_t *)w; w += sz_t1;
+      ia.tot[1] = (uint32_t *)w; w += sz_t2;
+      ia.range = (uint32_t *)w; w += sz_r;
+      ia.seg = (uint32_t *)w;
+      HIP_TRY(c, mplx::launch_identity(ia, ctr1, ctr2, c->stream));
+    }
   } else if (d_out->canon) {
+    c->last_identity_form = 0;
     uint64_t cap = 1024;
     while (cap < max_entries) cap <<= 1;  // >= the emitted successors whatever the frontier
     if (cap < 2 * max_entries && cap < (1ull << 27)) cap <<= 1;

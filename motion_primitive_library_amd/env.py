@@ -715,6 +715,12 @@ class EnvMap:
         control table, no yaw, occupancy map), "grid" (expand_grid_kernel.hip), "none" (another route)."""
         return {0: "none", 1: "grid", 2: "lex"}[_abi.lib().mplx_last_grid_kernel(self._ctx)]
 
+    def last_identity_form(self):
+        """Which form of the node-identity pass the last post_lists / post_packed call with canon ran: "table" (in HBM, small
+        batches), "claimed" (partition into buckets of fixed capacity), "exact" (partition by histograms),
+        "claimed+exact" (a bucket overflowed: the exact form ran after the claimed one).  Same canon[] from all."""
+        return {0: "table", 1: "claimed", 2: "exact", 3: "claimed+exact"}[_abi.lib().mplx_last_identity_form(self._ctx)]
+
     def yaw_pin_stats(self):
         """(nodes re-expanded with the host libm's trig values, fix passes launched) since the context was made."""
         a, b = C.c_int64(), C.c_int64()

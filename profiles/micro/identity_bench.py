@@ -16,7 +16,7 @@ import motion_primitive_library_amd as m  # noqa: E402
 from motion_primitive_library_amd import _abi  # noqa: E402
 
 out = {}
-wl = m.workloads.make("C4")
+wl = m.workloads.make("C4", n_nodes=int(os.environ.get("ID_BENCH_NODES", "65536")))
 env = m.EnvMap(3)
 wl.apply(env)
 L = _abi.lib()
@@ -44,7 +44,10 @@ def run(want_canon, reps=10):
     return env.timer_end() / reps
 
 
-for label, nodes in (("random", wl.nodes), ("wavefront", None)):
+legs = (("random", wl.nodes), ("wavefront", None))
+if os.environ.get("ID_BENCH_RANDOM_ONLY"):
+    legs = legs[:1]
+for label, nodes in legs:
     if nodes is None:
         nodes = m.workloads.wavefront_frontier(wl, wl.n_nodes, 0)
     fr = env.upload_frontier(nodes)
@@ -54,8 +57,12 @@ for label, nodes in (("random", wl.nodes), ("wavefront", None)):
     rec = {"successors": n_emit, "list_slots": ns}
     rec["heur_flags_only_ms"] = run(False)
     ref = None
-    for route, env_min in (("table_in_hbm", "1000000000"), ("partition_lds", "0")):
+    routes = (("table_in_hbm", "1000000000", "1"), ("partition_exact", "0", "0"), ("partition_claimed", "0", "1"))
+    if os.environ.get("ID_BENCH_SKIP_TABLE"):
+        routes = routes[1:]
+    for route, env_min, claimed in routes:
         os.environ["MPLX_POST_PARTITION_MIN"] = env_min
+        os.environ["MPLX_POST_CLAIMED"] = claimed
         ms = run(True)
         c = canon.download(np.int32, (ns,))
         cnt = lists.count.download(np.int32, (wl.n_nodes,))
@@ -64,6 +71,7 @@ for label, nodes in (("random", wl.nodes), ("wavefront", None)):
         if ref is None:
             ref = cv
         rec[route] = {"ms": ms, "identity_ms": ms - rec["heur_flags_only_ms"], "G_successors_per_s": n_emit / ms / 1e6,
+                      "form": env.last_identity_form(),
                       "first_occurrences": int(np.count_nonzero(cv == np.nonzero(valid)[0])),
                       "canon_equal_to_table_route": bool(np.array_equal(cv, ref))}
     out[label] = rec

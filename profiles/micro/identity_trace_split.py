@@ -1,16 +1,33 @@
-import csv,collections,re,sys
-rows=list(csv.DictReader(open(sys.argv[1])))
-per=collections.defaultdict(list)
+"""Per-call breakdown of the node-identity kernels from a rocprofv3 kernel trace of profiles/micro/identity_bench.py:
+    python profiles/micro/identity_trace_split.py gpurun_out/id_prof/id_kernel_trace.csv
+One line per (frontier, form): mean microseconds per kernel over the timed calls."""
+import collections, csv, re, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+groups, cur = [], []
 for r in rows:
-    n=r["Kernel_Name"]
-    m=re.search(r"(id_\w+?)(<\d>)?\(", n)
-    if m:
-        per[m.group(0).rstrip("(")].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
-tot=[0,0]
-for k,v in per.items():
-    h=len(v)//2
-    a,b=sum(v[2:h])/max(1,h-2), sum(v[h+2:])/max(1,len(v)-h-2)
-    mult = 2 if "scan" in k else 1
-    tot[0]+=a*mult; tot[1]+=b*mult
-    print("  %-24s random %7.1f  wavefront %7.1f" % (k, a, b))
-print("  sum                      random %7.1f  wavefront %7.1f" % tuple(tot))
+    m = re.search(r"(id_\w+?_kernel(<\d>)?|post_lists_kernel)", r["Kernel_Name"])
+    if not m:
+        continue
+    cur.append((m.group(1).replace("_kernel", "").replace("id_", ""), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    if m.group(1) == "post_lists_kernel":
+        groups.append(cur)
+        cur = []
+agg = collections.OrderedDict()
+for g in groups:
+    key = tuple(s for s, _ in g)
+    agg.setdefault(key, []).append([d for _, d in g])
+# consecutive runs of the same launch sequence = one (frontier, form) leg
+legs, last = [], None
+for g in groups:
+    key = tuple(s for s, _ in g)
+    if key != last:
+        legs.append((key, []))
+        last = key
+    legs[-1][1].append([d for _, d in g])
+for key, runs in legs:
+    if len(key) == 1:
+        continue
+    n = len(runs)
+    mean = [sum(r[i] for r in runs) / n for i in range(len(key))]
+    print("%2d calls: " % n + "  ".join("%s %.1f" % (k, v) for k, v in zip(key, mean)) + "  | identity sum %.1f us" % sum(mean[:-1]))

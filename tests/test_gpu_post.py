@@ -133,7 +133,11 @@ def _want_canon(h, idx):
 
 
 @pytest.mark.parametrize("knobs", [
-    {},                                                        # automatic: two partition levels at this size
+    {"_form": ("claimed", "claimed+exact")},                   # automatic: two partition levels at this size, claimed buckets
+    {"MPLX_POST_CLAIMED": "0", "_form": ("exact",)},           # ... by histograms + prefix sums
+    {"MPLX_POST_CAP": "4096,64", "_form": ("claimed+exact",)}, # fine buckets of 64 pairs: overflow -> the exact form runs after
+    {"MPLX_POST_CAP": "64,1024", "_form": ("claimed+exact",)}, # (bucket, shard) segments of 64 pairs: overflow at level 1
+    {"MPLX_POST_BITS": "2,3", "_form": ("claimed",)},          # 4 x 8 claimed buckets of ~70 k slots: rounds in every table
     {"MPLX_POST_BITS": "3,0"},                                 # one level, 8 buckets of ~50 k successors: many rounds per bucket
     {"MPLX_POST_BITS": "6,8", "MPLX_POST_FILL": "40"},         # finest partition, tiny tables: rounds in most buckets
     {"MPLX_POST_BITS": "0,0", "MPLX_POST_FILL": "900"},        # ONE bucket for everything
@@ -145,6 +149,8 @@ def test_partitioned_identity_equals_first_occurrence(engine, monkeypatch, knobs
     nodes, a lattice start region) so that buckets hold far more successors than distinct keys, for partitions finer
     and coarser than the automatic one and for tables that overflow into further rounds."""
     monkeypatch.setenv("MPLX_POST_PARTITION_MIN", "0")
+    knobs = dict(knobs)
+    forms = knobs.pop("_form", None)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     wl = engine.workloads.make("C4", scale=0.25, n_nodes=3000)
@@ -161,6 +167,8 @@ def test_partitioned_identity_equals_first_occurrence(engine, monkeypatch, knobs
     assert idx.size > 400000
     goal = wl.nodes[:, 7].copy()
     got = env.post_lists(lists, goal, tol_pos=0.6)
+    if forms:
+        assert env.last_identity_form() in forms, env.last_identity_form()
     want = _want_canon(L["hash"][idx], idx)
     assert np.array_equal(got["canon"][idx].astype(np.int64), want)
     assert np.array_equal((got["flags"][idx] & 4) != 0, want == idx)
@@ -187,6 +195,7 @@ def test_partitioned_identity_full_size_c4(engine):
     env.expand_lists_resident(fr, lists)
     env.synchronize()
     got = env.post_lists(lists, wl.nodes[:, 0].copy())
+    assert env.last_identity_form() == "claimed"
     h = lists.hash.download(np.uint64, (lists.n_slots,))
     cnt = lists.count.download(np.int32, (wl.n_nodes,))
     S = lists.stride
