@@ -641,25 +641,59 @@ __device__ __forceinline__ void table_bucket(const IdentityArgs &A, const int64_
           fresh += mine ? 0x10000u : 0u;
           if (mine && hh == kEmpty) atomicMin(&C.special, gg);  // the one key the key field cannot hold
           if (mine && hh != kEmpty) {
-            uint32_t s = (uint32_t)m & (kSlots - 1);
-            for (int probes = 0;; probes++) {
-              // plain reads first: a key that is already in the table (every duplicate after the first) costs no CAS,
-              // and -- the partition keeps list order up to a tile's run -- its index is rarely smaller than the one
-              // recorded, so usually no atomicMin either
-              unsigned long long k = keys[s];
-              if (k == kEmpty) {
-                k = atomicCAS(&keys[s], (unsigned long long)kEmpty, (unsigned long long)hh);
-                if (k == kEmpty) { fresh++; k = hh; }
-              }
-              if (k == hh) {
-                if (vals[s] > gg) atomicMin(&vals[s], gg);
-                break;
-              }
-              // a probe sequence this long means the table is (nearly) full: more distinct keys than `fill` are on
-              // their way in; give up at once (the round is repeated with the bucket split further) instead of
-              // walking a full table for every remaining pair
-              if (probes >= kMaxProbe) { C.ovf = 1; break; }
-              s = (s + 1) & (kSlots - 1);
+            // The probe loop, written out: the compiler's versions of it (four source shapes were tried) run 190 - 300
+            // instructions per 64 pairs, most of them exec-mask bookkeeping around the early exits, and the kernel is bound
+            // by exactly that instruction stream (profiles/README.md, round 4).  Here: the lanes still looking are the
+            // exec mask; a plain read first (a key that is already in the table -- every duplicate after the first --
+            // costs no CAS), a 64-bit CAS where the slot was empty (LDS atomics on scattered slots are cheap: 20 cycles per
+            // wave, profiles/micro/lds_atomic_rate.hip), lanes leave the mask when their slot holds their key.
+            uint32_t addr = ((uint32_t)m & (kSlots - 1)) * 8u;  // byte address of the slot inside keys[]
+            uint32_t won, fail;
+            unsigned long long k_, save_, tmp_, wm_;
+            uint32_t cnt_;
+            asm volatile(
+                "s_mov_b64 %[save], exec\n\t"
+                "v_mov_b32 %[won], 0\n\t"
+                "v_mov_b32 %[fail], 0\n\t"
+                "s_movk_i32 %[cnt], %[maxp]\n"
+                "1:\n\t"
+                "ds_read_b64 %[k], %[addr]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_cmp_eq_u64 vcc, -1, %[k]\n\t"
+                "s_mov_b64 %[wm], 0\n\t"
+                "s_and_saveexec_b64 %[tmp], vcc\n\t"
+                "s_cbranch_execz 2f\n\t"
+                "ds_cmpst_rtn_b64 %[k], %[addr], %[emp], %[hh]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_cmp_eq_u64 vcc, -1, %[k]\n\t"
+                "s_mov_b64 %[wm], vcc\n\t"
+                "s_nop 1\n\t"
+                "v_cndmask_b32 %[won], %[won], 1, vcc\n"
+                "2:\n\t"
+                "s_mov_b64 exec, %[tmp]\n\t"
+                "v_cmp_ne_u64 vcc, %[k], %[hh]\n\t"
+                "s_andn2_b64 vcc, vcc, %[wm]\n\t"
+                "s_and_b64 exec, exec, vcc\n\t"
+                "s_cbranch_execz 3f\n\t"
+                "v_add_u32 %[addr], 8, %[addr]\n\t"
+                "v_and_b32 %[addr], %[wrap], %[addr]\n\t"
+                "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+                "s_cmp_lg_u32 %[cnt], 0\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "v_mov_b32 %[fail], 1\n"
+                "3:\n\t"
+                "s_mov_b64 exec, %[save]\n\t"
+                : [addr] "+v"(addr), [won] "=&v"(won), [fail] "=&v"(fail), [k] "=&v"(k_), [save] "=&s"(save_), [tmp] "=&s"(tmp_), [wm] "=&s"(wm_), [cnt] "=&s"(cnt_)
+                : [hh] "v"(hh), [emp] "v"((unsigned long long)kEmpty), [wrap] "v"((uint32_t)(kSlots * 8 - 1)), [maxp] "n"(kMaxProbe + 1)
+                : "vcc", "scc", "memory");
+            fresh += won;
+            if (fail) {
+              // a probe sequence this long means the table is (nearly) full: more distinct keys than `fill` are on their
+              // way in; the round is repeated with the bucket split further
+              C.ovf = 1;
+            } else {
+              const uint32_t s = addr >> 3;
+              if (vals[s] > gg) atomicMin(&vals[s], gg);
             }
           }
         };
