@@ -187,6 +187,45 @@ def cpu_baseline(wl, target_seconds=12.0):
 
 
 # ------------------------------------------------------------------ extras (N = 1)
+def post_identity(m, env, wl, lists, reps=5):
+    """mplx_post_lists_device on resident lists: heuristic + goal flags alone, and with the node identity (canon[] = first
+    successor of the batch with the same lattice hash) -- the difference is the identity pass (identity_kernel.hip)."""
+    import ctypes as C
+    from motion_primitive_library_amd import _abi
+    L = _abi.lib()
+    ns = lists.n_slots
+    heur, flags, canon = (m.env.DeviceArray(env, ns * 8), m.env.DeviceArray(env, ns), m.env.DeviceArray(env, ns * 4))
+    goal = np.ascontiguousarray(wl.nodes[:, 0], dtype=np.float64)
+    g = _abi.GoalSpec()
+    g.goal, g.control, g.w, g.v_max = goal.ctypes.data, wl.control, 10.0, 2.0
+    g.tol_pos, g.tol_vel, g.tol_acc, g.tol_yaw = 0.5, -1.0, -1.0, -1.0
+    s = lists.c_struct()
+
+    def run(want_canon):
+        o = _abi.Post()
+        o.heur, o.flags, o.canon = heur.ptr, flags.ptr, canon.ptr if want_canon else None
+        for _ in range(2):
+            _abi.check(env._ctx, L.mplx_post_lists_device(env._ctx, C.byref(s), wl.n_nodes, C.byref(g), C.byref(o)))
+        env.synchronize()
+        env.timer_begin()
+        for _ in range(reps):
+            _abi.check(env._ctx, L.mplx_post_lists_device(env._ctx, C.byref(s), wl.n_nodes, C.byref(g), C.byref(o)))
+        return env.timer_end() / reps
+
+    base = run(False)
+    full = run(True)
+    form = env.last_identity_form()
+    c = canon.download(np.int32, (ns,))
+    cnt = lists.count.download(np.int32, (wl.n_nodes,))
+    valid = (np.arange(lists.stride)[None, :] < cnt[:, None]).ravel()
+    firsts = int(np.count_nonzero(c[valid] == np.nonzero(valid)[0]))
+    for b in (heur, flags, canon):
+        b.free()
+    n = int(cnt.sum(dtype=np.int64))
+    return {"successors": n, "first_occurrences": firsts, "heuristic_flags_ms": base, "with_identity_ms": full,
+            "identity_ms": full - base, "identity_form": form, "G_successors_per_s": n / max(full - base, 1e-9) / 1e6}
+
+
 def extra_e2e(m, wl, reps=3, want_state=True):
     """The same batch through host pointers (mplx_expand_lists): H2D of the frontier, kernel, D2H of the used list
     prefixes into the caller's pageable arrays -- SURVEY 8(d) "end-to-end incl. H2D + D2H".  want_state=False: the
@@ -442,12 +481,22 @@ def extras(m, args, wl, out):
         rounds = [(time_lists(env, fr_r, lists, args.steps, 2), time_lists(env, fr_w, lists, args.steps, 2)) for _ in range(3)]
         ms_r, ms_w = sorted(r[0] for r in rounds)[1], sorted(r[1] for r in rounds)[1]
         kname = kernel_name(env, env.last_lists_route())
+        # what the search does with the successors next: heuristic + goal flags + node identity of the
+        # whole batch on the device, on both frontiers' lists (same allocation)
+        post = {}
+        try:
+            for label, fr_x, emitted in (("random", fr_r, None), ("wavefront", fr_w, n_emit)):
+                env.expand_lists_resident(fr_x, lists)
+                env.synchronize()
+                post[label] = post_identity(m, env, wl, lists)
+        except Exception as e:  # noqa: BLE001 -- never lose the leg to the optional measurement
+            post = {"error": "%s: %s" % (type(e).__name__, e)}
         lists.free()
         fr_w.free()
         fr_r.free()
         env.close()
         b_alg = algorithmic_bytes(wl, wl.n_nodes, n_emit, n_samples)
-        return {"kernel_ms": ms_w, "value": wl.n_pairs / (ms_w * 1e-3), "random_frontier_same_allocation_ms": ms_r,
+        return {"kernel_ms": ms_w, "post": post, "value": wl.n_pairs / (ms_w * 1e-3), "random_frontier_same_allocation_ms": ms_r,
                 "ratio_to_random": ms_w / ms_r, "kernel_ms_cold": cold, "rounds_ms": [[round(a, 4), round(b, 4)] for a, b in rounds],
                 "algorithmic_bytes_per_launch": b_alg, "achieved_GBps": b_alg / (ms_w * 1e-3) / 1e9,
                 "frac": b_alg / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, "pairs": wl.n_pairs, "emitted": n_emit, "finite": n_fin,
@@ -928,6 +977,10 @@ def main():
                     out["speedup_vs_cpu_all_cores_e2e_edges_only"] = out["edges_only"]["e2e_pairs_per_s"] / out["cpu_baseline"]["value"]
                 if isinstance(out.get("wavefront"), dict) and "ratio_to_random" in out["wavefront"]:
                     out["wavefront_ratio_to_random"] = out["wavefront"]["ratio_to_random"]
+                    pst = out["wavefront"].get("post") or {}
+                    if isinstance(pst.get("random"), dict) and isinstance(pst.get("wavefront"), dict):
+                        out["post_identity_ms"] = {"random": pst["random"]["identity_ms"], "wavefront": pst["wavefront"]["identity_ms"],
+                                                   "form": pst["random"]["identity_form"]}
                 out["speedup_note"] = ("speedup_vs_cpu_all_cores: HBM-resident lists (the metric's configuration); "
                                        "..._e2e_host_pointers: the same batch through mplx_expand_lists on pageable host "
                                        "arrays, bound by the PCIe link (2.8 GB of list entries per step)")
