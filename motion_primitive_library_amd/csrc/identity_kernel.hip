@@ -8,9 +8,12 @@
 // into ONE table in HBM: 20 M successors = 20 M random 16-byte read-modify-writes, 2.8 ms on C4, 5.6 x the expansion
 // that produced them).  Here the random accesses happen in LDS instead:
 //
-//   1. radix partition of the (hash, index) pairs by the top bits of a mixed hash: at most two scatter passes
-//      (64 coarse buckets, then up to 256 fine buckets inside each), every pass = per-tile histogram, prefix sum,
-//      scatter staged through LDS so that a tile's share of a bucket leaves as one contiguous run;
+//   1. radix partition of the (key, index) pairs by the top bits of a mixed hash: at most two scatter passes (64 coarse
+//      buckets, then up to 256 fine buckets inside each), staged through LDS so that a tile's share of a bucket leaves
+//      as one contiguous run.  Two forms:
+//        exact    per pass a per-tile histogram and a prefix sum place every run (round 3; no capacities: every input);
+//        claimed  buckets of fixed capacity, a tile claims its run with one returning atomic per digit; no histogram
+//                 passes, the key mixed once (round 4: the default; an overflowing bucket makes the caller fall back);
 //   2. one workgroup per fine bucket (~1 k pairs): open-addressing table in LDS (64-bit ds_cmpst for the key,
 //      ds_min for the index), then canon[] of the bucket's pairs from the same table.
 //
@@ -19,8 +22,9 @@
 // successors than the partition was sized for) is processed in 2, 4, 8 ... rounds over further hash bits, so the
 // kernel is correct for every input and only slower for adversarial ones.
 //
-// HBM traffic per successor: 8 B hash read twice (histogram + scatter), 12 B written + read per partition level,
-// 12 B read + a scattered 4 B written by the tables: ~70 B against ~130 B of random sector traffic before.
+// HBM traffic per successor, exact form: 8 B hash read twice per level (histogram + scatter), 12 B written + read per
+// level, 12 B read + a scattered 4 B written by the tables: ~76 B; claimed form: 8 B read + 4 B canon + 12 B written,
+// 12 + 12 B at level 2, 12 B by the tables: ~60 B -- against ~130 B of random sector traffic of the table in HBM.
 #include "mplx_internal.h"
 
 namespace mplx {
@@ -34,7 +38,6 @@ constexpr int kSlots = 2048;  // LDS table of one fine bucket: 24 KB, six workgr
 constexpr int kFill = 1500;   // distinct keys a round may hold before the bucket is split further (IdentityArgs::fill)
 constexpr int kMaxProbe = 192; // longest probe sequence of an insert before the round is declared overflowed
 constexpr int kChunk = 2048;  // pairs a workgroup has in flight at once in the table kernel (8 per thread)
-constexpr uint32_t kNoSlot = 0xffffffffu;
 
 __device__ __forceinline__ uint64_t mix(uint64_t h) {  // bucket / slot selection only; never leaves the device
   h ^= h >> 33;
