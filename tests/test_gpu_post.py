@@ -207,3 +207,68 @@ def test_partitioned_identity_full_size_c4(engine):
     lists.free()
     fr.free()
     env.close()
+
+
+def _unmix(m):
+    """Inverse of identity_kernel.hip's mix (murmur3's 64-bit finaliser): the hash whose mixed key is m."""
+    M = (1 << 64) - 1
+
+    def unshift(x):  # inverse of x ^= x >> 33
+        return x ^ (x >> 33)
+
+    m = unshift(m)
+    m = (m * pow(0xc4ceb9fe1a85ec53, -1, 1 << 64)) & M
+    m = unshift(m)
+    m = (m * pow(0xff51afd7ed558ccd, -1, 1 << 64)) & M
+    return unshift(m)
+
+
+@pytest.mark.parametrize("shape", ["distinct", "few_keys", "one_key", "zipf", "special_keys"])
+@pytest.mark.parametrize("form", ["claimed", "exact"])
+def test_identity_on_synthetic_hashes(engine, monkeypatch, shape, form):
+    """The partitioned identity pass on hashes that no expansion produced: all distinct, a handful of keys, ONE key
+    (every pair in one bucket: the claimed form must notice the overflow and fall back), a Zipf mix, and the two keys the
+    tables cannot store as they are -- ~0 (the empty marker of the exact form's tables) and the hash whose MIXED key is
+    ~0 (the empty marker of the claimed form's, which stores mixed keys) -- among ordinary ones.  Packed lists (one
+    long list: mplx_post_packed_device), canon[] against numpy."""
+    monkeypatch.setenv("MPLX_POST_PARTITION_MIN", "0")
+    monkeypatch.setenv("MPLX_POST_CLAIMED", "1" if form == "claimed" else "0")
+    assert _unmix(0xFFFFFFFFFFFFFFFF) != 0xFFFFFFFFFFFFFFFF
+    n = 1_500_000
+    rng = np.random.default_rng(abs(hash(shape)) % 1000)
+    if shape == "distinct":
+        h = rng.permutation(np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+    elif shape == "few_keys":
+        h = rng.integers(1, 40, size=n).astype(np.uint64) * np.uint64(0x123456789ABCDEF1)
+    elif shape == "one_key":
+        h = np.full(n, 0xDEADBEEFCAFEF00D, dtype=np.uint64)
+    elif shape == "zipf":
+        h = (rng.zipf(1.3, size=n).astype(np.uint64) % np.uint64(200_000)) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(7)
+    else:
+        h = rng.integers(1, 1 << 62, size=n, dtype=np.int64).astype(np.uint64)
+        sp = rng.choice(n - 1, size=900, replace=False) + 1
+        h[sp[:300]] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        h[sp[300:600]] = np.uint64(_unmix(0xFFFFFFFFFFFFFFFF))
+        h[sp[600:]] = h[sp[600:] - 1]  # some ordinary duplicates as well
+    wl = engine.workloads.make("C2", scale=0.125, n_nodes=8)
+    env = engine_env(engine, wl)
+    F = 4 * wl.dim + 2
+    offs = engine.env.DeviceArray(env, 16)
+    offs.upload(np.array([0, n], dtype=np.int64))
+    hd = engine.env.DeviceArray(env, n * 8)
+    hd.upload(h)
+    st = engine.env.DeviceArray(env, F * n * 8)
+    st.upload(np.zeros(F * n, dtype=np.float64))
+    ps = engine._abi.PackedLists()
+    ps.count, ps.offs, ps.action, ps.cost, ps.hash, ps.state = None, offs.ptr, None, None, hd.ptr, st.ptr
+    ps.state_stride, ps.capacity = n, n
+    got = env.post_packed(ps, 1, np.zeros(F))
+    used = env.last_identity_form()
+    # (a key with more duplicates than a fine bucket's capacity -- one_key, few_keys, the head of the Zipf mix -- overflows)
+    assert used == {"claimed": "claimed+exact" if shape in ("one_key", "few_keys", "zipf") else "claimed", "exact": "exact"}[form], used
+    want = _want_canon(h, np.arange(n, dtype=np.int64))
+    assert np.array_equal(got["canon"].astype(np.int64), want)
+    assert np.array_equal((got["flags"] & 4) != 0, want == np.arange(n))
+    for b in (offs, hd, st):
+        b.free()
+    env.close()
