@@ -32,7 +32,7 @@ for seed in range(first, first + count):
         else:
             os.environ.pop(var, None)
     try:
-        wl, control, pot = odd_world(m, seed, n_nodes)
+        wl, control, pot = odd_world(m, seed, n_nodes, decorrelate=seed >= 20000)
         if seed % 3 == 0:
             wl.nodes[wl.dim:4 * wl.dim, ::int(rng.choice([3, 7, 50]))] = 0.0
         if seed % 5 == 0 and not (control & 0x10) and wl.dim == 2:
