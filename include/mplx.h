@@ -221,7 +221,11 @@ typedef struct {
 } mplx_post;
 
 /* d_lists: the lists as filled by mplx_expand_lists_device (count, hash and
- * state are read).  Asynchronous on the context stream.                      */
+ * state are read).  Asynchronous on the context stream -- except with canon on
+ * batches of >= 256 k list slots (ABI v7): their node identity claims runs in
+ * buckets of fixed capacity, and the call waits for the stream ONCE, after
+ * queueing everything, to learn that no bucket overflowed (then it returns), or
+ * else runs the capacity-free form behind it (mplx_last_identity_form).        */
 int mplx_post_lists_device(mplx_ctx *ctx, const mplx_succ_lists *d_lists, int64_t n_nodes,
                            const mplx_goal_spec *goal, const mplx_post *d_out);
 
