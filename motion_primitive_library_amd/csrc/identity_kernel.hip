@@ -143,15 +143,27 @@ __device__ __forceinline__ uint32_t load_tile(const IdentityArgs &A, const TileS
     } else {
       int cn[kPer];
       uint32_t jj[kPer];
+      const bool wide = A.nstride >= kBT;  // (uniform) a row of kBT slots crosses at most one node boundary
+      uint32_t q_run = 0, j_run = 0;
 #pragma unroll
       for (int i = 0; i < kPer; i++) {
-        // node = slot / nstride without a division per slot: x = (offset of the tile inside its first node) + (slot
-        // inside the tile) < nstride + 4096 < 2^24 is exact in f32, so the f32 quotient is off by at most one
-        const uint32_t x = t.r0 + (uint32_t)(i * kBT + threadIdx.x);
-        uint32_t q = (uint32_t)((float)x * t.inv);
-        if (q * (uint32_t)A.nstride > x) q--;
-        else if ((q + 1) * (uint32_t)A.nstride <= x) q++;
-        jj[i] = x - q * (uint32_t)A.nstride;
+        uint32_t q;
+        if (i == 0 || !wide) {
+          // node = slot / nstride without a division per slot: x = (offset of the tile inside its first node) + (slot
+          // inside the tile) < nstride + 4096 < 2^24 is exact in f32, so the f32 quotient is off by at most one
+          const uint32_t x = t.r0 + (uint32_t)(i * kBT + threadIdx.x);
+          q = (uint32_t)((float)x * t.inv);
+          if (q * (uint32_t)A.nstride > x) q--;
+          else if ((q + 1) * (uint32_t)A.nstride <= x) q++;
+          jj[i] = x - q * (uint32_t)A.nstride;
+        } else {  // ... and without the quotient from the second row on: kBT slots further, at most one node further
+          j_run += (uint32_t)kBT;
+          const bool over = j_run >= (uint32_t)A.nstride;
+          jj[i] = over ? j_run - (uint32_t)A.nstride : j_run;
+          q = q_run + (over ? 1u : 0u);
+        }
+        q_run = q;
+        j_run = jj[i];
         const int64_t node = (int64_t)t.node0 + q;
         cn[i] = A.count[node < A.n_nodes ? node : A.n_nodes - 1];
       }
