@@ -34,7 +34,8 @@ constexpr uint64_t kEmpty = ~0ull;
 constexpr int kTile = 4096;   // pairs (or list slots) per workgroup and pass
 constexpr int kBT = 256;
 constexpr int kPer = kTile / kBT;
-constexpr int kSlots = 2048;  // LDS table of one fine bucket: 24 KB, six workgroups per CU
+constexpr int kSlots = 2048;  // LDS table of one fine bucket: keys + indices 24 KB
+constexpr int kSlotsKeys = 3584;  // ... and the keys-only table of the first sweep over the same LDS: 28 KB, five workgroups per CU
 constexpr int kFill = 1500;   // distinct keys a round may hold before the bucket is split further (IdentityArgs::fill)
 constexpr int kMaxProbe = 192; // longest probe sequence of an insert before the round is declared overflowed
 constexpr int kChunk = 2048;  // pairs a workgroup has in flight at once in the table kernel (8 per thread)
@@ -640,6 +641,79 @@ __device__ __forceinline__ void table_bucket(const IdentityArgs &A, const int64_
                                              unsigned long long *keys, uint32_t *vals, TableCounters &C, Pairs8 &P) {
   constexpr bool premixed = PREMIXED;
   const bool single = hi - lo <= kChunk;
+  if (single) {
+    // A first sweep over keys alone, in a table of kSlotsKeys = 3 584 slots over the SAME LDS (28 KB = the 2 048 keys +
+    // 2 048 indices of the general table below and the unused quarter behind them): a bucket whose pairs all have different keys
+    // -- every bucket of a frontier without revisits -- is done after it, canon[g] = g is what level 1 wrote, and at a third
+    // of the load the slowest lane of a wave probes half as far.  Any duplicate (or one of the two unstorable keys) sends
+    // the bucket through the general sweeps: there the extra pass costs a few plain reads per pair.
+    unsigned long long *big = keys;
+    for (int i = threadIdx.x; i < kSlotsKeys; i += kBT) big[i] = kEmpty;
+    if (threadIdx.x == 0) { C.nuniq = 0; C.nseen = 0; C.ovf = 0; C.special = 0xffffffffu; }
+    lds_barrier();
+    uint32_t fresh = 0;
+    auto insert0 = [&](const uint64_t hh, const bool exists) {
+      if (!exists) return;
+      fresh += 0x10000u;
+      if (hh == kEmpty) { C.ovf = 1; return; }
+      const uint64_t m = premixed ? hh : mix(hh);
+      uint32_t addr = (uint32_t)(((uint64_t)(uint32_t)m * (uint64_t)kSlotsKeys) >> 32) * 8u;
+      uint32_t won, fail;
+      unsigned long long k_, save_, tmp_, wm_;
+      uint32_t cnt_;
+      asm volatile(
+          "s_mov_b64 %[save], exec\n\t"
+          "v_mov_b32 %[won], 0\n\t"
+          "v_mov_b32 %[fail], 0\n\t"
+          "s_movk_i32 %[cnt], %[maxp]\n"
+          "1:\n\t"
+          "ds_read_b64 %[k], %[addr]\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "v_cmp_eq_u64 vcc, -1, %[k]\n\t"
+          "s_mov_b64 %[wm], 0\n\t"
+          "s_and_saveexec_b64 %[tmp], vcc\n\t"
+          "s_cbranch_execz 2f\n\t"
+          "ds_cmpst_rtn_b64 %[k], %[addr], %[emp], %[hh]\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "v_cmp_eq_u64 vcc, -1, %[k]\n\t"
+          "s_mov_b64 %[wm], vcc\n\t"
+          "s_nop 1\n\t"
+          "v_cndmask_b32 %[won], %[won], 1, vcc\n"
+          "2:\n\t"
+          "s_mov_b64 exec, %[tmp]\n\t"
+          "v_cmp_ne_u64 vcc, %[k], %[hh]\n\t"
+          "s_andn2_b64 vcc, vcc, %[wm]\n\t"
+          "s_and_b64 exec, exec, vcc\n\t"
+          "s_cbranch_execz 3f\n\t"
+          "v_add_u32 %[addr], 8, %[addr]\n\t"
+          "v_cmp_eq_u32 vcc, %[size], %[addr]\n\t"
+          "s_nop 1\n\t"
+          "v_cndmask_b32 %[addr], %[addr], 0, vcc\n\t"
+          "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+          "s_cmp_lg_u32 %[cnt], 0\n\t"
+          "s_cbranch_scc1 1b\n\t"
+          "v_mov_b32 %[fail], 1\n"
+          "3:\n\t"
+          "s_mov_b64 exec, %[save]\n\t"
+          : [addr] "+v"(addr), [won] "=&v"(won), [fail] "=&v"(fail), [k] "=&v"(k_), [save] "=&s"(save_), [tmp] "=&s"(tmp_), [wm] "=&s"(wm_), [cnt] "=&s"(cnt_)
+          : [hh] "v"(hh), [emp] "v"((unsigned long long)kEmpty), [size] "v"((uint32_t)(kSlotsKeys * 8)), [maxp] "n"(kMaxProbe + 1)
+          : "vcc", "scc", "memory");
+      fresh += won;
+      if (fail) C.ovf = 1;
+    };
+    insert0(P.h0, P.have & 1u); insert0(P.h1, P.have & 2u); insert0(P.h2, P.have & 4u); insert0(P.h3, P.have & 8u);
+    insert0(P.h4, P.have & 16u); insert0(P.h5, P.have & 32u); insert0(P.h6, P.have & 64u); insert0(P.h7, P.have & 128u);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) fresh += (uint32_t)__shfl_xor((int)fresh, d, 64);
+    if ((threadIdx.x & 63) == 0 && fresh) {
+      if (fresh & 0xffffu) atomicAdd(&C.nuniq, fresh & 0xffffu);
+      atomicAdd(&C.nseen, fresh >> 16);
+    }
+    lds_barrier();
+    const bool clean = C.ovf == 0 && C.nuniq == C.nseen;  // (uniform)
+    lds_barrier();  // everyone has read the counters before the general sweeps clear them
+    if (clean) return;
+  }
   for (uint32_t R = 1;; R <<= 1) {
     bool split = false;
     for (uint32_t r = 0; r < R; r++) {
@@ -756,9 +830,10 @@ __device__ __forceinline__ void table_bucket(const IdentityArgs &A, const int64_
 }
 
 // ---- exact form: one workgroup per fine bucket, the bucket's range from the prefix sums
-__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(6))) void id_tables_kernel(const IdentityArgs A) {
-  __shared__ unsigned long long keys[kSlots];
-  __shared__ uint32_t vals[kSlots];
+__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(5))) void id_tables_kernel(const IdentityArgs A) {
+  __shared__ unsigned long long keys[kSlotsKeys];  // (general table: keys[0 .. kSlots), the indices behind them)
+  uint32_t *vals = (uint32_t *)(keys + kSlots);
+  static_assert(kSlots * 12 <= kSlotsKeys * 8, "keys + indices of the general table inside the keys-only one");
   __shared__ TableCounters C;
   const int64_t lo = A.range[blockIdx.x], hi = A.range[blockIdx.x + 1];
   if (hi <= lo) return;
@@ -774,9 +849,10 @@ __global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(6))) void i
 // were tried in round 4: the loads alone then take 52 us for C4, but the kernel got slower, 157 -> 198 us -- it is bound
 // by the instruction stream of the probe loops, ~25 passes of ~60 instructions per wave and bucket, not by its memory
 // round trips; profiles/README.md.)
-__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(6))) void id_tables_claimed_kernel(const IdentityArgs A) {
-  __shared__ unsigned long long keys[kSlots];
-  __shared__ uint32_t vals[kSlots];
+__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(5))) void id_tables_claimed_kernel(const IdentityArgs A) {
+  __shared__ unsigned long long keys[kSlotsKeys];  // (general table: keys[0 .. kSlots), the indices behind them)
+  uint32_t *vals = (uint32_t *)(keys + kSlots);
+  static_assert(kSlots * 12 <= kSlotsKeys * 8, "keys + indices of the general table inside the keys-only one");
   __shared__ TableCounters C;
   if (*A.ovf) return;  // (uniform) a bucket overflowed: the caller runs the exact form
   const int64_t n = (int64_t)A.cur2[blockIdx.x];
