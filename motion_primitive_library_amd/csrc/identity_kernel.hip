@@ -513,6 +513,20 @@ __global__ __launch_bounds__(512) void id_seg_kernel(const IdentityArgs A) {
   const uint32_t before = part[c] - nt;
   if (c == 511) A.tile_seg[0] = part[511];
   A.tile_seg[1 + c] = cnt;
+  {  // the capacity the fine buckets are USED with: 3/2 of the mean bucket + 512 pairs, at most the allocated one (which
+     // is sized for lists without padding).  Tighter buckets = the pairs of level 2 in 60 % of the address range: fewer
+     // pages and DRAM rows under the table kernel's 16 k concurrent streams.  An overflow falls back like any other.
+    __shared__ uint32_t live;
+    if (c == 0) live = 0;
+    __syncthreads();
+    if (cnt) atomicAdd(&live, cnt);
+    __syncthreads();
+    if (c == 0) {
+      const int64_t mean = (int64_t)(live >> (A.b1 + A.b2));
+      int64_t cap = (mean + (mean >> 1) + 512 + 15) & ~(int64_t)15;
+      A.ovf[1] = (uint32_t)(cap < A.cap2 ? cap : A.cap2);
+    }
+  }
   for (uint32_t k = 0; k < nt; k++) A.tile_seg[1 + 512 + before + k] = ((uint32_t)c << 20) | k;
 }
 
@@ -520,7 +534,8 @@ __global__ __launch_bounds__(kBT) void id_part2_kernel(const IdentityArgs A) {
   __shared__ uint32_t hist[256], lbase[256], gbase[256], wtot[4];
   __shared__ uint64_t st_h[kTile];
   __shared__ uint32_t st_g[kTile];
-  if (*A.ovf) return;  // (uniform)
+  if (A.ovf[0]) return;  // (uniform)
+  const int64_t cap2 = (int64_t)A.ovf[1];  // (id_seg_kernel)
   const uint32_t n_tiles = A.tile_seg[0], tile = xcd_tile(n_tiles);
   if (tile >= n_tiles || (blockIdx.x >> 3) >= ((n_tiles + 7u) >> 3)) return;
   const uint32_t e = A.tile_seg[1 + 512 + tile];
@@ -558,7 +573,7 @@ __global__ __launch_bounds__(kBT) void id_part2_kernel(const IdentityArgs A) {
     if (v) {  // (issued before the scan: the claim's round trip overlaps it)
       const uint32_t b = d1 * (uint32_t)nb + threadIdx.x;
       const uint32_t o = atomicAdd(&A.cur2[b], v);
-      if ((int64_t)o + (int64_t)v <= A.cap2) gb = (uint32_t)((int64_t)b * A.cap2) + o;
+      if ((int64_t)o + (int64_t)v <= cap2) gb = (uint32_t)((int64_t)b * cap2) + o;
       else raise_overflow(A);
     }
     uint32_t inc = v;
@@ -854,9 +869,10 @@ __global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(5))) void i
   uint32_t *vals = (uint32_t *)(keys + kSlots);
   static_assert(kSlots * 12 <= kSlotsKeys * 8, "keys + indices of the general table inside the keys-only one");
   __shared__ TableCounters C;
-  if (*A.ovf) return;  // (uniform) a bucket overflowed: the caller runs the exact form
+  if (A.ovf[0]) return;  // (uniform) a bucket overflowed: the caller runs the exact form
+  const int64_t cap2 = (int64_t)A.ovf[1];  // the capacity the buckets were filled with (id_seg_kernel)
   const int64_t n = (int64_t)A.cur2[blockIdx.x];
-  const int64_t lo = (int64_t)blockIdx.x * A.cap2, hi = lo + (n < A.cap2 ? n : A.cap2);
+  const int64_t lo = (int64_t)blockIdx.x * cap2, hi = lo + (n < cap2 ? n : cap2);
   if (hi <= lo) return;
   const uint64_t *hk = A.hk[1];
   const uint32_t *gi = A.gi[1];
