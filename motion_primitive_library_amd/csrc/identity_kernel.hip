@@ -35,7 +35,7 @@ constexpr int kTile = 4096;   // pairs (or list slots) per workgroup and pass
 constexpr int kBT = 256;
 constexpr int kPer = kTile / kBT;
 constexpr int kSlots = 2048;  // LDS table of one fine bucket: keys + indices 24 KB
-constexpr int kSlotsKeys = 3584;  // ... and the keys-only table of the first sweep over the same LDS: 28 KB, five workgroups per CU
+constexpr int kSlotsKeys = 3328;  // ... and the keys-only table of the first sweep over the same LDS: 26 KB, still six workgroups per CU
 constexpr int kFill = 1500;   // distinct keys a round may hold before the bucket is split further (IdentityArgs::fill)
 constexpr int kMaxProbe = 192; // longest probe sequence of an insert before the round is declared overflowed
 constexpr int kChunk = 2048;  // pairs a workgroup has in flight at once in the table kernel (8 per thread)
@@ -657,10 +657,11 @@ __device__ __forceinline__ void table_bucket(const IdentityArgs &A, const int64_
   constexpr bool premixed = PREMIXED;
   const bool single = hi - lo <= kChunk;
   if (single) {
-    // A first sweep over keys alone, in a table of kSlotsKeys = 3 584 slots over the SAME LDS (28 KB = the 2 048 keys +
-    // 2 048 indices of the general table below and the unused quarter behind them): a bucket whose pairs all have different keys
-    // -- every bucket of a frontier without revisits -- is done after it, canon[g] = g is what level 1 wrote, and at a third
-    // of the load the slowest lane of a wave probes half as far.  Any duplicate (or one of the two unstorable keys) sends
+    // A first sweep over keys alone, in a table of kSlotsKeys = 3 328 slots over the SAME LDS (26 KB = the 2 048 keys +
+    // 2 048 indices of the general table below and 2 KB more): a bucket whose pairs all have different keys -- every bucket
+    // of a frontier without revisits -- is done after it, canon[g] = g is what level 1 wrote, and at a load of 0.37
+    // instead of 0.61 the slowest lane of a wave probes half as far (3 072 and 3 584 slots -- the latter five workgroups
+    // per CU -- measured 1 - 6 % slower).  Any duplicate (or one of the two unstorable keys) sends
     // the bucket through the general sweeps: there the extra pass costs a few plain reads per pair.
     unsigned long long *big = keys;
     for (int i = threadIdx.x; i < kSlotsKeys; i += kBT) big[i] = kEmpty;
@@ -845,7 +846,7 @@ __device__ __forceinline__ void table_bucket(const IdentityArgs &A, const int64_
 }
 
 // ---- exact form: one workgroup per fine bucket, the bucket's range from the prefix sums
-__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(5))) void id_tables_kernel(const IdentityArgs A) {
+__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(6))) void id_tables_kernel(const IdentityArgs A) {
   __shared__ unsigned long long keys[kSlotsKeys];  // (general table: keys[0 .. kSlots), the indices behind them)
   uint32_t *vals = (uint32_t *)(keys + kSlots);
   static_assert(kSlots * 12 <= kSlotsKeys * 8, "keys + indices of the general table inside the keys-only one");
@@ -864,7 +865,7 @@ __global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(5))) void i
 // were tried in round 4: the loads alone then take 52 us for C4, but the kernel got slower, 157 -> 198 us -- it is bound
 // by the instruction stream of the probe loops, ~25 passes of ~60 instructions per wave and bucket, not by its memory
 // round trips; profiles/README.md.)
-__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(5))) void id_tables_claimed_kernel(const IdentityArgs A) {
+__global__ __launch_bounds__(kBT) __attribute__((amdgpu_waves_per_eu(6))) void id_tables_claimed_kernel(const IdentityArgs A) {
   __shared__ unsigned long long keys[kSlotsKeys];  // (general table: keys[0 .. kSlots), the indices behind them)
   uint32_t *vals = (uint32_t *)(keys + kSlots);
   static_assert(kSlots * 12 <= kSlotsKeys * 8, "keys + indices of the general table inside the keys-only one");
