@@ -31,10 +31,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <deque>
-#include <queue>
-#include <unordered_map>
+#include <new>
 #include <vector>
+
+#include <sys/mman.h>
 
 namespace mplx {
 namespace host {
@@ -151,137 +151,178 @@ struct SuccView {
   int64_t fs = 1, es = 1;
 };
 
-struct Node;
-typedef Node *NodePtr;  // nodes live in Planner::pool (a deque: stable addresses, one allocation per block)
-
-// state_space.h:37-70 (A* fields)
-struct Node {
-  // the fields every relaxation touches share the first cache line
-  double g = kInf, rhs = kInf, h = kInf;
-  // pred_coord / pred_action_cost / pred_action_id of state_space.h:49-53: a list threaded through the
-  // planner's one pool of records (Planner::preds), in insertion order -- no allocation per node
-  int32_t pred_head = -1, pred_tail = -1;
-  int heap_pos = -1;
-  bool opened = false, closed = false;
-  bool cached = false;  // successor cache (batched expansion)
-  uint64_t key = 0;
-  double coord[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 4D+2 used
-  std::vector<double> c_succ;
-  std::vector<double> c_cost;
-  std::vector<int32_t> c_act;
-  std::vector<uint64_t> c_key;  // lattice hashes of the cached successors (when the provider supplies them)
-  // packed provider: one recycled buffer [cost m][hash m][state (4D+2) x m][action m] (Planner::take_blob)
-  char *c_blob = nullptr;
-  int32_t c_m = 0;
-  // ... or, until the next launch, the node's index in the provider's own landing buffer (Planner::cur_view)
-  int32_t c_slot = -1;
-  uint32_t c_batch = 0;
-  uint32_t pick_stamp = 0;  // launch for which the node was last picked (a re-opened node sits in the heap twice)
-  bool c_has_state = true;
+// ---- the search's bookkeeping (StateSpace of the reference, state_space.h:37-104), laid out for the relaxation loop.
+// A 3D search with hundreds of controls relaxes 300+ edges per expansion and eight in ten of them neither create a
+// node nor improve one: all such a relaxation needs is the child's g and the head of its predecessor list.  Both live
+// INSIDE the hash table's slot, so that relaxation is one cache line (the slot, prefetched ahead through the device's
+// lattice hashes) plus a sequential append to the predecessor pool.  Everything else about a node -- heuristic, heap
+// handle, flags, where its state comes from -- is in `Cold`, touched only when a node is created, improved, picked
+// for a launch or popped.  Nodes are 32-bit indices in creation order; their 4D+2 coordinates are not stored at
+// creation: a node remembers the (parent, control) that created it (the reference keeps the state of the FIRST
+// parent that reached a lattice hash, graph_search.h:83-85) and forward_state() rebuilds exactly that state if and
+// when the node is picked for expansion -- one node in fifteen on the 3D problems.
+struct Slot {          // hm_ of the reference (state_space.h:78): lattice hash -> node, plus the node's hot fields
+  uint64_t key;
+  double g;            // State::g (state_space.h:58)
+  uint32_t idx;        // node index (creation order)
+  int32_t pred_head;   // newest record of the node's predecessor list (Planner::preds), -1 = none
+  uint32_t epoch;      // slot is live iff epoch == table epoch (clear() is O(1): planners are re-used plan after plan)
+  uint32_t pad;
 };
+static_assert(sizeof(Slot) == 32, "two slots per cache line");
 
-// hm_ of the reference's StateSpace (state_space.h:78): lattice hash -> node.  Open addressing with linear
-// probing, key and pointer side by side (one cache line per look-up at millions of nodes, where a node-based
-// std::unordered_map takes three); prefetch() lets the relaxation loop hide that one miss.
-class NodeMap {
+class NodeTable {
  public:
-  // The slot of `key`, created empty (nullptr) when absent; the caller fills a new slot at once.
-  NodePtr &operator[](uint64_t key) {
-    if ((n_ + 1) * 10 > cap_ * 6) grow();
-    size_t i = slot(key);
-    while (slots_[i].val) {
-      if (slots_[i].key == key) return slots_[i].val;
-      i = (i + 1) & (cap_ - 1);
-    }
-    slots_[i].key = key;
-    n_++;
-    return slots_[i].val;
+  ~NodeTable() { std::free(s_); }
+  NodeTable() = default;
+  NodeTable(const NodeTable &) = delete;
+  NodeTable &operator=(const NodeTable &) = delete;
+  static constexpr uint32_t kNoIndex = 0xffffffffu;
+  // Room for `more` insertions without a rehash: slot pointers stay valid that long.
+  void reserve(size_t more) {
+    while ((n_ + more) * 10 > cap_ * 6) grow();
   }
-  // The node of `key` or nullptr, without inserting.
-  NodePtr peek(uint64_t key) const {
-    if (!cap_) return nullptr;
-    size_t i = slot(key);
-    while (slots_[i].val) {
-      if (slots_[i].key == key) return slots_[i].val;
-      i = (i + 1) & (cap_ - 1);
+  // The slot of `key`; `fresh` says it was created by this call (g = inf, no predecessors, idx = kNoIndex until the
+  // caller numbers the node).  Call reserve() first; the pointer is valid until the next reserve().
+  Slot *insert(uint64_t key, bool *fresh) {
+    size_t i = home(key);
+    for (;; i = (i + 1) & (cap_ - 1)) {
+      Slot &s = s_[i];
+      if (s.epoch != epoch_) {
+        s.key = key;
+        s.g = kInf;
+        s.idx = kNoIndex;
+        s.pred_head = -1;
+        s.epoch = epoch_;
+        n_++;
+        *fresh = true;
+        return &s;
+      }
+      if (s.key == key) { *fresh = false; return &s; }
     }
-    return nullptr;
+  }
+  Slot *find(uint64_t key) const {
+    if (!cap_) return nullptr;
+    for (size_t i = home(key);; i = (i + 1) & (cap_ - 1)) {
+      Slot &s = s_[i];
+      if (s.epoch != epoch_) return nullptr;
+      if (s.key == key) return &s;
+    }
   }
   void prefetch(uint64_t key) const {
-    if (cap_) __builtin_prefetch(&slots_[slot(key)]);
+    if (cap_) __builtin_prefetch(&s_[home(key)]);
   }
   size_t size() const { return n_; }
   void clear() {
-    std::fill(slots_.begin(), slots_.end(), Slot{0, nullptr});
     n_ = 0;
+    if (++epoch_ == 0) {  // (4 G plans later)
+      std::memset((void *)s_, 0, cap_ * sizeof(Slot));
+      epoch_ = 1;
+    }
   }
 
  private:
-  struct Slot { uint64_t key; NodePtr val; };
-  size_t slot(uint64_t k) const {
+  size_t home(uint64_t k) const {
     k ^= k >> 33;
     k *= 0xff51afd7ed558ccdULL;
     k ^= k >> 33;
     return (size_t)k & (cap_ - 1);
   }
-  void grow() {
-    std::vector<Slot> old;
-    old.swap(slots_);
-    cap_ = cap_ ? cap_ * 2 : 1024;
-    slots_.assign(cap_, Slot{0, nullptr});
-    for (const Slot &o : old)
-      if (o.val) {
-        size_t i = slot(o.key);
-        while (slots_[i].val) i = (i + 1) & (cap_ - 1);
-        slots_[i] = o;
-      }
+  static Slot *alloc(size_t cap) {
+    const size_t bytes = cap * sizeof(Slot), huge = (size_t)2 << 20;
+    void *p = nullptr;
+    if (posix_memalign(&p, bytes >= huge ? huge : 64, bytes) != 0) throw std::bad_alloc();
+#ifdef MADV_HUGEPAGE
+    if (bytes >= huge) (void)madvise(p, bytes, MADV_HUGEPAGE);  // 100+ MB of random probes: 4-KB pages would miss the TLB every time
+#endif
+    std::memset(p, 0, bytes);
+    return (Slot *)p;
   }
-  std::vector<Slot> slots_;
+  void grow() {
+    Slot *old = s_;
+    const size_t old_cap = cap_;
+    cap_ = cap_ ? cap_ * 2 : (size_t)1 << 16;
+    s_ = alloc(cap_);
+    for (size_t j = 0; j < old_cap; j++)
+      if (old[j].epoch == epoch_) {
+        size_t i = home(old[j].key);
+        while (s_[i].epoch == epoch_) i = (i + 1) & (cap_ - 1);
+        s_[i] = old[j];
+      }
+    std::free(old);
+  }
+  Slot *s_ = nullptr;
   size_t cap_ = 0, n_ = 0;
+  uint32_t epoch_ = 1;
 };
 
-// Mutable binary max-heap on compare_pair (state_space.h:16-34): the top is the
-// smallest f, ties go to the smaller min(g, rhs).  Sift rules follow a 2-ary
-// boost::heap::d_ary_heap: sift-up stops at equality, sift-down swaps at
-// equality and prefers the first maximal child.
+struct Cold {            // per node, indexed by node index
+  double g = kInf;       // copy of the slot's g (heap tie-breaks of re-opened nodes, recoverTraj)
+  double h = kInf;       // State::h
+  uint64_t key = 0;
+  uint32_t parent = 0;   // the node whose expansion created this one (the start node: itself) ...
+  int32_t action = -1;   // ... through this control: coordinates = forward_state(parent, U[action])
+  int32_t coord = -1;    // index into Planner::coords once the state has been materialised
+  int32_t handle = -1;   // heap handle of the latest push (State::heapkey)
+  int32_t cache = -1;    // successor lists waiting for this node's expansion (Planner::caches)
+  uint32_t pick_stamp = 0;  // launch for which the node was last picked (a re-opened node sits in the heap twice)
+  bool opened = false, closed = false;
+};
+
+// Mutable binary max-heap on compare_pair (state_space.h:16-34): the top is the smallest f, ties go to the smaller
+// min(g, rhs).  Sift rules follow a 2-ary boost::heap::d_ary_heap (mutable): sift-up stops at equality, sift-down
+// swaps at equality and prefers the first maximal child.  Entries are addressed through handles like boost's: a node
+// that is pushed while an older entry of it is still in the heap (closed, improved twice before its second pop --
+// graph_search.h:117-136 pushes instead of updating because iterationclosed is still set) owns two entries, and
+// `increase` moves the one of the LATEST push.  The tie-break reads the node's g at comparison time in the reference
+// (compare_pair dereferences the state); an entry carries a copy that is exact as long as every node has one entry,
+// and from the first double entry on the live value is read instead (`live`).
 class OpenList {
  public:
-  struct Item { double f; NodePtr n; };
+  struct Item { double f, g; uint32_t idx; int32_t handle; };
   bool empty() const { return q_.empty(); }
   size_t size() const { return q_.size(); }
   const Item &top() const { return q_.front(); }
   const std::vector<Item> &items() const { return q_; }
-  void push(double f, const NodePtr &n) {
-    q_.push_back({f, n});
-    n->heap_pos = (int)q_.size() - 1;
+  void reset(const std::vector<Cold> *cold) { q_.clear(); pos_.clear(); cold_ = cold; live = false; }
+  bool live = false;
+  int32_t push(double f, double g, uint32_t idx) {
+    const int32_t h = (int32_t)pos_.size();
+    pos_.push_back((int32_t)q_.size());
+    q_.push_back({f, g, idx, h});
     up((int)q_.size() - 1);
+    return h;
   }
   void pop() {
-    q_.front().n->heap_pos = -1;
+    pos_[(size_t)q_.front().handle] = -1;
     if (q_.size() > 1) {
-      std::swap(q_.front(), q_.back());
+      q_.front() = q_.back();
       q_.pop_back();
-      q_.front().n->heap_pos = 0;
+      pos_[(size_t)q_.front().handle] = 0;
       down(0);
     } else {
       q_.pop_back();
     }
   }
   // key became better (smaller f): state_space `increase` (graph_search.h:133)
-  void increase(const NodePtr &n, double f) {
-    q_[(size_t)n->heap_pos].f = f;
-    up(n->heap_pos);
+  void increase(int32_t handle, double f, double g) {
+    const int i = pos_[(size_t)handle];
+    q_[(size_t)i].f = f;
+    q_[(size_t)i].g = g;
+    up(i);
+  }
+  int position(int32_t handle) const { return pos_[(size_t)handle]; }
+  double tie(const Item &a) const { return live ? (*cold_)[a.idx].g : a.g; }
+  bool less(const Item &a, const Item &b) const {
+    if (a.f == b.f) return tie(a) > tie(b);
+    return a.f > b.f;
   }
 
  private:
-  static bool less(const Item &a, const Item &b) {
-    if (a.f == b.f) return std::min(a.n->g, a.n->rhs) > std::min(b.n->g, b.n->rhs);
-    return a.f > b.f;
-  }
   void swap_at(int i, int j) {
     std::swap(q_[(size_t)i], q_[(size_t)j]);
-    q_[(size_t)i].n->heap_pos = i;
-    q_[(size_t)j].n->heap_pos = j;
+    pos_[(size_t)q_[(size_t)i].handle] = i;
+    pos_[(size_t)q_[(size_t)j].handle] = j;
   }
   void up(int i) {
     while (i > 0) {
@@ -300,6 +341,8 @@ class OpenList {
     }
   }
   std::vector<Item> q_;
+  std::vector<int32_t> pos_;  // handle -> position in q_ (-1 once popped)
+  const std::vector<Cold> *cold_ = nullptr;
 };
 
 // Primitive1D::J for an arbitrary effort order (primitive.h:92-122), used only
@@ -366,6 +409,19 @@ inline void forward_state(int dim, int control, const double *nd, const double *
   out[4 * dim + 1] = nd[4 * dim + 1] + T;  // env_map.h:161
 }
 
+// forward_state()'s position rows only (the default heuristic of a new node needs nothing else, env_base.h:58-64)
+inline void forward_pos(int dim, int control, const double *nd, const double *u, double T, double *out) {
+  const int K = (control & 8) ? 4 : (control & 4) ? 3 : (control & 2) ? 2 : 1;
+  const double t3 = (T * T) * T;
+  for (int i = 0; i < dim; i++) {
+    const double p = nd[i], v = nd[dim + i], a = nd[2 * dim + i], j = nd[3 * dim + i], ui = u[i];
+    if (K == 1) out[i] = (0.0 + ui * T) + p;
+    else if (K == 2) out[i] = ((0.0 + ((ui / 2) * T) * T) + v * T) + p;
+    else if (K == 3) out[i] = (((0.0 + (ui / 6) * t3) + ((a / 2) * T) * T) + v * T) + p;
+    else out[i] = ((((0.0 + (ui / 24) * (t3 * T)) + (j / 6) * t3) + ((a / 2) * T) * T) + v * T) + p;
+  }
+}
+
 struct PlanResult {
   bool ok = false;
   double cost = kInf;
@@ -375,6 +431,9 @@ struct PlanResult {
   int spec_hits = 0;        // expansions served from lists that rode along in an earlier launch (speculated children)
   int64_t pairs = 0;        // node x control pairs evaluated by the provider
   int64_t state_mismatches = 0;  // check_states: successors whose host-evaluated state differs from the device's
+  // where the wall time went (ms) and what the relaxation loop did
+  double t_total = 0, t_provider = 0, t_fill = 0, t_pick = 0, t_relax = 0, t_recover = 0;
+  int64_t relaxed = 0, improved = 0, pushes = 0, materialised = 0;
   double total_time = 0;
   double J[4] = {0, 0, 0, 0};  // J(VEL), J(ACC), J(JRK), J(SNP) of the trajectory
   std::vector<double> traj_nodes;  // [segments][4D+2] start state of each primitive
@@ -405,14 +464,50 @@ class Planner {
                                // counter must come out as exactly 1
   void *user = nullptr;
 
-  std::deque<Node> pool;
-  struct PredRec { uint64_t key; double cost; int32_t action; int32_t next; };
-  std::vector<PredRec> preds;
-  NodeMap hm;
+  struct PredRec { double cost; uint32_t parent; int32_t next; };  // pred_coord / pred_action_cost of state_space.h:49-53
+  NodeTable hm;
+  std::vector<Cold> cold;        // nodes in creation order
+  std::vector<PredRec> preds;    // every relaxed edge (graph_search.h:97-99), newest first per child
+  std::vector<int32_t> pred_act; // pred_action_id, parallel to preds
+  std::vector<double> coords;    // [materialised][4D+2]
   OpenList pq;
   PlanResult last;
 
   int F() const { return 4 * dim + 2; }
+
+  // order-independent digest of the closed set (sum of mixed lattice hashes): two searches that closed the same nodes agree
+  uint64_t closed_checksum() const {
+    uint64_t s = 0;
+    for (const Cold &nd : cold)
+      if (nd.closed) { uint64_t k = nd.key; k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; s += k; }
+    return s;
+  }
+  // PlannerBase::getCloseSet (positions, creation order): fills up to cap points, returns the closed-set size
+  int32_t closed_positions(double *pos, int32_t cap) {
+    int32_t m = 0;
+    for (uint32_t i = 0; i < (uint32_t)cold.size(); i++) {
+      if (!cold[i].closed) continue;
+      if (pos && m < cap) {
+        const double *c = coord_of(i);
+        for (int k = 0; k < dim; k++) pos[(size_t)m * dim + k] = c[k];
+      }
+      m++;
+    }
+    return m;
+  }
+  // PlannerBase::getOpenSet walks the heap (planner_base.h:77-81): full states, heap order
+  int32_t open_states(double *states, int32_t cap) {
+    const int f = F();
+    int32_t m = 0;
+    for (const OpenList::Item &it : pq.items()) {
+      if (states && m < cap) {
+        const double *c = coord_of(it.idx);
+        for (int k = 0; k < f; k++) states[(size_t)m * f + k] = c[k];
+      }
+      m++;
+    }
+    return m;
+  }
 
   double heur(const double *s, const double *goal) const {  // env_base.h:46-64
     return heur_keyed(s, lattice_hash(dim, control, s), goal, lattice_hash(dim, goal_control ? goal_control : control, goal));
@@ -438,167 +533,275 @@ class Planner {
     return goaled;
   }
 
+  // The node's state: the one its creating expansion produced (graph_search.h:83-85), rebuilt on first use.
+  const double *coord_of(uint32_t idx) {
+    Cold &nd = cold[idx];
+    if (nd.coord < 0) {
+      const int f = F();
+      const double *par = coord_of(nd.parent);  // (a creating parent was expanded, so it has its state: depth 1)
+      const size_t at = coords.size();
+      coords.resize(at + (size_t)f);
+      // (coord_of(parent) may have pointed into `coords` before the resize: take it again)
+      par = &coords[(size_t)cold[nd.parent].coord * (size_t)f];
+      forward_state(dim, control, par, &U[(size_t)cold[idx].action * udim], dt, &coords[at]);
+      cold[idx].coord = (int32_t)(at / (size_t)f);
+      last.materialised++;
+    }
+    return &coords[(size_t)cold[idx].coord * (size_t)F()];
+  }
+
   // PlannerBase::plan (A*), planner_base.h:275-325 + GraphSearch::Astar
   int plan(const double *start, const double *goal) {
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    const auto t_plan0 = clk::now();
     last = PlanResult();
     t_succ = t_provider = t_fill = t_pick = 0;
     checked_states = 0;
     hm.clear();
-    pool.clear();
+    cold.clear();
+    coords.clear();
+    preds.clear();
+    pred_act.clear();
+    caches.clear();
+    free_caches.clear();
     if (spec.cap) spec.clear();  // (the map may have changed since the last plan)
     spec_now = spec_cfg();
     spec_keys.clear();  // (states a plan with batch > 1 assembled must not ride along in this plan's launches)
     spec_states.clear();
-    preds.clear();
-    all_blobs.clear();
+    blob_bytes_check();
     free_blobs.clear();
+    for (auto &b : all_blobs) free_blobs.push_back(b.get());  // (buffers of the previous plan are recycled, not freed)
     cur_blob = nullptr;
     cur_group.clear();
     cur_view = PackedView();
-    pq = OpenList();
-    if (!single && !batched) return -1;
+    pq.reset(&cold);
+    if (!single && !batched && !lists && !packed) return -1;
     int pn[3];
     grid.to_cell(start, pn);
     if (!grid.is_free(pn)) return 0;  // "start is not free": plan() == false
     const int f = F();
     if (is_goal(start, goal)) { last.ok = true; last.cost = 0; return 0; }
 
-    pool.emplace_back();
-    NodePtr curr = &pool.back();
-    std::copy(start, start + f, curr->coord);
-    curr->key = lattice_hash(dim, control, start);
-    curr->g = 0;
-    curr->h = eps == 0 ? 0 : heur(start, goal);
-    curr->opened = true;
-    pq.push(curr->g + eps * curr->h, curr);
-    hm[curr->key] = curr;
+    const uint64_t goal_key = lattice_hash(dim, goal_control ? goal_control : control, goal);
+    {
+      bool fresh;
+      const uint64_t key = lattice_hash(dim, control, start);
+      hm.reserve(1);
+      Slot *sl = hm.insert(key, &fresh);
+      sl->g = 0;
+      sl->idx = 0;
+      cold.emplace_back();
+      Cold &nd = cold.back();
+      nd.key = key;
+      nd.g = 0;
+      nd.h = eps == 0 ? 0 : heur(start, goal);
+      nd.parent = 0;
+      nd.coord = 0;
+      coords.assign(start, start + f);
+      nd.opened = true;
+      nd.handle = pq.push(nd.g + eps * nd.h, nd.g, 0);
+    }
 
     v_succ.resize((size_t)nU * f);
     v_cost.resize((size_t)nU);
     v_act.resize((size_t)nU);
     v_keys.resize((size_t)nU);
-    const uint64_t goal_key = lattice_hash(dim, goal_control ? goal_control : control, goal);
+    r_fin.resize((size_t)nU);
+    r_new.resize((size_t)nU + 1);
+    r_imp.resize((size_t)nU + 1);
+    r_tent.resize((size_t)nU);
+    r_slot.resize((size_t)nU);
     int expand_iteration = 0;
     bool reached = false;
-    double sc[14];
+    uint32_t curr = 0;
+    double sc[14], hs[14];
     for (;;) {
       expand_iteration++;
-      curr = pq.top().n;
+      curr = pq.top().idx;
       pq.pop();
-      curr->closed = true;
-      const auto t_s0 = std::chrono::steady_clock::now();
+      cold[curr].closed = true;
+      const auto t_s0 = clk::now();
       SuccView sv;
       if (int rc = successors(curr, &sv)) return rc;
-      t_succ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_s0).count();
+      t_succ += ms_since(t_s0);
+      // ---- relaxation of the node's successors (graph_search.h:78-141), in four passes over the list.  Written as one
+      // loop, every edge costs three branches nobody can predict (blocked? new node? better path?) and each miss throws
+      // away the table probes in flight behind it; split up, the per-edge work is branch-free and the rare cases
+      // (one edge in five creates a node, one in four improves one) run in loops of their own.  Order is kept where the
+      // reference's results depend on it: nodes are numbered, predecessors recorded and heap operations issued in
+      // ascending successor index, exactly as the single loop did.
       const int n_succ = sv.m;
-      const bool have_keys = sv.keys != nullptr;
-      // The relaxation is bound by cache misses of the node map and of the nodes (1 M look-ups on the 3D
-      // problems): with the device's hashes at hand the slots are prefetched kAhead successors ahead and the
-      // nodes half that far.
-      constexpr int kAhead = 16;
-      if (have_keys)
-        for (int s = 0; s < n_succ && s < kAhead; s++) hm.prefetch(sv.keys[s]);
+      const double g_curr = cold[curr].g;
+      const double *c_curr = coord_of(curr);
+      // pass 0: the finite edges (graph_search.h:81 skips the blocked ones)
+      int nf = 0;
       for (int s = 0; s < n_succ; s++) {
-        if (have_keys) {
-          if (s + kAhead < n_succ) hm.prefetch(sv.keys[s + kAhead]);
-          if (s + kAhead / 2 < n_succ && !std::isinf(sv.cost[s + kAhead / 2])) {
-            const int q = s + kAhead / 2;
-            if (const Node *nx = hm.peek(sv.keys[q])) {
-              __builtin_prefetch(nx);
-            } else if (sv.state && sv.fs > 64) {
-              // a state not seen before: its fields will be gathered from rows far apart (lists read in place)
-              for (int r = 0; r < f; r++) __builtin_prefetch(&sv.state[(int64_t)r * sv.fs + (int64_t)q * sv.es]);
-            }
-          }
+        r_fin[(size_t)nf] = s;
+        nf += std::fabs(sv.cost[s]) != kInf;  // (!isinf)
+      }
+      const uint64_t *keys = sv.keys;
+      if (!keys) {  // a provider without lattice hashes: hash the states it delivered (or their host evaluation)
+        for (int j = 0; j < nf; j++) {
+          const int s = r_fin[(size_t)j];
+          if (sv.state) for (int r = 0; r < f; r++) sc[r] = sv.state[(int64_t)r * sv.fs + (int64_t)s * sv.es];
+          else forward_state(dim, control, c_curr, &U[(size_t)sv.act[s] * udim], dt, sc);  // (lists that rode along without hashes)
+          v_keys[(size_t)s] = lattice_hash(dim, control, sc);
         }
+        keys = v_keys.data();
+      }
+      // pass 1: find or claim the child's slot, record the edge, lower g -- no branch depends on the data
+      hm.reserve((size_t)nf);
+      if (cold.capacity() < cold.size() + (size_t)nf) cold.reserve(std::max(cold.capacity() * 2, cold.size() + (size_t)nf));
+      const size_t rec0 = preds.size();
+      if (rec0 + (size_t)nf > (size_t)0x7fffffff) return -2;  // (32-bit record indices)
+      preds.resize(rec0 + (size_t)nf);
+      pred_act.resize(rec0 + (size_t)nf);
+      PredRec *const P = preds.data() + rec0;
+      int32_t *const A = pred_act.data() + rec0;
+      const Cold *const cold0 = cold.data();
+      constexpr int kAhead = 12;
+      for (int j = 0; j < nf && j < kAhead; j++) hm.prefetch(keys[r_fin[(size_t)j]]);
+      int n_new = 0, n_imp = 0;
+      for (int j = 0; j < nf; j++) {
+        if (j + kAhead < nf) hm.prefetch(keys[r_fin[(size_t)(j + kAhead)]]);
+        const int s = r_fin[(size_t)j];
+        bool fresh;
+        Slot *sl = hm.insert(keys[s], &fresh);
+        r_slot[(size_t)j] = sl;
+        r_new[(size_t)n_new] = j;
+        n_new += fresh;
         const double c_s = sv.cost[s];
-        if (std::isinf(c_s)) continue;  // graph_search.h:81
-        uint64_t key;
+        P[j] = PredRec{c_s, curr, sl->pred_head};
+        A[j] = sv.act[s];
+        sl->pred_head = (int32_t)(rec0 + (size_t)j);
+        const double tentative = g_curr + c_s;
+        const bool better = tentative < sl->g;
+        r_tent[(size_t)j] = tentative;
+        r_imp[(size_t)n_imp] = j;
+        n_imp += better;
+        sl->g = better ? tentative : sl->g;
+        // the improved child's cold record is needed in pass 3 (a new child's is about to be written anyway)
+        __builtin_prefetch(better && !fresh ? (const void *)(cold0 + sl->idx) : (const void *)sl);
+      }
+      last.relaxed += nf;
+      last.improved += n_imp;
+      // pass 2: the new nodes, numbered in successor order
+      for (int q = 0; q < n_new; q++) {
+        const int j = r_new[(size_t)q], s = r_fin[(size_t)j];
+        Slot *sl = r_slot[(size_t)j];
+        const uint64_t key = keys[s];
+        sl->idx = (uint32_t)cold.size();
+        cold.emplace_back();
+        Cold &nd = cold.back();
+        nd.key = key;
+        nd.parent = curr;
+        nd.action = sv.act[s];
         bool have_sc = false;
-        auto gather = [&] {
-          if (!have_sc) {
-            if (sv.state) {
-              for (int r = 0; r < f; r++) sc[r] = sv.state[(int64_t)r * sv.fs + (int64_t)s * sv.es];
-              if (check_states) {  // test hook: the host evaluation against the device's states
-                double hs[14];
-                forward_state(dim, control, curr->coord, &U[(size_t)sv.act[s] * udim], dt, hs);
-                if (check_perturb >= 0 && checked_states++ == check_perturb) {
-                  uint64_t b;
-                  std::memcpy(&b, &hs[0], 8);
-                  b ^= 1ull;
-                  std::memcpy(&hs[0], &b, 8);
-                }
-                if (std::memcmp(hs, sc, sizeof(double) * (size_t)f) != 0) last.state_mismatches++;
-              }
-            } else {
-              forward_state(dim, control, curr->coord, &U[(size_t)sv.act[s] * udim], dt, sc);
-            }
-          }
+        if (sv.state) {
+          // the provider's own rows are the node's state (and, as a test hook, are compared with the host evaluation)
+          for (int r = 0; r < f; r++) sc[r] = sv.state[(int64_t)r * sv.fs + (int64_t)s * sv.es];
           have_sc = true;
-        };
-        if (have_keys) key = sv.keys[s];
-        else { gather(); key = lattice_hash(dim, control, sc); }
-        NodePtr &child = hm[key];
-        if (!child) {
-          gather();
-          pool.emplace_back();
-          child = &pool.back();
-          std::copy(sc, sc + f, child->coord);
-          child->key = key;
-          child->h = eps == 0 ? 0 : heur_keyed(sc, key, goal, goal_key);
-        }
-        {
-          const int32_t rec = (int32_t)preds.size();
-          preds.push_back({curr->key, c_s, sv.act[s], -1});
-          if (child->pred_tail >= 0) preds[(size_t)child->pred_tail].next = rec;
-          else child->pred_head = rec;
-          child->pred_tail = rec;
-        }
-        const double tentative = curr->g + c_s;
-        if (tentative < child->g) {
-          child->g = tentative;
-          const double fval = child->g + eps * child->h;
-          if (child->opened && !child->closed) {
-            pq.increase(child, fval);
-          } else {
-            pq.push(fval, child);
-            child->opened = true;
+          if (check_states) {
+            forward_state(dim, control, c_curr, &U[(size_t)sv.act[s] * udim], dt, hs);
+            if (check_perturb >= 0 && checked_states++ == check_perturb) {
+              uint64_t b;
+              std::memcpy(&b, &hs[0], 8);
+              b ^= 1ull;
+              std::memcpy(&hs[0], &b, 8);
+            }
+            if (std::memcmp(hs, sc, sizeof(double) * (size_t)f) != 0) last.state_mismatches++;
           }
+          nd.coord = (int32_t)(coords.size() / (size_t)f);
+          coords.insert(coords.end(), sc, sc + f);
+          c_curr = &coords[(size_t)cold[curr].coord * (size_t)f];  // (coords may have moved)
+        }
+        if (eps == 0 || key == goal_key) nd.h = 0;
+        else {
+          if (!have_sc) forward_pos(dim, control, c_curr, &U[(size_t)sv.act[s] * udim], dt, sc);
+          nd.h = heur_keyed(sc, key, goal, goal_key);
         }
       }
-      if (is_goal(curr->coord, goal)) { reached = true; break; }
+      // pass 3: the improved children into the open list (graph_search.h:108-141), in successor order
+      for (int q = 0; q < n_imp; q++) {
+        const int j = r_imp[(size_t)q];
+        const Slot *sl = r_slot[(size_t)j];
+        Cold &ch = cold[sl->idx];
+        const double tentative = r_tent[(size_t)j];
+        ch.g = tentative;
+        const double fval = tentative + eps * ch.h;
+        if (ch.opened && !ch.closed) {
+          pq.increase(ch.handle, fval, tentative);
+        } else {
+          // (a closed node whose older entry is still in the heap: two entries of one node from here on)
+          if (ch.handle >= 0 && pq.position(ch.handle) >= 0) pq.live = true;
+          ch.handle = pq.push(fval, tentative, sl->idx);
+          ch.opened = true;
+          last.pushes++;
+        }
+      }
+      if (is_goal(coord_of(curr), goal)) { reached = true; break; }
       if (max_expand > 0 && expand_iteration >= max_expand) break;
       if (pq.empty()) break;
     }
-    if (getenv("MPLX_PLAN_TIMING"))
-      fprintf(stderr, "[host_planner] successors() %.1f ms (provider %.1f ms, cache fill %.1f ms, candidate pick %.1f ms)\n",
-              t_succ, t_provider, t_fill, t_pick);
     last.expansions = expand_iteration;
     last.nodes = (int)hm.size();
-    for (const Node &nd : pool)
+    for (const Cold &nd : cold)
       if (nd.closed) last.closed++;
     // PlannerBase::getOpenSet walks the heap (planner_base.h:77-81): a closed node that was pushed again counts
     last.opened = (int)pq.size();
-    if (!reached) return 0;
-    if (recover(curr, start)) { last.ok = true; last.cost = curr->g; }
+    const auto t_r0 = clk::now();
+    if (reached && recover(curr, start)) { last.ok = true; last.cost = cold[curr].g; }
+    last.t_recover = ms_since(t_r0);
+    last.t_total = ms_since(t_plan0);
+    last.t_provider = t_provider;
+    last.t_fill = t_fill;
+    last.t_pick = t_pick;
+    last.t_relax = last.t_total - t_succ - last.t_recover;
+    if (getenv("MPLX_PLAN_TIMING"))
+      fprintf(stderr, "[host_planner] %.1f ms: successors() %.1f (provider %.1f, cache fill %.1f, candidate pick %.1f), relaxation + heap %.1f, "
+              "recover %.2f; %lld edges relaxed, %lld improved, %lld pushes, %zu nodes, %lld states materialised\n",
+              last.t_total, t_succ, t_provider, t_fill, t_pick, last.t_relax, last.t_recover, (long long)last.relaxed,
+              (long long)last.improved, (long long)last.pushes, cold.size(), (long long)last.materialised);
     return 0;
   }
 
  private:
   double t_succ = 0, t_provider = 0, t_fill = 0, t_pick = 0;  // MPLX_PLAN_TIMING diagnostics
   int64_t checked_states = 0;
-  std::vector<int32_t> b_cnt, b_act;  // staging of one batched launch (lists provider)
-  std::vector<double> b_cost, b_state;
-  std::vector<uint64_t> b_hash;
-  std::vector<double> v_succ, v_cost;  // the current expansion's successors (providers that fill caller arrays)
+  std::vector<int32_t> r_fin, r_new, r_imp;  // scratch of the relaxation passes (one successor list)
+  std::vector<double> r_tent;
+  std::vector<Slot *> r_slot;
+
+  // ---- successor lists between the launch that produced them and the pop that consumes them.  The provider's landing
+  // buffer of the latest launch stays valid until the next one: nodes expanded before that (9 in 10) are read in
+  // place; the others are moved to buffers of their own just before the next launch (Planner::keep).
+  struct CacheRec {
+    int32_t slot = -1;       // index in the landing buffer of launch `batch` ...
+    uint32_t batch = 0;
+    char *blob = nullptr;    // ... or a recycled buffer [cost m][hash m]?[state (4D+2) x m]?[action m]
+    int32_t m = 0;
+    bool has_state = false, has_keys = false;
+  };
+  std::vector<CacheRec> caches;
+  std::vector<int32_t> free_caches;
+  int32_t take_cache() {
+    if (!free_caches.empty()) { const int32_t c = free_caches.back(); free_caches.pop_back(); caches[(size_t)c] = CacheRec(); return c; }
+    caches.emplace_back();
+    return (int32_t)caches.size() - 1;
+  }
+  std::vector<int32_t> own_cnt, own_act;  // landing buffer of the providers that fill caller arrays
+  std::vector<int64_t> own_offs;
+  std::vector<double> own_cost, own_state;
+  std::vector<uint64_t> own_hash;
+  std::vector<uint8_t> own_status;
+  std::vector<double> v_succ, v_cost;  // the current expansion's successors (single provider, speculation store)
   std::vector<int32_t> v_act;
   std::vector<uint64_t> v_keys;
   char *cur_blob = nullptr;            // ... or the packed lists of the node being expanded
-  // The provider's landing buffer of the latest launch stays valid until the next one: nodes expanded before
-  // that (9 in 10) are read in place; the others are moved to buffers of their own just before the next launch.
   PackedView cur_view;
   uint32_t cur_batch = 0, pick_counter = 0;
-  std::vector<NodePtr> cur_group;
+  std::vector<uint32_t> cur_group;
   std::vector<int> aux_buf;  // storage of the candidate walk's position heap, recycled between launches
 
   // ---- speculation on states that are not nodes yet.  The open list can only offer nodes that exist; in a goal-directed
@@ -659,48 +862,56 @@ class Planner {
     if (const char *e = getenv("MPLX_PLAN_SPEC")) return atoi(e);
     return nU <= 32 ? 4 : 0;  // (a child per control per parent: small control tables only)
   }
-  void keep(Node &nd) {  // lists of `nd` out of the landing buffer into a recycled buffer
-    const int f = F();
-    const size_t m = (size_t)cur_view.count[nd.c_slot], o = (size_t)cur_view.offs[nd.c_slot];
-    nd.c_m = (int32_t)m;
-    if (!nd.c_blob) nd.c_blob = take_blob();
-    char *b = nd.c_blob;
-    std::memcpy(b, cur_view.cost + o, m * 8);
-    std::memcpy(b + m * 8, cur_view.hash + o, m * 8);
-    if (cur_view.state)
-      for (int r = 0; r < f; r++) std::memcpy(b + m * 8 * (size_t)(2 + r), cur_view.state + (size_t)r * cur_view.total + o, m * 8);
-    std::memcpy(b + m * 8 * (size_t)(2 + f), cur_view.action + o, m * 4);
-    nd.c_has_state = cur_view.state != nullptr;
-    nd.c_slot = -1;
-  }
-  // Buffers of the packed lists: fixed capacity (a full list), recycled when their node has been expanded, so
-  // that steady state touches no fresh pages (a fresh 40-KB allocation per node cost more than the copy itself).
+  // Buffers of the kept lists: fixed capacity (a full list), recycled when their node has been expanded and from plan
+  // to plan, so that steady state touches no fresh pages (a fresh 40-KB allocation per node cost more than the copy).
   std::vector<std::unique_ptr<char[]>> all_blobs;
   std::vector<char *> free_blobs;
+  size_t blob_bytes = 0;
+  void blob_bytes_check() {  // a control table or state size that changed since the buffers were made: start over
+    const size_t need = (size_t)nU * (size_t)(8 + 8 + 8 * F() + 4);
+    if (need != blob_bytes) { all_blobs.clear(); free_blobs.clear(); blob_bytes = need; }
+  }
   char *take_blob() {
     if (!free_blobs.empty()) { char *b = free_blobs.back(); free_blobs.pop_back(); return b; }
-    all_blobs.emplace_back(new char[(size_t)nU * (size_t)(8 + 8 + 8 * F() + 4)]);
+    all_blobs.emplace_back(new char[blob_bytes]);
     return all_blobs.back().get();
   }
-  // One get_succ, possibly served from / filling the batch cache.
-  int successors(const NodePtr &curr, SuccView *v) {
+  void keep(CacheRec &c) {  // lists out of the landing buffer into a recycled buffer
     const int f = F();
-    if (batch <= 1 || (!batched && !lists && !packed)) {
+    const size_t m = (size_t)cur_view.count[c.slot], o = (size_t)cur_view.offs[c.slot];
+    c.m = (int32_t)m;
+    if (!c.blob) c.blob = take_blob();
+    char *b = c.blob;
+    std::memcpy(b, cur_view.cost + o, m * 8);
+    b += m * 8;
+    c.has_keys = cur_view.hash != nullptr;
+    if (c.has_keys) { std::memcpy(b, cur_view.hash + o, m * 8); b += m * 8; }
+    c.has_state = cur_view.state != nullptr;
+    if (c.has_state)
+      for (int r = 0; r < f; r++, b += m * 8) std::memcpy(b, cur_view.state + (size_t)r * cur_view.total + o, m * 8);
+    std::memcpy(b, cur_view.action + o, m * 4);
+    c.slot = -1;
+  }
+
+  // One get_succ, possibly served from / filling the batch cache.
+  int successors(uint32_t curr, SuccView *v) {
+    const int f = F();
+    if (single && (batch <= 1 || (!batched && !lists && !packed))) {  // the reference's loop: one node, one call
       last.device_launches++;
       last.pairs += nU;
       int32_t m = 0;
-      if (single) {
-        if (int rc = single(user, curr->coord, v_succ.data(), v_cost.data(), v_act.data(), &m)) return rc;
-        *v = SuccView{m, v_cost.data(), nullptr, v_act.data(), v_succ.data(), 1, f};
-        return 0;
-      }
+      if (int rc = single(user, coord_of(curr), v_succ.data(), v_cost.data(), v_act.data(), &m)) return rc;
+      *v = SuccView{m, v_cost.data(), nullptr, v_act.data(), v_succ.data(), 1, f};
+      return 0;
+    }
+    if (batch <= 1 || (!batched && !lists && !packed)) {
       if (int rc = run_batch({curr})) return rc;
       return fetch(curr, v);
     }
     const int n_spec_parents = spec_now;
-    if (!curr->cached && n_spec_parents > 0 && spec.cap) {
-      const int e = spec.find(curr->key);
-      if (e >= 0 && std::memcmp(&spec.coord[(size_t)e * f], curr->coord, sizeof(double) * (size_t)f) == 0) {
+    if (cold[curr].cache < 0 && n_spec_parents > 0 && spec.cap) {
+      const int e = spec.find(cold[curr].key);
+      if (e >= 0 && std::memcmp(&spec.coord[(size_t)e * f], coord_of(curr), sizeof(double) * (size_t)f) == 0) {
         const int32_t m = spec.m[(size_t)e];
         std::copy(&spec.cost[(size_t)e * nU], &spec.cost[(size_t)e * nU] + m, v_cost.begin());
         std::copy(&spec.act[(size_t)e * nU], &spec.act[(size_t)e * nU] + m, v_act.begin());
@@ -710,19 +921,19 @@ class Planner {
         return 0;
       }
     }
-    if (!curr->cached) {
+    if (cold[curr].cache < 0) {
       const auto t_p0 = std::chrono::steady_clock::now();
       // the popped node plus the best open nodes that have no list yet: best-first walk of the heap
       // array (k smallest of a binary heap with an auxiliary heap of positions), O(k log k) whatever
       // the size of the open list
-      std::vector<NodePtr> group{curr};
-      curr->pick_stamp = ++pick_counter;
+      std::vector<uint32_t> group{curr};
+      cold[curr].pick_stamp = ++pick_counter;
       const size_t want = (size_t)batch - 1;
       const std::vector<OpenList::Item> &h = pq.items();
       auto worse = [&](int a, int b) {  // max-heap on "better", so top() is the best position
         const OpenList::Item &x = h[(size_t)a], &y = h[(size_t)b];
         if (x.f != y.f) return x.f > y.f;
-        return std::min(x.n->g, x.n->rhs) > std::min(y.n->g, y.n->rhs);
+        return pq.tie(x) > pq.tie(y);
       };
       // (the walk stops after ~2 x batch heap positions: what lies deeper is not popped soon enough to be worth a
       // slot, and on a small problem most of the top of the heap already holds its lists -- walking 16 x batch
@@ -737,10 +948,10 @@ class Planner {
         const int i = aux.back();
         aux.pop_back();
         visited++;
-        Node *cand = h[(size_t)i].n;
-        if (!cand->cached && cand->pick_stamp != pick_counter) {
-          cand->pick_stamp = pick_counter;
-          group.push_back(cand);
+        Cold &cand = cold[h[(size_t)i].idx];
+        if (cand.cache < 0 && cand.pick_stamp != pick_counter) {
+          cand.pick_stamp = pick_counter;
+          group.push_back(h[(size_t)i].idx);
         }
         if (2 * i + 1 < (int)h.size()) push(2 * i + 1);
         if (2 * i + 2 < (int)h.size()) push(2 * i + 2);
@@ -750,17 +961,19 @@ class Planner {
       spec_keys.clear();
       if (n_spec_parents > 0) {
         if (spec.cap == 0 || spec.nU != nU || spec.F != f) spec.reset(nU, f, 2048);
-        double cs[14];
+        double cs[14], par[14];
         // children of `par`: into the launch -- as nodes when they exist and wait for lists, as bare states otherwise
-        auto children = [&](const double *par) {
+        auto children = [&](uint32_t pidx) {
+          std::memcpy(par, coord_of(pidx), sizeof(double) * (size_t)f);  // (coord_of of a child may move `coords`)
           for (int i = 0; i < nU; i++) {
             forward_state(dim, control, par, &U[(size_t)i * udim], dt, cs);
             const uint64_t key = lattice_hash(dim, control, cs);
-            if (Node *ex = hm.peek(key)) {
+            if (const Slot *sl = hm.find(key)) {
               // a node already: closed or served -> nothing to do; open without lists -> an ordinary member of the launch
-              if (!ex->closed && !ex->cached && ex->pick_stamp != pick_counter && group.size() < (size_t)batch + 64) {
-                ex->pick_stamp = pick_counter;
-                group.push_back(ex);
+              Cold &ex = cold[sl->idx];
+              if (!ex.closed && ex.cache < 0 && ex.pick_stamp != pick_counter && group.size() < (size_t)batch + 64) {
+                ex.pick_stamp = pick_counter;
+                group.push_back(sl->idx);
               }
               continue;
             }
@@ -774,7 +987,7 @@ class Planner {
         };
         // (the group grows while its first members' children are looked at: only members picked from the heap count)
         const size_t n_par = std::min(group.size(), (size_t)n_spec_parents);
-        for (size_t gi = 0; gi < n_par; gi++) children(group[gi]->coord);
+        for (size_t gi = 0; gi < n_par; gi++) children(group[gi]);
       }
       t_pick += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p0).count();
       if (int rc = run_batch(group)) return rc;
@@ -782,7 +995,9 @@ class Planner {
     return fetch(curr, v);
   }
 
-  int run_batch(const std::vector<NodePtr> &group) {
+  int run_batch(const std::vector<uint32_t> &group) {
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const int f = F();
     // (speculated states only ever ride along into a store of their own shape: a control table or state size that
     // changed since they were assembled would index the store's arrays with the wrong strides)
@@ -791,111 +1006,91 @@ class Planner {
     const int64_t n = ng + ns;  // the launch: the nodes of the group, then the speculated states
     std::vector<double> &nodes = nodes_buf;
     nodes.resize((size_t)f * n);
-    for (int64_t k = 0; k < ng; k++)
-      for (int r = 0; r < f; r++) nodes[(size_t)r * n + k] = group[(size_t)k]->coord[(size_t)r];
+    for (int64_t k = 0; k < ng; k++) {
+      const double *c = coord_of(group[(size_t)k]);
+      for (int r = 0; r < f; r++) nodes[(size_t)r * n + k] = c[r];
+    }
     for (int64_t k = 0; k < ns; k++)
       for (int r = 0; r < f; r++) nodes[(size_t)r * n + ng + k] = spec_states[(size_t)k * f + r];
     const int64_t slots = n * nU;
+    last.device_launches++;
+    last.pairs += slots;
+    const auto t_f0 = clk::now();
+    for (uint32_t p : cur_group) {  // what the previous launch delivered and the search has not consumed yet
+      const int32_t ci = cold[p].cache;  // (a re-opened node is closed AND waiting)
+      if (ci >= 0 && caches[(size_t)ci].slot >= 0 && caches[(size_t)ci].batch == cur_batch) keep(caches[(size_t)ci]);
+    }
+    const auto t_l0 = clk::now();
+    t_fill += ms(t_f0, t_l0);
+    cur_group.clear();
+    cur_batch++;
+    if (packed) {
+      if (int rc = packed(user, nodes.data(), n, &cur_view)) return rc;
+      t_provider += ms(t_l0, clk::now());
+    } else if (lists) {
+      // compact per-node lists with the device's lattice hashes, in caller arrays: node k owns [k nU, k nU + count[k])
+      own_cnt.resize((size_t)n);
+      own_act.resize((size_t)slots);
+      own_cost.resize((size_t)slots);
+      own_hash.resize((size_t)slots);
+      own_state.resize((size_t)f * slots);
+      own_offs.resize((size_t)n + 1);
+      if (int rc = lists(user, nodes.data(), n, own_cnt.data(), own_act.data(), own_cost.data(), own_hash.data(), own_state.data()))
+        return rc;
+      t_provider += ms(t_l0, clk::now());
+      for (int64_t k = 0; k <= n; k++) own_offs[(size_t)k] = k * nU;
+      cur_view = PackedView{slots, own_cnt.data(), own_offs.data(), own_cost.data(), own_hash.data(), own_act.data(), own_state.data()};
+    } else {
+      // dense slots: the emitted ones (finite or blocked), in control order, moved to the front of each node's range
+      own_status.resize((size_t)slots);
+      own_cnt.resize((size_t)n);
+      own_act.resize((size_t)slots);
+      own_cost.resize((size_t)slots);
+      own_state.resize((size_t)f * slots);
+      own_offs.resize((size_t)n + 1);
+      if (int rc = batched(user, nodes.data(), n, own_status.data(), own_cost.data(), own_state.data())) return rc;
+      const auto t_b1 = clk::now();
+      t_provider += ms(t_l0, t_b1);
+      for (int64_t k = 0; k < n; k++) {
+        int32_t m = 0;
+        const int64_t o = k * nU;
+        for (int i = 0; i < nU; i++) {
+          const uint8_t st = own_status[(size_t)(o + i)];
+          if (st != 1 && st != 2) continue;
+          if (m != i) {
+            own_cost[(size_t)(o + m)] = own_cost[(size_t)(o + i)];
+            for (int r = 0; r < f; r++) own_state[(size_t)r * slots + o + m] = own_state[(size_t)r * slots + o + i];
+          }
+          own_act[(size_t)(o + m)] = i;
+          m++;
+        }
+        own_cnt[(size_t)k] = m;
+        own_offs[(size_t)k] = o;
+      }
+      own_offs[(size_t)n] = slots;
+      cur_view = PackedView{slots, own_cnt.data(), own_offs.data(), own_cost.data(), nullptr, own_act.data(), own_state.data()};
+      t_fill += ms(t_b1, clk::now());
+    }
+    for (int64_t k = 0; k < ng; k++) {
+      Cold &nd = cold[group[(size_t)k]];
+      if (nd.cache < 0) nd.cache = take_cache();
+      CacheRec &c = caches[(size_t)nd.cache];
+      c.slot = (int32_t)k;
+      c.batch = cur_batch;
+    }
     // lists of the speculated states into the store (entry e <- column ng + k of the launch)
-    auto harvest = [&](int64_t k, int32_t m, const double *cost, const uint64_t *keys, const int32_t *act) {
+    if (ns) spec.has_keys = cur_view.hash != nullptr;
+    for (int64_t k = 0; k < ns; k++) {
+      const size_t o = (size_t)cur_view.offs[ng + k];
+      const int32_t m = cur_view.count[ng + k];
       const int e = spec.insert(spec_keys[(size_t)k]);
       std::copy(&spec_states[(size_t)k * f], &spec_states[(size_t)k * f] + f, &spec.coord[(size_t)e * f]);
       spec.m[(size_t)e] = m;
-      std::copy(cost, cost + m, &spec.cost[(size_t)e * nU]);
-      std::copy(act, act + m, &spec.act[(size_t)e * nU]);
-      if (keys) std::copy(keys, keys + m, &spec.keys[(size_t)e * nU]);
-    };
-    last.device_launches++;
-    last.pairs += slots;
-    if (packed) {
-      const auto t_f0 = std::chrono::steady_clock::now();
-      for (NodePtr p : cur_group)  // what the previous launch delivered and the search has not consumed yet
-        if (p->cached && p->c_slot >= 0 && p->c_batch == cur_batch) keep(*p);  // (a re-opened node is closed AND waiting)
-      const auto t_l0 = std::chrono::steady_clock::now();
-      t_fill += std::chrono::duration<double, std::milli>(t_l0 - t_f0).count();
-      cur_group.clear();
-      cur_batch++;
-      if (int rc = packed(user, nodes.data(), n, &cur_view)) return rc;
-      t_provider += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_l0).count();
-      for (int64_t k = 0; k < ng; k++) {
-        Node &nd = *group[(size_t)k];
-        nd.c_slot = (int32_t)k;
-        nd.c_batch = cur_batch;
-        nd.cached = true;
-      }
-      if (ns) spec.has_keys = true;
-      for (int64_t k = 0; k < ns; k++) {
-        const size_t o = (size_t)cur_view.offs[ng + k];
-        harvest(k, cur_view.count[ng + k], cur_view.cost + o, cur_view.hash + o, cur_view.action + o);
-      }
-      cur_group.assign(group.begin(), group.end());
-      return 0;
+      std::copy(cur_view.cost + o, cur_view.cost + o + m, &spec.cost[(size_t)e * nU]);
+      std::copy(cur_view.action + o, cur_view.action + o + m, &spec.act[(size_t)e * nU]);
+      if (cur_view.hash) std::copy(cur_view.hash + o, cur_view.hash + o + m, &spec.keys[(size_t)e * nU]);
     }
-    if (lists) {
-      // compact per-node lists with the device's lattice hashes: no scan of skipped slots, no host hashing
-      b_cnt.resize((size_t)n);
-      b_act.resize((size_t)slots);
-      b_cost.resize((size_t)slots);
-      b_hash.resize((size_t)slots);
-      b_state.resize((size_t)f * slots);
-      const auto t_l0 = std::chrono::steady_clock::now();
-      if (int rc = lists(user, nodes.data(), n, b_cnt.data(), b_act.data(), b_cost.data(), b_hash.data(), b_state.data()))
-        return rc;
-      const auto t_l1 = std::chrono::steady_clock::now();
-      t_provider += std::chrono::duration<double, std::milli>(t_l1 - t_l0).count();
-      if (ns) spec.has_keys = true;
-      for (int64_t k = 0; k < ns; k++) {
-        const int64_t o = (ng + k) * nU;
-        harvest(k, b_cnt[(size_t)(ng + k)], b_cost.data() + o, b_hash.data() + o, b_act.data() + o);
-      }
-      for (int64_t k = 0; k < ng; k++) {
-        Node &nd = *group[(size_t)k];
-        const int32_t m = b_cnt[(size_t)k];
-        const int64_t o = k * nU;
-        nd.c_succ.resize((size_t)m * f);
-        for (int r = 0; r < f; r++) {
-          const double *row = b_state.data() + (size_t)r * slots + o;
-          for (int32_t j = 0; j < m; j++) nd.c_succ[(size_t)j * f + r] = row[j];
-        }
-        nd.c_cost.assign(b_cost.begin() + o, b_cost.begin() + o + m);
-        nd.c_act.assign(b_act.begin() + o, b_act.begin() + o + m);
-        nd.c_key.assign(b_hash.begin() + o, b_hash.begin() + o + m);
-        nd.cached = true;
-      }
-      t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_l1).count();
-      return 0;
-    }
-    std::vector<uint8_t> st((size_t)slots);
-    std::vector<double> cs((size_t)slots), state((size_t)f * slots);
-    const auto t_b0 = std::chrono::steady_clock::now();
-    if (int rc = batched(user, nodes.data(), n, st.data(), cs.data(), state.data())) return rc;
-    const auto t_b1 = std::chrono::steady_clock::now();
-    t_provider += std::chrono::duration<double, std::milli>(t_b1 - t_b0).count();
-    if (ns) spec.has_keys = false;
-    for (int64_t k = 0; k < ns; k++) {  // dense slots: the emitted ones, in control order
-      int32_t m = 0;
-      for (int i = 0; i < nU; i++) {
-        const int64_t sl = (ng + k) * nU + i;
-        if (st[(size_t)sl] != 1 && st[(size_t)sl] != 2) continue;
-        v_cost[(size_t)m] = cs[(size_t)sl];
-        v_act[(size_t)m] = i;
-        m++;
-      }
-      harvest(k, m, v_cost.data(), nullptr, v_act.data());
-    }
-    for (int64_t k = 0; k < ng; k++) {
-      Node &nd = *group[(size_t)k];
-      nd.c_succ.clear(); nd.c_cost.clear(); nd.c_act.clear();
-      for (int i = 0; i < nU; i++) {
-        const int64_t s = k * nU + i;
-        if (st[(size_t)s] != 1 && st[(size_t)s] != 2) continue;  // emitted: finite or blocked
-        for (int r = 0; r < f; r++) nd.c_succ.push_back(state[(size_t)r * slots + s]);
-        nd.c_cost.push_back(cs[(size_t)s]);
-        nd.c_act.push_back(i);
-      }
-      nd.cached = true;
-    }
-    t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b1).count();
+    cur_group.assign(group.begin(), group.end());
     return 0;
   }
 
@@ -903,68 +1098,71 @@ class Planner {
   // when a cheaper path re-opens it after it was closed (graph_search.h:108-141 pushes it a second time; that
   // happens with an inconsistent heuristic, i.e. eps > 1 or the default v_max <= 0), so the cache entry must not
   // outlive its one use -- a re-popped node goes through run_batch again (get_succ is pure: same lists).
-  int fetch(const NodePtr &n, SuccView *v) {
-    if (!n->cached) return -1;
+  int fetch(uint32_t n, SuccView *v) {
+    Cold &nd = cold[n];
+    if (nd.cache < 0) return -1;
     const int f = F();
-    n->cached = false;
-    if (packed && n->c_slot >= 0 && n->c_batch == cur_batch) {
+    const int32_t ci = nd.cache;
+    CacheRec &c = caches[(size_t)ci];
+    nd.cache = -1;
+    if (cur_blob) { free_blobs.push_back(cur_blob); cur_blob = nullptr; }  // the previous expansion's lists are done with
+    if (c.slot >= 0 && c.batch == cur_batch) {
       // still in the landing buffer of the latest launch: read in place
-      const size_t o = (size_t)cur_view.offs[n->c_slot];
-      *v = SuccView{cur_view.count[n->c_slot], cur_view.cost + o, cur_view.hash + o, cur_view.action + o,
+      const size_t o = (size_t)cur_view.offs[c.slot];
+      *v = SuccView{cur_view.count[c.slot], cur_view.cost + o, cur_view.hash ? cur_view.hash + o : nullptr, cur_view.action + o,
                     cur_view.state ? cur_view.state + o : nullptr, cur_view.total, 1};
-      n->c_slot = -1;
-      return 0;
-    }
-    if (packed) {
-      if (cur_blob) free_blobs.push_back(cur_blob);  // the previous expansion's lists are done with
-      cur_blob = n->c_blob;  // the planner takes the node's lists over for the duration of this expansion
-      n->c_blob = nullptr;
-      n->c_slot = -1;
-      const size_t m = (size_t)n->c_m;
-      n->c_m = 0;
+      if (c.blob) free_blobs.push_back(c.blob);
+    } else {
+      cur_blob = c.blob;  // the planner takes the node's lists over for the duration of this expansion
+      const size_t m = (size_t)c.m;
       const char *b = cur_blob;
-      *v = SuccView{(int32_t)m, (const double *)b, (const uint64_t *)(b + m * 8), (const int32_t *)(b + m * 8 * (size_t)(2 + f)),
-                    n->c_has_state ? (const double *)(b + m * 16) : nullptr, (int64_t)m, 1};
-      return 0;
+      const double *cost = (const double *)b;
+      b += m * 8;
+      const uint64_t *keys = nullptr;
+      if (c.has_keys) { keys = (const uint64_t *)b; b += m * 8; }
+      const double *state = nullptr;
+      if (c.has_state) { state = (const double *)b; b += m * 8 * (size_t)f; }
+      *v = SuccView{(int32_t)m, cost, keys, (const int32_t *)b, state, (int64_t)m, 1};
     }
-    std::copy(n->c_succ.begin(), n->c_succ.end(), v_succ.begin());
-    std::copy(n->c_cost.begin(), n->c_cost.end(), v_cost.begin());
-    std::copy(n->c_act.begin(), n->c_act.end(), v_act.begin());
-    const bool have_keys = n->c_key.size() == n->c_act.size() && !n->c_act.empty();
-    if (have_keys) std::copy(n->c_key.begin(), n->c_key.end(), v_keys.begin());
-    *v = SuccView{(int32_t)n->c_act.size(), v_cost.data(), have_keys ? v_keys.data() : nullptr, v_act.data(), v_succ.data(), 1, f};
-    n->c_key.clear(); n->c_key.shrink_to_fit();
-    n->c_succ.clear(); n->c_succ.shrink_to_fit();
-    n->c_cost.clear(); n->c_act.clear();
+    c = CacheRec();
+    free_caches.push_back(ci);
     return 0;
   }
 
   // GraphSearch::recoverTraj, graph_search.h:369-455
-  bool recover(NodePtr curr, const double *start) {
+  bool recover(uint32_t curr, const double *start) {
     const int f = F();
     const uint64_t start_key = lattice_hash(dim, control, start);
-    last.traj_end.assign(curr->coord, curr->coord + f);
-    std::vector<std::vector<double>> from;
-    std::vector<int32_t> acts;
+    {
+      const double *c = coord_of(curr);
+      last.traj_end.assign(c, c + f);
+    }
+    std::vector<uint32_t> from;
+    std::vector<int32_t> acts, recs;
     bool found = false;
-    while (curr->pred_head >= 0) {
+    for (;;) {
+      const Slot *sl = hm.find(cold[curr].key);
+      if (!sl || sl->pred_head < 0) break;
+      recs.clear();
+      for (int32_t i = sl->pred_head; i >= 0; i = preds[(size_t)i].next) recs.push_back(i);
+      std::reverse(recs.begin(), recs.end());  // insertion order, as the reference's pred_coord vector holds them
       int min_id = -1;
       double min_rhs = kInf, min_g = kInf;
-      for (int32_t i = curr->pred_head; i >= 0; i = preds[(size_t)i].next) {
+      for (int32_t i : recs) {
         const PredRec &pr = preds[(size_t)i];
-        const NodePtr &p = hm[pr.key];
-        const double v = p->g + pr.cost;
-        if (min_rhs > v) { min_rhs = v; min_g = p->g; min_id = (int)i; }
+        const double pg = cold[pr.parent].g;
+        const double v = pg + pr.cost;
+        if (min_rhs > v) { min_rhs = v; min_g = pg; min_id = (int)i; }
         else if (!std::isinf(pr.cost) && min_rhs == v) {
-          if (min_g < p->g) { min_g = p->g; min_id = (int)i; }
+          if (min_g < pg) { min_g = pg; min_id = (int)i; }
         }
       }
       if (min_id < 0) break;
-      const int a = preds[(size_t)min_id].action;
-      curr = hm[preds[(size_t)min_id].key];
-      from.push_back(std::vector<double>(curr->coord, curr->coord + f));
+      const int a = pred_act[(size_t)min_id];
+      curr = preds[(size_t)min_id].parent;
+      from.push_back(curr);
       acts.push_back(a);
-      if (curr->key == start_key) { found = true; break; }
+      if (cold[curr].key == start_key) { found = true; break; }
     }
     if (!found) return false;
     std::reverse(from.begin(), from.end());
@@ -972,7 +1170,7 @@ class Planner {
     // Trajectory(prs): total time and efforts (trajectory.h:52-57, 250-254)
     const int K = (control & 8) ? 4 : (control & 4) ? 3 : (control & 2) ? 2 : 1;
     for (size_t s = 0; s < from.size(); s++) {
-      const double *nd = from[s].data();
+      const double *nd = coord_of(from[s]);
       const double *u = &U[(size_t)acts[s] * udim];
       last.total_time += dt;
       for (int order = 1; order <= 4; order++) {

@@ -152,7 +152,7 @@ int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, 
   if (!p || !start || !goal || !out) return MPLX_ERR_ARG;
   if (p->pl.grid.cells.empty()) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: map not set");
   if (p->pl.nU <= 0) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: controls not set");
-  if (!p->pl.single && !p->pl.batched) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: no successor provider attached");
+  if (!p->pl.single && !p->pl.batched && !p->pl.packed) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: no successor provider attached");
   int rc;
   try {
     rc = p->pl.plan(start, goal);
@@ -217,27 +217,13 @@ int mplx_selftest_forward_state(int32_t dim, int32_t control, const double *node
 
 int mplx_planner_closed_set(mplx_planner *p, double *pos, int32_t cap, int32_t *n) {
   if (!p || !n) return MPLX_ERR_ARG;
-  int32_t m = 0;
-  for (const mplx::host::Node &nd : p->pl.pool) {
-    if (!nd.closed) continue;
-    if (pos && m < cap)
-      for (int i = 0; i < p->pl.dim; i++) pos[(size_t)m * p->pl.dim + i] = nd.coord[(size_t)i];
-    m++;
-  }
-  *n = m;
+  *n = p->pl.closed_positions(pos, cap);
   return MPLX_OK;
 }
 
 int mplx_planner_open_set(mplx_planner *p, double *states, int32_t cap, int32_t *n) {
   if (!p || !n) return MPLX_ERR_ARG;
-  const int f = p->pl.F();
-  int32_t m = 0;
-  for (const mplx::host::OpenList::Item &it : p->pl.pq.items()) {  // the heap, as planner_base.h:77-81 walks it
-    if (states && m < cap)
-      for (int i = 0; i < f; i++) states[(size_t)m * f + i] = it.n->coord[(size_t)i];
-    m++;
-  }
-  *n = m;
+  *n = p->pl.open_states(states, cap);  // the heap, as planner_base.h:77-81 walks it
   return MPLX_OK;
 }
 

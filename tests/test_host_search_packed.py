@@ -1,0 +1,40 @@
+"""CPU: the engine's host search on its product wiring -- the "packed" provider (lists read in place from a landing
+buffer, edges only: action + cost + lattice hash, states of picked nodes rebuilt with forward_state) -- with the CPU
+oracle standing in for the device (tests/tools/host_plan_harness.cpp), against the reference's own MapPlanner<3>::plan
+(oracle/_ref) on a 3D voxel problem: same cost, expansions, closed and open set sizes, trajectory length, and the same
+search whatever the launch size.  The GPU tests run the same comparison with the device as the provider
+(tests/test_gpu_plan.py); this one covers the relaxation passes, the node table's growth, lazily materialised states
+and the list cache where there is no GPU."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+from oracle import oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def prof():
+    import host_plan_profile as P
+    P.build()
+    return P
+
+
+@pytest.mark.parametrize("edge,nu", [(48, 5), (64, 7)])
+def test_packed_search_equals_the_reference_planner(prof, edge, nu):
+    env, start, goal = prof.problem_3d(edge, nu=nu)
+    runs = {b: prof.run(env, start, goal, batch=b, reps=2, threads=4) for b in (1, 16, 64)}
+    r0 = runs[1][0]
+    assert r0["ok"] and r0["launches"] == r0["expansions"]
+    for b, rs in runs.items():
+        for r in rs:  # (the second plan of a planner re-uses table, pools and buffers of the first)
+            for k in ("ok", "cost", "expansions", "closed", "opened", "nodes", "segments", "closed_checksum", "traj_checksum", "J"):
+                assert r[k] == r0[k], (b, k, r[k], r0[k])
+    assert runs[64][0]["launches"] < r0["launches"] / 8
+    if not os.path.exists(O.REF_PLANNER_SO):
+        pytest.skip("oracle/_ref/libmpl_ref_planner.so not built")
+    ref = O.ref_plan(env, start, goal, use_gpu=False)
+    assert ref["ok"] and ref["cost"] == r0["cost"] and ref["expansions"] == r0["expansions"]
+    assert ref["closed"] == r0["closed"] and ref["opened"] == r0["opened"] and ref["segments"] == r0["segments"]
+    assert ref["J"] == r0["J"] and ref["total_time"] == r0["total_time"]
