@@ -270,14 +270,22 @@ def engine_plan(m, dim, origin, md, cells, res, U, start, goal, v_max, a_max, ba
     pl.setU(U)
     pl.setBatch(batch)
     pl.plan(start, goal)  # warm-up
-    best = 1e30
+    best, split = 1e30, None
     for _ in range(reps):
         t0 = time.perf_counter()
         ok = pl.plan(start, goal)
-        best = min(best, (time.perf_counter() - t0) * 1e3)
+        ms = (time.perf_counter() - t0) * 1e3
+        if ms < best:
+            best, split = ms, pl.timing()  # where that plan's time went (mplx_planner_timing, host_planner.hpp)
     s = pl.summary()
     pl.close()
-    return {"wall_ms": best, "ok": bool(ok), "cost": s["cost"], "expansions": s["expansions"], "launches": s["device_launches"]}
+    sp = {k: round(split[k], 3) for k in ("provider_ms", "fill_ms", "pick_ms", "relax_ms", "recover_ms")}
+    sp.update({k: int(split[k]) for k in ("relaxed", "improved", "pushes", "materialised")})
+    sp["what"] = ("provider = launches + completion + transfers (the device's share); relax = relaxation passes, node table, "
+                  "heap and goal tests on one host thread; fill = lists moved out of the landing buffer; pick = choice of the "
+                  "next launch's nodes")
+    return {"wall_ms": best, "ok": bool(ok), "cost": s["cost"], "expansions": s["expansions"], "closed": s["closed"],
+            "nodes": s["nodes"], "launches": s["device_launches"], "timing_split": sp}
 
 
 def extra_plan(m):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MPLX_ABI_VERSION 7
+#define MPLX_ABI_VERSION 8
 
 typedef struct mplx_ctx mplx_ctx;
 
@@ -450,6 +450,21 @@ int mplx_planner_closed_set(mplx_planner *p, double *pos, int32_t cap, int32_t *
  * cap rows of 4D+2 doubles; *n receives the open-set size.                    */
 int mplx_planner_open_set(mplx_planner *p, double *states, int32_t cap, int32_t *n);
 const char *mplx_planner_last_error(const mplx_planner *p);
+/* ABI v8.  Where the wall time of the last mplx_planner_plan went and what its relaxation loop did (the search is
+ * host code around the device's get_succ: graph_search.h:63-143 spends its time per relaxed edge).               */
+typedef struct {
+  double total_ms;      /* the whole plan() call                                                                  */
+  double provider_ms;   /* inside the successor provider: launches, completion, transfers                         */
+  double fill_ms;       /* moving lists that outlive their launch out of the landing buffer                       */
+  double pick_ms;       /* choosing the nodes of the next launch (best open nodes, children that ride along)      */
+  double relax_ms;      /* everything else of the search loop: relaxation passes, node table, heap, goal tests    */
+  double recover_ms;    /* recoverTraj                                                                            */
+  int64_t relaxed;      /* finite edges relaxed (graph_search.h:97-99 records each as a predecessor)              */
+  int64_t improved;     /* ... of which lowered the child's g (graph_search.h:108)                                */
+  int64_t pushes;       /* heap pushes (the rest of `improved` were updates in place)                             */
+  int64_t materialised; /* nodes whose 4D+2 state was ever built on the host (picked for a launch or on the path) */
+} mplx_plan_timing;
+int mplx_planner_timing(const mplx_planner *p, mplx_plan_timing *out);
 
 /* ---- diagnostics -------------------------------------------------------- */
 /* The host search's evaluation of a successor state (Primitive<Dim>(node, u, dt).evaluate(dt),

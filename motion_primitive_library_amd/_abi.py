@@ -27,7 +27,7 @@ SYMBOLS = [
     "mplx_synchronize", "mplx_timer_begin", "mplx_timer_end",
     "mplx_planner_create", "mplx_planner_destroy", "mplx_planner_attach_ctx", "mplx_planner_set_provider",
     "mplx_planner_set_map", "mplx_planner_set_controls", "mplx_planner_configure", "mplx_planner_plan",
-    "mplx_planner_trajectory", "mplx_planner_trajectory_end", "mplx_planner_closed_set", "mplx_planner_open_set", "mplx_planner_last_error",
+    "mplx_planner_trajectory", "mplx_planner_trajectory_end", "mplx_planner_closed_set", "mplx_planner_open_set", "mplx_planner_last_error", "mplx_planner_timing",
     "mplx_selftest_math", "mplx_selftest_forward_state", "mplx_set_lists_route", "mplx_last_lists_route", "mplx_last_grid_kernel", "mplx_last_identity_form", "mplx_debug_store_model", "mplx_yaw_pin_stats", "mplx_service", "mplx_device_info",
 ]
 
@@ -108,6 +108,11 @@ class PlanSummary(C.Structure):
     ]
 
 
+class PlanTiming(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("total_ms", "provider_ms", "fill_ms", "pick_ms", "relax_ms", "recover_ms")] + \
+               [(k, C.c_int64) for k in ("relaxed", "improved", "pushes", "materialised")]
+
+
 class MplxError(RuntimeError):
     def __init__(self, code, text):
         super().__init__("mplx error %d: %s" % (code, text))
@@ -180,6 +185,7 @@ def lib():
         "mplx_planner_closed_set": (C.c_int, [vp, vp, i32, C.POINTER(i32)]),
         "mplx_planner_open_set": (C.c_int, [vp, vp, i32, C.POINTER(i32)]),
         "mplx_planner_last_error": (C.c_char_p, [vp]),
+        "mplx_planner_timing": (C.c_int, [vp, C.POINTER(PlanTiming)]),
         "mplx_selftest_math": (C.c_int, [vp, C.c_int, vp, vp, vp, i64]),
         "mplx_selftest_forward_state": (C.c_int, [i32, i32, vp, vp, C.c_double, vp]),
         "mplx_set_lists_route": (C.c_int, [vp, C.c_int]),

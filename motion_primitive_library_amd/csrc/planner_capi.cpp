@@ -187,6 +187,22 @@ int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, 
   return MPLX_OK;
 }
 
+int mplx_planner_timing(const mplx_planner *p, mplx_plan_timing *out) {
+  if (!p || !out) return MPLX_ERR_ARG;
+  const mplx::host::PlanResult &r = p->pl.last;
+  out->total_ms = r.t_total;
+  out->provider_ms = r.t_provider;
+  out->fill_ms = r.t_fill;
+  out->pick_ms = r.t_pick;
+  out->relax_ms = r.t_relax;
+  out->recover_ms = r.t_recover;
+  out->relaxed = r.relaxed;
+  out->improved = r.improved;
+  out->pushes = r.pushes;
+  out->materialised = r.materialised;
+  return MPLX_OK;
+}
+
 int mplx_planner_trajectory(mplx_planner *p, double *nodes, int32_t *actions, int32_t cap) {
   if (!p || !nodes || !actions) return MPLX_ERR_ARG;
   const mplx::host::PlanResult &r = p->pl.last;

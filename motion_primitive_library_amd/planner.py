@@ -203,6 +203,12 @@ class MapPlanner:
                                            "pairs", "cost", "total_time", "segments")} | {
             "J": list(o.J), "state_mismatches": o.state_mismatches}
 
+    def timing(self):
+        """Where the wall time of the last plan() went (ms) and what its relaxation loop did (mplx_plan_timing)."""
+        t = _abi.PlanTiming()
+        self._check(self._L.mplx_planner_timing(self._p, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _abi.PlanTiming._fields_}
+
     def getCloseSet(self):
         n = C.c_int32()
         self._check(self._L.mplx_planner_closed_set(self._p, None, 0, C.byref(n)))

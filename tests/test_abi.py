@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(engine):
     for s in _declared_symbols():
         assert hasattr(lib, s), "libmplx.so does not export %s" % s
     assert sorted(engine._abi.SYMBOLS) == sorted(set(_declared_symbols()) - {"mplx_status"})
-    assert engine._abi.lib().mplx_abi_version() == 7
+    assert engine._abi.lib().mplx_abi_version() == 8
 
 
 def test_struct_layouts_match_the_header(engine):
