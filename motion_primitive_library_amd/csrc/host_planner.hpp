@@ -35,6 +35,9 @@
 #include <vector>
 
 #include <sys/mman.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace mplx {
 namespace host {
@@ -454,7 +457,7 @@ struct PlanResult {
   int64_t state_mismatches = 0;  // check_states: successors whose host-evaluated state differs from the device's
   // where the wall time went (ms) and what the relaxation loop did
   double t_total = 0, t_provider = 0, t_fill = 0, t_pick = 0, t_relax = 0, t_recover = 0;
-  int64_t relaxed = 0, improved = 0, pushes = 0, materialised = 0, predicted = 0;
+  int64_t relaxed = 0, improved = 0, pushes = 0, materialised = 0;
   double total_time = 0;
   double J[4] = {0, 0, 0, 0};  // J(VEL), J(ACC), J(JRK), J(SNP) of the trajectory
   std::vector<double> traj_nodes;  // [segments][4D+2] start state of each primitive
@@ -596,6 +599,7 @@ class Planner {
     cur_blob = nullptr;
     cur_group.clear();
     cur_view = PackedView();
+    cur_view_n = 0;
     pq.reset(&cold);
     if (!single && !batched && !lists && !packed) return -1;
     int pn[3];
@@ -628,9 +632,7 @@ class Planner {
     v_cost.resize((size_t)nU);
     v_act.resize((size_t)nU);
     v_keys.resize((size_t)nU);
-    r_fin.resize((size_t)nU);
-    prep_fin.resize((size_t)nU);
-    prep_node = kNone;
+    r_fin.resize((size_t)nU + 8);  // (+8: the compress-store of pass 0 may touch a full vector past the end)
     r_new.resize((size_t)nU + 1);
     r_imp.resize((size_t)nU + 1);
     r_tent.resize((size_t)nU);
@@ -660,30 +662,8 @@ class Planner {
       const double g_curr = cold[curr].g;
       const double *c_curr = coord_of(curr);
       const uint64_t tp0 = pass_timing ? __builtin_ia32_rdtsc() : 0;
-      // pass 0: the finite edges (graph_search.h:81 skips the blocked ones), their slots on the way to the cache --
-      // unless this node was the predicted next one during the previous expansion: then both happened a whole
-      // expansion ago (see below) and the slots are in the cache by now
-      int nf;
-      if (prep_node == curr) {
-        r_fin.swap(prep_fin);
-        nf = prep_nf;
-        last.predicted++;
-      } else {
-        nf = finite_pass(sv, r_fin.data());
-      }
-      prep_node = kNone;
-      // The node the search will most probably pop next is the top of the heap right now (it is, 9 998 times in
-      // 10 000 on the 3D problems: children rarely undercut the best open node).  If its lists are at hand, its pass 0
-      // runs here, before this node's edges are relaxed: the table lines of its children travel from DRAM while
-      // this expansion computes, instead of stalling the next one twelve edges at a time.
-      if (!pq.empty() && sv.keys) {
-        const uint32_t nxt = pq.top().idx;
-        SuccView nv;
-        if (peek(nxt, &nv) && nv.keys) {
-          prep_nf = finite_pass(nv, prep_fin.data());
-          prep_node = nxt;
-        }
-      }
+      // pass 0: the finite edges (graph_search.h:81 skips the blocked ones)
+      const int nf = finite_pass(sv.cost, n_succ, r_fin.data());
       const uint64_t *keys = sv.keys;
       if (!keys) {  // a provider without lattice hashes: hash the states it delivered (or their host evaluation)
         for (int j = 0; j < nf; j++) {
@@ -705,14 +685,22 @@ class Planner {
       PredRec *const P = preds.data() + rec0;
       int32_t *const A = pred_act.data() + rec0;
       const Cold *const cold0 = cold.data();
+      // 1a: the probes.  The only data-dependent branches of the relaxation are the ends of the probe sequences; a
+      // mispredicted one discards nothing but other probes.
+      constexpr int kAhead = 24;
+      for (int j = 0; j < nf && j < kAhead; j++) hm.prefetch(keys[r_fin[(size_t)j]]);
       int n_new = 0, n_imp = 0;
       for (int j = 0; j < nf; j++) {
-        const int s = r_fin[(size_t)j];
+        if (j + kAhead < nf) hm.prefetch(keys[r_fin[(size_t)(j + kAhead)]]);
         bool fresh;
-        Slot *sl = hm.insert(keys[s], &fresh);
-        r_slot[(size_t)j] = sl;
+        r_slot[(size_t)j] = hm.insert(keys[r_fin[(size_t)j]], &fresh);
         r_new[(size_t)n_new] = j;
         n_new += fresh;
+      }
+      // 1b: the edge into the child's predecessor list, the child's g lowered -- straight-line code
+      for (int j = 0; j < nf; j++) {
+        const int s = r_fin[(size_t)j];
+        Slot *sl = r_slot[(size_t)j];
         const double c_s = sv.cost[s];
         P[j] = PredRec{c_s, curr, sl->pred_head};
         A[j] = sv.act[s];
@@ -724,7 +712,7 @@ class Planner {
         n_imp += better;
         sl->g = better ? tentative : sl->g;
         // the improved child's cold record is needed in pass 3 (a new child's is about to be written anyway)
-        __builtin_prefetch(better && !fresh ? (const void *)(cold0 + sl->idx) : (const void *)sl);
+        __builtin_prefetch(better && sl->idx != NodeTable::kNoIndex ? (const void *)(cold0 + sl->idx) : (const void *)sl);
       }
       last.relaxed += nf;
       last.improved += n_imp;
@@ -822,33 +810,47 @@ class Planner {
  private:
   double t_succ = 0, t_provider = 0, t_fill = 0, t_pick = 0;  // MPLX_PLAN_TIMING diagnostics
   int64_t checked_states = 0;
-  static constexpr uint32_t kNone = 0xffffffffu;
   std::vector<int32_t> r_fin, r_new, r_imp;  // scratch of the relaxation passes (one successor list)
-  std::vector<int32_t> prep_fin;             // pass 0 of the predicted next node ...
-  int prep_nf = 0;
-  uint32_t prep_node = kNone;                // ... which is this one, if any
-  // pass 0 of the relaxation: indices of the finite entries of a list; the table slots of their children are
-  // requested from memory on the way (a list is 200 - 300 lines: they all fit the L1 / L2)
-  int finite_pass(const SuccView &sv, int32_t *fin) const {
+  std::vector<double> r_tent;
+  std::vector<Slot *> r_slot;
+  // pass 0 of the relaxation: the indices of the finite entries of a cost list, in order.  One entry in three is
+  // blocked, at random: a compare-and-compress per 8 entries where the host has AVX-512 (every EPYC an MI355X sits
+  // in), a branch-free scalar loop elsewhere.
+  static int finite_scalar(const double *cost, int m, int32_t *fin) {
     int nf = 0;
-    const int m = sv.m;
-    if (sv.keys) {
-      for (int s = 0; s < m; s++) {
-        fin[nf] = s;
-        const bool finite = std::fabs(sv.cost[s]) != kInf;  // (!isinf)
-        nf += finite;
-        if (finite) hm.prefetch(sv.keys[s]);
-      }
-    } else {
-      for (int s = 0; s < m; s++) {
-        fin[nf] = s;
-        nf += std::fabs(sv.cost[s]) != kInf;
-      }
+    for (int s = 0; s < m; s++) {
+      fin[nf] = s;
+      nf += std::fabs(cost[s]) != kInf;  // (!isinf)
     }
     return nf;
   }
-  std::vector<double> r_tent;
-  std::vector<Slot *> r_slot;
+#if defined(__x86_64__)
+  __attribute__((target("avx512f,avx512vl"))) static int finite_avx512(const double *cost, int m, int32_t *fin) {
+    const __m512d inf = _mm512_set1_pd(kInf);
+    __m256i idx = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+    const __m256i eight = _mm256_set1_epi32(8);
+    int nf = 0, s = 0;
+    for (; s + 8 <= m; s += 8) {
+      const __m512d c = _mm512_abs_pd(_mm512_loadu_pd(cost + s));
+      const __mmask8 k = _mm512_cmp_pd_mask(c, inf, _CMP_NEQ_UQ);
+      _mm256_mask_compressstoreu_epi32(fin + nf, k, idx);
+      nf += __builtin_popcount((unsigned)k);
+      idx = _mm256_add_epi32(idx, eight);
+    }
+    for (; s < m; s++) {
+      fin[nf] = s;
+      nf += std::fabs(cost[s]) != kInf;
+    }
+    return nf;
+  }
+#endif
+  int finite_pass(const double *cost, int m, int32_t *fin) const {
+#if defined(__x86_64__)
+    static const bool wide = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && !getenv("MPLX_PLAN_NO_AVX512");
+    if (wide) return finite_avx512(cost, m, fin);
+#endif
+    return finite_scalar(cost, m, fin);
+  }
 
   // ---- successor lists between the launch that produced them and the pop that consumes them.  The provider's landing
   // buffer of the latest launch stays valid until the next one: nodes expanded before that (9 in 10) are read in
@@ -877,6 +879,7 @@ class Planner {
   std::vector<uint64_t> v_keys;
   char *cur_blob = nullptr;            // ... or the packed lists of the node being expanded
   PackedView cur_view;
+  int64_t cur_view_n = 0;  // nodes (slots) of the landing buffer
   uint32_t cur_batch = 0, pick_counter = 0;
   std::vector<uint32_t> cur_group;
   std::vector<int> aux_buf;  // storage of the candidate walk's position heap, recycled between launches
@@ -1148,6 +1151,7 @@ class Planner {
       cur_view = PackedView{slots, own_cnt.data(), own_offs.data(), own_cost.data(), nullptr, own_act.data(), own_state.data()};
       t_fill += ms(t_b1, clk::now());
     }
+    cur_view_n = n;
     for (int64_t k = 0; k < ng; k++) {
       Cold &nd = cold[group[(size_t)k]];
       if (nd.cache < 0) nd.cache = take_cache();
@@ -1185,6 +1189,11 @@ class Planner {
     view_of(c, v);
     if (c.slot >= 0 && c.batch == cur_batch) {
       if (c.blob) free_blobs.push_back(c.blob);
+      // The lists of a launch lie in memory the device wrote: the first read of every line is a DRAM miss, and three
+      // short streams per node (cost, hash, action: a page or two each) are over before the hardware prefetcher has
+      // locked on.  The launch's nodes were picked best first, so they are popped roughly in slot order: ask for the
+      // lists two slots further on now.
+      for (int d = 1; d <= 2; d++) prefetch_lists(c.slot + d);
     } else {
       cur_blob = c.blob;  // the planner takes the node's lists over for the duration of this expansion
     }
@@ -1192,12 +1201,14 @@ class Planner {
     free_caches.push_back(ci);
     return 0;
   }
-  // The lists waiting for node `n`, if any, without consuming them (the same entries fetch() will hand out).
-  bool peek(uint32_t n, SuccView *v) const {
-    const int32_t ci = cold[n].cache;
-    if (ci < 0) return false;
-    view_of(caches[(size_t)ci], v);
-    return true;
+  void prefetch_lists(int64_t slot) const {
+    if (slot >= cur_view_n) return;
+    const size_t o = (size_t)cur_view.offs[slot];
+    const size_t m = (size_t)cur_view.count[slot];
+    const char *c = (const char *)(cur_view.cost + o), *h = (const char *)(cur_view.hash + o), *a = (const char *)(cur_view.action + o);
+    for (size_t b = 0; b < m * 8; b += 64) __builtin_prefetch(c + b);
+    if (cur_view.hash) for (size_t b = 0; b < m * 8; b += 64) __builtin_prefetch(h + b);
+    for (size_t b = 0; b < m * 4; b += 64) __builtin_prefetch(a + b);
   }
   void view_of(const CacheRec &c, SuccView *v) const {
     const int f = F();
