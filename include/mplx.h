@@ -225,7 +225,9 @@ typedef struct {
  * batches of >= 256 k list slots (ABI v7): their node identity claims runs in
  * buckets of fixed capacity, and the call waits for the stream ONCE, after
  * queueing everything, to learn that no bucket overflowed (then it returns), or
- * else runs the capacity-free form behind it (mplx_last_identity_form).        */
+ * else runs the capacity-free form behind it (mplx_last_identity_form) -- and
+ * then takes that form directly, asynchronously, for the context's next 8 calls
+ * with canon (ABI v8: a frontier that overflows does so call after call).      */
 int mplx_post_lists_device(mplx_ctx *ctx, const mplx_succ_lists *d_lists, int64_t n_nodes,
                            const mplx_goal_spec *goal, const mplx_post *d_out);
 
@@ -262,7 +264,10 @@ int mplx_pack_lists_device(mplx_ctx *ctx, const mplx_succ_lists *d_lists, int64_
  * indices): the consumer of the all-gather -- every rank runs it on the gathered set and so learns, without the
  * host, which successors of the whole frontier are first occurrences of their lattice state (the search's node
  * identity, waypoint.h:128-135), their heuristic (env_base.h:46-64) and goal flags (env_map.h:25-37): the on-device
- * open-list merge north_star names as the reason to gather at all.  d_packed needs offs, hash and state.         */
+ * open-list merge north_star names as the reason to gather at all.  d_packed needs offs, hash and state.
+ * Like mplx_post_lists_device it waits for the context's stream ONCE when canon is asked for on >= 256 k entries
+ * (the claimed identity pass learns that no bucket overflowed); after an overflow the next 8 calls of the context
+ * with canon take the capacity-free form directly and stay asynchronous (ABI v8).                                */
 int mplx_post_packed_device(mplx_ctx *ctx, const mplx_packed_lists *d_packed, int64_t n_nodes,
                             const mplx_goal_spec *goal, const mplx_post *d_out);
 

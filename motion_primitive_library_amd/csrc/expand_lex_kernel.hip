@@ -31,9 +31,9 @@
 // compares every pair of C2, C3 and C4 with the reference build through this kernel (route "grid", kernel "lex"),
 // tests/test_gpu_lex.py the two kernels with each other on odd worlds.
 //
-// Scope: Dim 2/3, VEL / ACC / JRK, lexicographic control table with <= 16 values per axis and <= 1024 controls,
-// v_max > 0 (or VEL), n_max <= 61, occupancy map (with or without a search region).  Everything else is
-// expand_grid_kernel.hip's.
+// Scope: Dim 2/3, VEL / ACC / JRK, lexicographic control table with <= 32 values per axis (instantiations with tables
+// of 8 / 16 / 32 entries per axis) and <= 8192 controls, v_max > 0 (or VEL), n_max <= 61, occupancy map (with or
+// without a search region).  Everything else is expand_grid_kernel.hip's.
 #include "mplx_internal.h"
 #include "mplx_device_common.h"
 

@@ -534,7 +534,13 @@ __global__ __launch_bounds__(kBT) void id_part2_kernel(const IdentityArgs A) {
   __shared__ uint32_t hist[256], lbase[256], gbase[256], wtot[4];
   __shared__ uint64_t st_h[kTile];
   __shared__ uint32_t st_g[kTile];
-  if (A.ovf[0]) return;  // (uniform)
+  // The overflow flag may be RAISED by other workgroups of this very launch while this one starts, and every wave does
+  // its own load: the decision is taken once per workgroup (thread 0 reads, all branch on the LDS copy), otherwise
+  // the waves that stayed would scatter through hist / lbase / gbase entries the leavers never wrote.
+  __shared__ uint32_t quit;
+  if (threadIdx.x == 0) quit = A.ovf[0];
+  __syncthreads();
+  if (quit) return;
   const int64_t cap2 = (int64_t)A.ovf[1];  // (id_seg_kernel)
   const uint32_t n_tiles = A.tile_seg[0], tile = xcd_tile(n_tiles);
   if (tile >= n_tiles || (blockIdx.x >> 3) >= ((n_tiles + 7u) >> 3)) return;

@@ -559,7 +559,10 @@ GridPlan plan_grid(const mplx_ctx *c) {
                  : mplx::grid_lds_bytes(c->dim, order, c->nU, ndp, n_max, rm, boxcap, ym, ndy, ulex);
   };
   while (rmax > 1 && lds_of(rmax) > 80 * 1024) rmax--;
-  const int wpb = mplx::grid_waves_per_block();
+  // (both factorised kernels run 4 waves = 4 nodes in flight per workgroup; plan_grid, grid_work and the prescreen
+  // threshold size launches with the one figure)
+  const int wpb = g.lex ? mplx::lex_waves_per_block() : mplx::grid_waves_per_block();
+  if (mplx::lex_waves_per_block() != mplx::grid_waves_per_block()) return GridPlan();
   // The launch is persistent: every workgroup must be RESIDENT (a workgroup that waits for a slot starts its first,
   // statically assigned node only after another one has drained the whole queue).  What fits is the runtime's answer
   // for this instantiation (registers, LDS granules), not LDS bytes alone.
@@ -569,7 +572,8 @@ GridPlan plan_grid(const mplx_ctx *c) {
     if (lds > 160 * 1024) return 0;
     int nb = -1;
     // (the cache key tells the two kernels apart through its control word: bit 8 = the lexicographic kernel)
-    const int key = p.control | (g.lex ? 0x100 : 0);
+    // ... and the lexicographic kernel's instantiations (table sizes 8 / 16 / 32 by the values per axis) through bits 12+
+    const int key = p.control | (g.lex ? 0x100 | (ndp << 12) : 0);
     for (const auto &e : c->grid_occ)
       if (e.control == key && e.pot == c->has_pot && e.lds == lds) nb = e.nb;
     if (nb < 0) {

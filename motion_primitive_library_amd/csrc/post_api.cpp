@@ -75,7 +75,13 @@ static int post_lists_impl(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t 
     const size_t total = levels * (sz_h + sz_g) + sz_c1 + sz_c2 + sz_t1 + sz_t2 + sz_r + 1024;
     // ... and of the claimed form (two levels): buckets of fixed capacity, cursors, the tile table of level 2
     const char *e_cl = getenv("MPLX_POST_CLAIMED"), *e_cap = getenv("MPLX_POST_CAP");
-    const bool claimed = levels == 2 && !(e_cl && atoi(e_cl) == 0);
+    // (sticky fall-back: a frontier that overflowed a bucket -- heavy duplication of few lattice states -- does so call
+    // after call; the next calls of this context take the capacity-free form straight away instead of paying claimed +
+    // synchronisation + exact each time, and the claimed form gets another try after kIdentityBackoff calls)
+    constexpr int kIdentityBackoff = 8;
+    const bool backoff = c->id_backoff > 0 && !(e_cl && atoi(e_cl) == 1);
+    if (backoff) c->id_backoff--;
+    const bool claimed = levels == 2 && !(e_cl && atoi(e_cl) == 0) && !backoff;
     int64_t subcap1 = 0, cap2 = 0, pairs1 = 0, pairs2 = 0, tiles2_max = 0, cur_words = 0;
     size_t total_cl = 0, cl_h0 = 0, cl_h1 = 0, cl_g0 = 0, cl_g1 = 0, cl_cur = 0, cl_ts = 0;
     if (claimed) {
@@ -124,6 +130,7 @@ static int post_lists_impl(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t 
       *c->id_ovf_host = 0;
       exact = true;
       c->last_identity_form = 3;
+      c->id_backoff = kIdentityBackoff;
     }
     if (exact) {
       char *w = (char *)c->post_ws.p;

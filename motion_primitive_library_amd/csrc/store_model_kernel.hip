@@ -28,8 +28,13 @@ __global__ __launch_bounds__(256) void store_model_kernel(const int32_t *count, 
   const int kChunk = (mode & 255) ? (mode & 255) : 4;
   for (int64_t c0 = wave * kChunk; c0 < n_nodes; c0 += W * kChunk)
     for (int64_t node = c0; node < c0 + kChunk && node < n_nodes; node++) {
-      const int E = count[node];
-      const int e16 = pad ? (E + 15) & ~15 : E, e32 = pad ? (E + 31) & ~31 : E;
+      // (count[] comes from device memory the caller filled: a stale or garbage value must not write past the node's
+      // segment of S entries, nor may the line-completing round-up when S is not a multiple of 32)
+      int E = count[node];
+      E = E < 0 ? 0 : (E > S ? (int)S : E);
+      int e16 = pad ? (E + 15) & ~15 : E, e32 = pad ? (E + 31) & ~31 : E;
+      e16 = e16 > S ? (int)S : e16;
+      e32 = e32 > S ? (int)S : e32;
       const int64_t base = node * S;
       if (mode & 256) {
         if (action) for (int e = lane; e < e32; e += 64) sm_st((int32_t)e, &action[base + e]);

@@ -56,10 +56,18 @@ def full_size_workload(engine, name):
     return wl
 
 
-@pytest.mark.parametrize("name,route", [("C2", "grid"), ("C3", "grid"), ("C4", "grid"), ("C5", "grid"), ("C5-tunnel", "grid"),
-                                        ("C4", "tile"), ("C3", "dense")])
-def test_full_size_every_pair_against_the_reference(engine, oracle_lib, name, route):
+# which kernel serves route "grid": the lexicographic one for C2 / C3 / C4 (asserted, not assumed), the general factorised
+# one for C5 -- and the general one again on C2 / C3 / C4 with the lexicographic kernel switched off (MPLX_GRID_LEX=0): it
+# is still the product path of shuffled tables, SNP and > 32 values per axis
+@pytest.mark.parametrize("name,route,kernel", [("C2", "grid", "lex"), ("C3", "grid", "lex"), ("C4", "grid", "lex"),
+                                               ("C5", "grid", "grid"), ("C5-tunnel", "grid", "grid"),
+                                               ("C2", "grid", "general"), ("C3", "grid", "general"), ("C4", "grid", "general"),
+                                               ("C4", "tile", "none"), ("C3", "dense", "none")])
+def test_full_size_every_pair_against_the_reference(engine, oracle_lib, monkeypatch, name, route, kernel):
     use_ref = require_reference_build()
+    if kernel == "general":
+        monkeypatch.setenv("MPLX_GRID_LEX", "0")
+        kernel = "grid"
     wl = full_size_workload(engine, name)
     nU, N = wl.U.shape[0], wl.n_nodes
     threads = os.cpu_count() or 1
@@ -72,7 +80,7 @@ def test_full_size_every_pair_against_the_reference(engine, oracle_lib, name, ro
     lists = env.alloc_lists(N, want_state=True, want_iters=True)
     env.expand_lists_resident(fr, lists)
     env.synchronize()
-    assert env.last_lists_route() == route
+    assert env.last_lists_route() == route and env.last_grid_kernel() == kernel
     chunk = max(1, min(N, (6 << 20) // nU))  # ~6 M pairs (0.8 GB of reference output) at a time
     n_emit = n_fin = n_dyn = 0
     for lo in range(0, N, chunk):
@@ -169,7 +177,7 @@ def test_c4_wavefront_frontier_costs_at_most_1_3x_the_random_one(engine, oracle_
     """Round-3 review: the frontier a search really produces (open list of an eps = 0 search, graph_search.h:63-75) must
     not be a slow path of the kernel.  Both frontiers through the SAME allocation of the lists in one context, after a
     clock spin-up, alternating: the wavefront launch may cost at most 1.3 x the random one (measured 1.11: it emits 12 %
-    more successors); and its lists are the reference's, every pair of a 2 048-node slice."""
+    more successors); and its lists are the reference's, every pair of the whole 65 536-node frontier."""
     require_reference_build()
     W = engine.workloads
     wl = W.make("C4")
@@ -191,13 +199,18 @@ def test_c4_wavefront_frontier_costs_at_most_1_3x_the_random_one(engine, oracle_
     rounds = [(ms(fr_r), ms(fr_w)) for _ in range(3)]
     ratio = sorted(b / a for a, b in rounds)[1]
     assert ratio < 1.3, rounds
-    # parity of a slice of the wavefront launch (the last thing written)
+    # parity of the WHOLE wavefront launch (the last thing written): every pair against the reference build
     env.expand_lists_resident(fr_w, lists)
     env.synchronize()
-    n = 2048
-    got = lists.download_nodes(0, n)
-    ref = oracle_lib.expand(oracle_env(wl), np.ascontiguousarray(wf[:, :n]), threads=os.cpu_count() or 1, ref=True)
-    assert_lists_equal(got, ref, n, wl.U.shape[0])
+    assert env.last_grid_kernel() == "lex"
+    N, nU = wl.n_nodes, wl.U.shape[0]
+    chunk = max(1, min(N, (6 << 20) // nU))
+    oenv = oracle_env(wl)
+    for lo in range(0, N, chunk):
+        hi = min(N, lo + chunk)
+        got = lists.download_nodes(lo, hi)
+        ref = oracle_lib.expand(oenv, np.ascontiguousarray(wf[:, lo:hi]), threads=os.cpu_count() or 1, ref=True)
+        assert_lists_equal(got, ref, hi - lo, nU, what="C4 wavefront frontier nodes [%d, %d)" % (lo, hi))
     lists.free()
     fr_r.free()
     fr_w.free()

@@ -122,6 +122,37 @@ def test_lex_kernel_is_not_taken_outside_its_scope(engine, monkeypatch):
     env.close()
 
 
+@pytest.mark.parametrize("case", ["n_max_62", "unbounded_velocity", "9261_controls", "8000_controls_in_scope"])
+def test_lex_scope_exits_still_give_the_reference_lists(engine, oracle_lib, case):
+    """The edges of the lexicographic kernel's scope (expand_lex_kernel.hip header; plan_grid in mplx_api.cpp): more than 61
+    samples per primitive (v_max * dt / res > 60), no velocity bound (v_max <= 0: the sample count has no bound either)
+    and more than 8 192 controls leave the factorised route altogether -- AUTO must pick a kernel that covers them and the
+    lists must still be the reference's; 8 000 controls (20^3) are the largest cubic table still inside."""
+    W = engine.workloads
+    if case in ("n_max_62", "unbounded_velocity"):
+        wl = _small_world(engine, 3, 0x03, seed=9100, n_nodes=64)
+        wl.params["v_max"] = 6.15 if case == "n_max_62" else -1.0  # ceil(6.15 / 0.1) + 1 = 63 > 61
+        if case == "n_max_62":
+            wl.nodes[3:6, :8] = np.array([[6.0, -6.0, 5.5, 0.0, 6.1, -6.1, 3.0, 6.0]] * 3) * np.array([[1.0], [0.5], [-1.0]])
+    else:
+        k = 21 if case == "9261_controls" else 20
+        wl = _small_world(engine, 3, 0x03, seed=9200, n_nodes=24)
+        wl.U = W.grid_controls(np.linspace(-1.0, 1.0, k), 3)
+        assert wl.U.shape[0] == k ** 3
+    ref = oracle_lib.expand(oracle_env(wl), wl.nodes, threads=8)
+    env = engine_env(engine, wl)
+    got = env.expand_lists(wl.nodes)
+    route, kernel = env.last_lists_route(), env.last_grid_kernel()
+    env.close()
+    if case == "8000_controls_in_scope":
+        assert route == "grid" and kernel == "lex", (route, kernel)
+    else:
+        assert route in ("tile", "dense") and kernel == "none", (case, route, kernel)
+    assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="scope exit %s (route %s)" % (case, route))
+    st = ref["status"]
+    assert (st == 1).any() and (st == 2).any()
+
+
 def test_lex_kernel_single_node_calls_and_empty_lists(engine, oracle_lib):
     """get_succ-sized calls (one node, the completion word) and nodes without any successor (every entry of an axis over
     the limit: nA = 0) through the host-pointer entry point."""
