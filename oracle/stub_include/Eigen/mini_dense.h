@@ -161,8 +161,8 @@ class Matrix : public MatrixBase<Matrix<T, R, C>> {
   // 3.3's redux on an SSE2 build with EIGEN_UNALIGNED_VECTORIZE (its default): one Packet2d of products reduced, then the
   // scalar tail added (Redux.h, LinearVectorizedTraversal + CompleteUnrolling).  A build without vectorisation (Eigen 3.2,
   // or -DEIGEN_DONT_VECTORIZE) unrolls the scalar redux in halves instead: x0 y0 + (x1 y1 + x2 y2).  The reference pins
-  // no Eigen version, so either is "the reference"; the two differ by at most one rounding of the sum
-  // (<= 1.2e-16 relative after the square root), and on the hot path only env_map.h:116's vel.norm() on 3D potential
+  // no Eigen version, so either is "the reference"; the two differ by at most two units in the last
+  // place of the norm (<= 4.5e-16 relative), and on the hot path only env_map.h:116's vel.norm() on 3D potential
   // maps with gradient_weight != 0 sees a 3-vector -- a COST, for which north_star allows 1e-6.  2-vectors (validate_yaw,
   // the heading cost) have one tree only.  tests/test_oracle_known_answers.py bounds the difference.
   T dot(const Matrix &o) const { T acc = (*this)(0) * o(0); for (int i = 1; i < size(); i++) acc += (*this)(i) * o(i); return acc; }

@@ -105,16 +105,17 @@ def test_default_heuristic():
     assert O.heur(2, O.ACC, 10.0, 1.0, goal, goal) == 0.0
 
 
-def test_three_vector_norm_summation_order_is_within_one_rounding():
+def test_three_vector_norm_summation_order_is_within_two_ulps():
     """env_map.h:116's vel.norm() on a 3-vector is the one expression of the path whose value depends on Eigen's redux
     tree, which the reference does not pin (oracle/stub_include/Eigen/mini_dense.h): index order
     (x^2 + y^2) + z^2 -- Eigen 3.3 vectorised, the oracle, the stand-in headers and the kernels -- against the scalar
-    unrolled x^2 + (y^2 + z^2).  The two norms differ by at most one unit in the last place; the potential-map COST that
-    multiplies them by gradient_weight * dt is therefore identical to ~1e-16 relative, ten orders inside north_star's 1e-6."""
+    unrolled x^2 + (y^2 + z^2).  The two norms differ by at most two units in the last place; the potential-map COST that
+    multiplies them by gradient_weight * dt is therefore identical to ~5e-16 relative, nine orders inside north_star's 1e-6."""
     rng = np.random.default_rng(5)
     v = np.round(rng.uniform(-3, 3, size=(200000, 3)) / 0.125) * 0.125 + rng.uniform(-1e-3, 1e-3, size=(200000, 3))
     a = np.sqrt((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2])
     b = np.sqrt(v[:, 0] * v[:, 0] + (v[:, 1] * v[:, 1] + v[:, 2] * v[:, 2]))
     differ = a != b
     assert 0 < differ.mean() < 0.5          # the order does matter on some inputs ...
-    assert np.all(np.abs(a - b) <= np.spacing(np.maximum(a, b)))   # ... by one unit in the last place at most
+    assert np.all(np.abs(a - b) <= 2 * np.spacing(np.maximum(a, b)))   # ... by two units in the last place at most
+    assert np.all(np.abs(a - b) <= 4.5e-16 * b)
