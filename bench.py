@@ -75,6 +75,9 @@ def measured_traffic(workload, kernel):
     """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, each its own
     run; profiles/README.md): bench.py cannot collect counters itself, so it reports the figure measured for
     this workload + kernel, or None when no such profile is committed."""
+    rec = committed_counters(workload, kernel)  # round 5: every configuration in one file
+    if rec and rec.get("traffic_bytes"):
+        return rec["traffic_bytes"]
     for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (rnd, workload.lower()))
         try:
@@ -84,6 +87,43 @@ def measured_traffic(workload, kernel):
         if rec.get("kernel", "").split("<")[0] in kernel:
             return rec["traffic_bytes"]
     return None
+
+
+def committed_counters(workload, kernel):
+    """Per-launch counters of this workload's kernel from the committed round-5 PMC passes (profiles/r05_counters.json,
+    written by profiles/run_round5_counters.sh on the GPU box: SQ_INSTS_VALU, FETCH_SIZE and WRITE_SIZE, each its own
+    rocprofv3 pass): bench.py cannot collect counters itself.  None when nothing is committed for this kernel."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r05_counters.json"))).get(workload)
+    except (OSError, ValueError):
+        return None
+    if not rec or rec.get("kernel", "").split("<")[0] not in kernel:
+        return None
+    return rec
+
+
+N_SIMD, SHADER_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def bound_of(rec, kernel_ms, frac_hbm):
+    """Which ceiling a kernel of the path runs against.  VALU issue: a wave64 VALU instruction occupies its SIMD for 4
+    cycles, so `SQ_INSTS_VALU x 4 / (1024 SIMDs x 2.4 GHz)` is the time the launch's vector instructions alone need with
+    every SIMD busy every cycle; issue_frac = that / the measured kernel time.  >= 0.4: the instruction stream is the
+    bound ("valu-issue"); HBM fraction >= 0.4: "hbm"; neither: "latency" (dependent chains / occupancy: more of either
+    resource would not be used)."""
+    out = {"bound": "hbm" if frac_hbm >= 0.4 else "latency", "issue_frac": None}
+    if rec and rec.get("valu_insts_per_launch"):
+        issue_ms = rec["valu_insts_per_launch"] * 4.0 / (N_SIMD * SHADER_CLOCK_HZ) * 1e3
+        out["issue_frac"] = issue_ms / kernel_ms
+        out["valu_issue_ms"] = issue_ms
+        out["valu_insts_per_launch"] = rec["valu_insts_per_launch"]
+        if frac_hbm < 0.4 and out["issue_frac"] >= 0.4:
+            out["bound"] = "valu-issue"
+    if rec and rec.get("traffic_bytes"):
+        out["traffic"] = rec["traffic_bytes"]
+    out["counters_source"] = ("profiles/r05_counters.json (rocprofv3 --pmc passes of this workload + kernel on an MI355X, committed; "
+                              "not collected in this run)") if rec else None
+    return out
 
 
 def count_work(env, frontier, n_nodes):
@@ -527,6 +567,16 @@ def extras(m, args, wl, out):
             r = run_config(m, w, args.steps, args.warmup)
             r.update(stats)
             r["workload"] = WORKLOAD_DESC[name]
+            r.update(bound_of(committed_counters(name, r["kernel"]), r["kernel_ms"], r["frac"]))
+            if not args.no_cpu_baseline:
+                # per configuration the reference's CPU path beside the kernel (bounded sample, ~3 s of all cores)
+                try:
+                    cb, _, _ = cpu_baseline(w, target_seconds=3.0)
+                    r["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "value_1thread")}
+                    r["speedup_vs_cpu_all_cores"] = r["pairs_per_s"] / cb["value"]
+                    r["speedup_vs_cpu_1thread"] = r["pairs_per_s"] / cb["value_1thread"]
+                except Exception as e:  # noqa: BLE001
+                    r["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
             res[name] = r
         # a lattice twice as fine as C4's on every axis (du = u / 8: 17 values per axis, 4 913 controls): the lexicographic
         # kernel's since round 4 (before: the general routes below); 8 192 nodes keep the lists at 5.3 GB
@@ -549,6 +599,33 @@ def extras(m, args, wl, out):
             res[args.workload + "_" + route + "_route"] = r
         return res
     leg("other_configs", others)
+
+    def strong_bound():
+        """The curve an 8-GPU node can at best produce for THE frontier (strong scaling, no data-path collective): the
+        kernel time of one rank's shard -- the first N/G nodes of the frontier, as shard.partition deals them -- on this
+        one GPU, each after its own clock spin-up.  Aggregate bound = all pairs / the shard's time (ranks run
+        concurrently on their own GPUs; launch gaps and the barrier come on top)."""
+        from motion_primitive_library_amd import shard
+        env = m.EnvMap(wl.dim, 0)
+        wl.apply(env)
+        res = []
+        for g in (1, 2, 4, 8):
+            lo, hi = shard.partition(wl.n_nodes, g, 0)
+            fr = env.upload_frontier(np.ascontiguousarray(wl.nodes[:, lo:hi]))
+            lists = env.alloc_lists(hi - lo, want_state=True, want_iters=False)
+            spin_up(env, fr, lists)
+            ms = sorted(time_lists(env, fr, lists, args.steps, 2) for _ in range(3))[1]
+            res.append({"gpus": g, "nodes_per_gpu": hi - lo, "shard_kernel_ms": ms,
+                        "aggregate_pairs_per_s_bound": wl.n_pairs / (ms * 1e-3),
+                        "efficiency_bound": None})
+            lists.free()
+            fr.free()
+        env.close()
+        for r in res:
+            r["efficiency_bound"] = res[0]["shard_kernel_ms"] / (r["gpus"] * r["shard_kernel_ms"])
+        return {"curve": res, "kernel": "expand_lex_kernel", "what": "compute bound of the strong-scaling run measured on ONE GPU (rank 0's "
+                "shard per world size); not a multi-GPU measurement"}
+    leg("strong_scaling_compute_bound", strong_bound)
     leg("plan", lambda: extra_plan(m))
 
 
@@ -933,7 +1010,13 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(args.workload, out_kernel) if world == 1 and args.frontier == "random" else None,
                 "traffic_source": "committed rocprofv3 --pmc passes of this workload + kernel (profiles/), not collected in this run",
+                # the launch's time is the write bandwidth of the pages its 2.7 GB of list entries landed in, and that has
+                # two modes per allocation (profiles/README.md, rounds 2 - 4): this run's, and the committed figures of both
+                "placement_modes": {"this_run_ms": kernel_ms, "this_run_frac": achieved / HBM_PEAK_GBS,
+                                    "fast_mode": {"ms": 0.480, "frac": 0.75}, "slow_mode": {"ms": 0.555, "frac": 0.65},
+                                    "source": "profiles/r04_placement_per_box.txt (6 boxes, first allocations: 4 slow, 2 fast)"},
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_alg,
+                "issue_frac": bound_of(committed_counters(args.workload, out_kernel), kernel_ms, achieved / HBM_PEAK_GBS).get("issue_frac"),
                 # what a process that allocates its output lists ONCE and never probes measures: the first probe (after
                 # the clock spin-up, before any other allocation existed)
                 "ms_per_step_first_allocation": placement["probe_ms"][0] if placement["probe_ms"] else kernel_ms,

@@ -172,6 +172,12 @@ typedef struct {
   int64_t state_stride;
   int32_t *iters;          /* diagnostic: executed sample-loop iterations     */
   int64_t node_stride;     /* S: entries reserved per node, >= nU; 0 = nU     */
+  /* ABI v8 -- what the graph search computes for every successor right after
+   * get_succ (graph_search.h:84-88), written by the expansion kernels while the
+   * successor is still in registers; needs mplx_set_goal:     */
+  double *heur;            /* [n_nodes*S] env_base::get_heur, default branch (env_base.h:46-64), or NULL */
+  uint8_t *flags;          /* [n_nodes*S] bit 0 inside the goal tolerances (env_map.h:25-37, no ray trace),
+                              bit 1 same lattice state as the goal (env_base.h:47), or NULL              */
 } mplx_succ_lists;
 
 /* Batched get_succ producing lists; device pointers, asynchronous on the
@@ -203,6 +209,14 @@ typedef struct {
   double tol_pos, tol_vel, tol_acc, tol_yaw; /* env_base.h:374-380; vel / acc /
                               yaw tests are skipped when < 0 (env_map.h:29-36)  */
 } mplx_goal_spec;
+
+/* ABI v8.  env_base::set_goal (env_base.h:274-276) for the device: the goal the `heur` / `flags` rows of
+ * mplx_succ_lists refer to -- the default heuristic w * |pos - goal.pos|_inf / v_max (w, v_max as given here: the
+ * search's, not necessarily the expansion's) and the tolerance tests of is_goal.  Copied; NULL clears it.  A launch
+ * that asks for either row without a goal fails with MPLX_ERR_STATE.  Bit-identical to mplx_post_lists_device on
+ * the same lists (tests/test_gpu_post.py), without reading them back: +9 bytes per successor on the launch instead
+ * of a second pass over hash and position rows.                                                                   */
+int mplx_set_goal(mplx_ctx *ctx, const mplx_goal_spec *goal);
 
 /* Outputs, device pointers of n_nodes*S entries each (S = node_stride of the
  * lists), any may be NULL; only the entries of emitted successors are written.

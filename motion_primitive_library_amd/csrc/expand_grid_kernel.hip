@@ -990,6 +990,26 @@ void expand_grid_kernel(const GridArgs A_kernarg) {
             st_stream(YAW ? s_yawT[jy] : 0.0, &o[(4 * D) * ss]);
             st_stream(node_t + A.dt, &o[(4 * D + 1) * ss]);  // env_map.h:161
           }
+          // what the search computes for the successor next (graph_search.h:84-88), while it is in registers
+          if ((A.post.heur || A.post.flags) && (mine || pad16)) {
+            double pp[D], vv[D], aa[D];
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+              const double *st = s_est + en[i] * (K - 1);
+              const double u = s_uval[en[i]];
+              const double uK = 0.0 + u;
+              const double top = (0.0 + u * T) + s_node[(K - 1) * D + i];
+              pp[i] = (K >= 2) ? st[0] : top;
+              vv[i] = (K >= 3) ? st[1] : (K == 2 ? top : uK);
+              aa[i] = (K >= 4) ? st[2] : (K == 3 ? top : (K == 2 ? uK : 0.0));
+            }
+            double hv;
+            unsigned int fv;
+            MPLX_POST_GOAL(pg, A.post, D)
+            post_eval<D>(pg, h, pp, vv, aa, YAW ? s_yawT[jy] : 0.0, &hv, &fv);
+            if (A.post.heur) st_stream(hv, &A.post.heur[idx]);
+            if (A.post.flags && mine) A.post.flags[idx] = (uint8_t)fv;
+          }
         }
         // ---- the sample loop of traverse_primitive (env_map.h:97-120)
         const bool smp = mine && n != 0;

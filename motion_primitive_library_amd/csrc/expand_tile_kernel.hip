@@ -360,6 +360,15 @@ __global__ __launch_bounds__(kBT) void expand_tile_kernel(const TileArgs A_kerna
           __builtin_nontemporal_store(0.0, &o[(4 * D) * ss]);  // Waypoint::yaw of a control without yaw (primitive.h:322)
           __builtin_nontemporal_store(ct + A.dt, &o[(4 * D + 1) * ss]);  // env_map.h:161
         }
+        // what the search computes for the successor next (graph_search.h:84-88), while it is in registers
+        if (wr && (A.post.heur || A.post.flags)) {
+          double hv;
+          unsigned int fv;
+          MPLX_POST_GOAL(pg, A.post, D)
+          post_eval<D>(pg, h_next, npos, nvel, nacc, 0.0, &hv, &fv);
+          if (A.post.heur) __builtin_nontemporal_store(hv, &A.post.heur[idx]);
+          if (A.post.flags) A.post.flags[idx] = (uint8_t)fv;
+        }
         if (!ONE) atomicAdd(&s_ncnt[nl], 1);
       } else {
         s_j[v] = 0xffffu;

@@ -6,6 +6,7 @@
 // There is deliberately no CPU implementation behind this ABI: every compute
 // entry either runs the gfx950 kernels or returns an error.
 #include "mplx_ctx.h"
+#include "host_planner.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -287,6 +288,31 @@ int mplx_set_params(mplx_ctx *c, const mplx_params *p) {
   if (int rc = mplx_detail::svc_stop(c)) return rc;  // a resident kernel carries the old parameters in its arguments
   c->prm = *p;
   c->has_params = true;
+  return MPLX_OK;
+}
+
+int mplx_set_goal(mplx_ctx *c, const mplx_goal_spec *g) {
+  if (!c) return MPLX_ERR_ARG;
+  if (int rc = resolve_pending(c)) return rc;
+  mplx::PostFuse f{};
+  bool has = false;
+  if (g) {
+    if (!g->goal) return fail(c, MPLX_ERR_ARG, "mplx_set_goal: goal waypoint is NULL");
+    if (!control_ok(g->control) || (g->goal_control && !control_ok(g->goal_control)))
+      return fail(c, MPLX_ERR_ARG, "mplx_set_goal: unknown control flag");
+    const int F = 4 * c->dim + 2;
+    for (int i = 0; i < F; i++) f.goal[i] = g->goal[i];
+    // env_base.h:47 compares the goal with a state by hash, each side hashed with its own flags (waypoint.h:93-125)
+    f.goal_hash = mplx::host::lattice_hash(c->dim, g->goal_control ? g->goal_control : g->control, g->goal);
+    f.w = g->w; f.v_max = g->v_max;
+    f.tol_pos = g->tol_pos; f.tol_vel = g->tol_vel; f.tol_acc = g->tol_acc; f.tol_yaw = g->tol_yaw;
+    has = true;
+  }
+  if (has != c->has_goal || std::memcmp(&f, &c->goal_fuse, sizeof(f)) != 0) {
+    if (int rc = mplx_detail::svc_stop(c)) return rc;  // a resident kernel carries the old goal in its arguments
+    c->goal_fuse = f;
+    c->has_goal = has;
+  }
   return MPLX_OK;
 }
 
@@ -833,6 +859,14 @@ int ensure_tables(mplx_ctx *c) {
   return MPLX_OK;
 }
 
+// the goal of mplx_set_goal with this launch's output rows (null rows: nothing is computed)
+mplx::PostFuse post_of(const mplx_ctx *c, const mplx_succ_lists *o) {
+  mplx::PostFuse f = c->goal_fuse;
+  f.heur = o->heur;
+  f.flags = o->flags;
+  return f;
+}
+
 mplx::TileArgs tile_args(mplx_ctx *c, const TilePlan &tp, const double *d_nodes, int64_t n_nodes, int64_t node_stride,
                          const mplx_succ_lists *o) {
   mplx::TileArgs a{};
@@ -856,6 +890,7 @@ mplx::TileArgs tile_args(mplx_ctx *c, const TilePlan &tp, const double *d_nodes,
   a.l_count = o->count; a.l_action = o->action; a.l_cost = o->cost; a.l_hash = o->hash;
   a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
   a.l_nstride = o->node_stride ? o->node_stride : c->nU;
+  a.post = post_of(c, o);
   return a;
 }
 
@@ -863,6 +898,8 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
                  const mplx_succ_lists *o) {
   const int F = 4 * c->dim + 2;
   const int route = c->lists_route;
+  if ((o->heur || o->flags) && !c->has_goal)
+    return fail(c, MPLX_ERR_STATE, "the heur / flags rows of the lists need a goal: call mplx_set_goal first");
   GridPlan gp = (route == MPLX_ROUTE_AUTO || route == MPLX_ROUTE_GRID) ? plan_grid(c) : GridPlan();
   if (route == MPLX_ROUTE_GRID && !gp.ok)
     return fail(c, MPLX_ERR_STATE, "lists route GRID does not cover this configuration");
@@ -911,6 +948,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
     a.l_nstride = o->node_stride ? o->node_stride : c->nU;
     a.l_pad = (a.l_nstride % 32 == 0 && !c->tune.no_line_pad) ? 1 : 0;  // see expand_grid_kernel.hip
+    a.post = post_of(c, o);
     if (int rc = yaw_slot(c, &a.yaw)) return rc;
     // Yaw controls with a heading limit on a frontier of several nodes per wave: validate_yaw(t = 0) of every node
     // first, lane per node, and the main kernel walks the survivors only (grid_prescreen_kernel).  Small batches (a
@@ -1015,6 +1053,26 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     ca.l_state = o->state; ca.l_stride = o->state_stride; ca.l_iters = o->iters;
     ca.l_nstride = o->node_stride ? o->node_stride : c->nU;
     HIP_TRY(c, mplx::launch_compact_lists(ca, c->stream));
+  }
+  if (o->heur || o->flags) {
+    // the lane-per-pair kernel + compaction keeps no successor in registers at its list stores: the rows are made by
+    // the stand-alone pass over the finished lists (post_kernel.hip; same values), which reads hash and state rows
+    if (!o->hash || !o->state)
+      return fail(c, MPLX_ERR_STATE, "heur / flags rows on the DENSE lists route need the hash and state rows as well");
+    mplx::PostArgs pa{};
+    pa.count = o->count;
+    pa.hash = o->hash;
+    pa.state = o->state;
+    pa.sstride = o->state_stride;
+    pa.n_nodes = n_nodes;
+    pa.nstride = o->node_stride ? o->node_stride : c->nU;
+    for (int i = 0; i < F; i++) pa.goal[i] = c->goal_fuse.goal[i];
+    pa.goal_hash = c->goal_fuse.goal_hash;
+    pa.w = c->goal_fuse.w; pa.v_max = c->goal_fuse.v_max;
+    pa.tol_pos = c->goal_fuse.tol_pos; pa.tol_vel = c->goal_fuse.tol_vel; pa.tol_acc = c->goal_fuse.tol_acc; pa.tol_yaw = c->goal_fuse.tol_yaw;
+    pa.heur = o->heur;
+    pa.flags = o->flags;
+    HIP_TRY(c, mplx::launch_post_lists(c->dim, pa, c->stream));
   }
   c->last_route = MPLX_ROUTE_DENSE;
   return MPLX_OK;
@@ -1123,14 +1181,14 @@ int resolve_pending(mplx_ctx *c, bool stream_is_idle) {
 // ---- the service: small synchronous batches through a resident kernel (expand_tile_kernel.hip, SERVICE MODE)
 namespace {
 struct ArenaLayout {  // one block: node rows, counts, then the list rows that were asked for, all sized for n_alloc nodes
-  size_t o_count = 0, o_action = 0, o_cost = 0, o_hash = 0, o_iters = 0, o_state = 0, total = 0;
+  size_t o_count = 0, o_action = 0, o_cost = 0, o_hash = 0, o_iters = 0, o_heur = 0, o_flags = 0, o_state = 0, total = 0;
   int64_t n_alloc = 0, n_slots = 0;
 };
-enum : unsigned { kRowAction = 1, kRowCost = 2, kRowHash = 4, kRowIters = 8, kRowState = 16 };
+enum : unsigned { kRowAction = 1, kRowCost = 2, kRowHash = 4, kRowIters = 8, kRowState = 16, kRowHeur = 32, kRowFlags = 64 };
 
 unsigned rows_of(const mplx_succ_lists *o) {
   return (o->action ? kRowAction : 0u) | (o->cost ? kRowCost : 0u) | (o->hash ? kRowHash : 0u) |
-         (o->iters ? kRowIters : 0u) | (o->state ? kRowState : 0u);
+         (o->iters ? kRowIters : 0u) | (o->state ? kRowState : 0u) | (o->heur ? kRowHeur : 0u) | (o->flags ? kRowFlags : 0u);
 }
 
 ArenaLayout arena_layout(int F, int64_t n_alloc, int64_t S, unsigned rows) {
@@ -1143,7 +1201,9 @@ ArenaLayout arena_layout(int F, int64_t n_alloc, int64_t S, unsigned rows) {
   L.o_cost = L.o_action + ((rows & kRowAction) ? up((size_t)L.n_slots * 4) : 0);
   L.o_hash = L.o_cost + ((rows & kRowCost) ? up((size_t)L.n_slots * 8) : 0);
   L.o_iters = L.o_hash + ((rows & kRowHash) ? up((size_t)L.n_slots * 8) : 0);
-  L.o_state = L.o_iters + ((rows & kRowIters) ? up((size_t)L.n_slots * 4) : 0);
+  L.o_heur = L.o_iters + ((rows & kRowIters) ? up((size_t)L.n_slots * 4) : 0);
+  L.o_flags = L.o_heur + ((rows & kRowHeur) ? up((size_t)L.n_slots * 8) : 0);
+  L.o_state = L.o_flags + ((rows & kRowFlags) ? up((size_t)L.n_slots) : 0);
   L.total = L.o_state + ((rows & kRowState) ? up((size_t)F * L.n_slots * 8) : 0);
   return L;
 }
@@ -1160,6 +1220,8 @@ mplx_succ_lists arena_lists(char *b, const ArenaLayout &L, int64_t S, unsigned r
   if (rows & kRowCost) d.cost = (double *)(b + L.o_cost);
   if (rows & kRowHash) d.hash = (uint64_t *)(b + L.o_hash);
   if (rows & kRowIters) d.iters = (int32_t *)(b + L.o_iters);
+  if (rows & kRowHeur) d.heur = (double *)(b + L.o_heur);
+  if (rows & kRowFlags) d.flags = (uint8_t *)(b + L.o_flags);
   if (rows & kRowState) { d.state = (double *)(b + L.o_state); d.state_stride = L.n_slots; }
   d.node_stride = S;
   return d;
@@ -1176,6 +1238,8 @@ void arena_get_lists(const char *hb, const ArenaLayout &L, int F, int64_t S, int
     if (h_out->cost) std::memcpy(h_out->cost + at, hb + L.o_cost + at * 8, m * 8);
     if (h_out->hash) std::memcpy(h_out->hash + at, hb + L.o_hash + at * 8, m * 8);
     if (h_out->iters) std::memcpy(h_out->iters + at, hb + L.o_iters + at * 4, m * 4);
+    if (h_out->heur) std::memcpy(h_out->heur + at, hb + L.o_heur + at * 8, m * 8);
+    if (h_out->flags) std::memcpy(h_out->flags + at, hb + L.o_flags + at, m);
     if (h_out->state)
       for (int f = 0; f < F; f++)
         std::memcpy(h_out->state + (size_t)f * h_out->state_stride + at,

@@ -34,6 +34,9 @@ struct mplx_ctx {
   // environment (device copies)
   mplx_detail::DevBuf map, pot, region_bits, region_bytes, U;
   bool has_map = false, has_pot = false, has_region = false, has_params = false, has_U = false;
+  // mplx_set_goal: the goal the heur / flags rows of mplx_succ_lists refer to (PostFuse without its output pointers)
+  bool has_goal = false;
+  mplx::PostFuse goal_fuse{};
   int32_t mdim[3] = {1, 1, 1};
   double origin[3] = {0, 0, 0};
   double res = 0;

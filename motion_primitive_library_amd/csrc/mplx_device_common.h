@@ -246,6 +246,58 @@ struct Ax {
   }
 };
 
+// Heuristic and goal flags of ONE successor (PostFuse of mplx_internal.h), from the values its state rows hold --
+// the arithmetic of post_kernel.hip::post_lists_kernel, which reads those rows back from memory:
+//   heur   env_base.h:46-64, default branch: 0 for the goal's own lattice state (a hash comparison, :47), else
+//          w * |pos - goal.pos|_inf / v_max (w * |.|_inf when v_max <= 0)
+//   flags  bit 0: env_map.h:25-37 without the ray trace; bit 1: the goal's lattice state
+// pos / vel / acc: the D values of the successor's rows 0..D-1, D..2D-1, 2D..3D-1; yaw: row 4D.
+struct PostGoal {  // PostFuse's scalars in registers (the kernel arguments live in the constant address space)
+  double g[14];
+  uint64_t goal_hash;
+  double w, v_max, tol_pos, tol_vel, tol_acc, tol_yaw;
+};
+#define MPLX_POST_GOAL(PG, PF, D_)                                                                         \
+  dev::PostGoal PG;                                                                                        \
+  _Pragma("unroll") for (int i_ = 0; i_ < 3 * (D_); i_++) PG.g[i_] = (PF).goal[i_];                        \
+  PG.g[4 * (D_)] = (PF).goal[4 * (D_)];                                                                    \
+  PG.goal_hash = (PF).goal_hash; PG.w = (PF).w; PG.v_max = (PF).v_max; PG.tol_pos = (PF).tol_pos;          \
+  PG.tol_vel = (PF).tol_vel; PG.tol_acc = (PF).tol_acc; PG.tol_yaw = (PF).tol_yaw;
+
+template <int D>
+__device__ __forceinline__ void post_eval(const PostGoal &P, uint64_t h, const double *pos, const double *vel, const double *acc,
+                                          double yaw, double *heur, unsigned int *flags) {
+  const bool is_goal_state = (h == P.goal_hash);
+  double m = 0;  // lpNorm<Infinity> of pos - goal.pos
+#pragma unroll
+  for (int i = 0; i < D; i++) {
+    const double d = fabs(pos[i] - P.g[i]);
+    m = d > m ? d : m;
+  }
+  *heur = is_goal_state ? 0.0 : (P.v_max > 0 ? P.w * m / P.v_max : P.w * m);
+  bool goaled = m <= P.tol_pos;  // env_map.h:26-28
+  if (goaled && P.tol_vel >= 0) {
+    double mv = 0;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      const double d = fabs(vel[i] - P.g[D + i]);
+      mv = d > mv ? d : mv;
+    }
+    goaled = mv <= P.tol_vel;
+  }
+  if (goaled && P.tol_acc >= 0) {
+    double ma = 0;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      const double d = fabs(acc[i] - P.g[2 * D + i]);
+      ma = d > ma ? d : ma;
+    }
+    goaled = ma <= P.tol_acc;
+  }
+  if (goaled && P.tol_yaw >= 0) goaled = fabs(yaw - P.g[4 * D]) <= P.tol_yaw;
+  *flags = (goaled ? 1u : 0u) | (is_goal_state ? 2u : 0u);
+}
+
 }  // namespace dev
 }  // namespace mplx
 #endif

@@ -75,6 +75,17 @@ struct DoneSignal {
   uint64_t seq;
 };
 
+// What the graph search computes for every successor right after get_succ (graph_search.h:84-88),
+// fused into the list stores of the expansion kernels: default heuristic (env_base.h:46-64) and goal flags
+// (env_map.h:25-37, bit 0; env_base.h:47, bit 1).  Null pointers = off.  Same arithmetic as post_kernel.hip.
+struct PostFuse {
+  double *heur;     // [n_nodes * l_nstride] or null
+  uint8_t *flags;   // [n_nodes * l_nstride] or null
+  double goal[14];  // the goal waypoint's rows (pos, vel, acc, jrk, yaw, t)
+  uint64_t goal_hash;
+  double w, v_max, tol_pos, tol_vel, tol_acc, tol_yaw;
+};
+
 // Mailbox of the resident (service) form of the tiled kernel, in pinned host memory; every word on its own line.
 struct SvcMailbox {
   uint64_t doorbell;  // host -> device: (seq << 32) | n_nodes of the request in the landing block
@@ -122,6 +133,7 @@ struct TileArgs {
   int32_t *l_iters;
   int64_t l_nstride;  // entries reserved per node (>= nU)
   int32_t l_pad;      // 1: complete the last 128-byte line of every list row (node stride is a multiple of 32)
+  PostFuse post;      // heuristic / goal flags per successor, same indexing as the lists
   // service mode (expand_tile_kernel.hip): null / 0 for an ordinary launch
   SvcMailbox *svc_mb;   // pinned host memory
   uint64_t *svc_dev;    // device memory, zeroed before the launch: [0] = command, [1 + g] = last request workgroup g finished
@@ -193,6 +205,7 @@ struct GridArgs {
   int32_t *l_iters;
   int64_t l_nstride;  // entries reserved per node (>= nU)
   int32_t l_pad;      // 1: complete the last 128-byte line of every list row (node stride is a multiple of 32)
+  PostFuse post;      // heuristic / goal flags per successor, same indexing as the lists
   YawPin yaw;         // heading-limit decisions pinned to the host libm (see YawPin); tab row: [c0, s0, cT[16], sT[16]]
   // Pre-screen of yaw controls (grid_prescreen_kernel): the nodes whose own heading passes validate_yaw at t = 0, in
   // frontier order, and their number (device memory, written by the pre-screen launch that precedes this one on the

@@ -16,8 +16,12 @@ static int post_lists_impl(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t 
   if (!c) return MPLX_ERR_ARG;
   if (!d_lists || !goal || !d_out || n_nodes < 0 || !goal->goal)
     return fail(c, MPLX_ERR_ARG, "mplx_post_lists_device: NULL argument");
-  if (!d_lists->count || !d_lists->hash || !d_lists->state)
-    return fail(c, MPLX_ERR_ARG, "mplx_post_lists_device: the lists need count, hash and state");
+  if (!d_lists->count || !d_lists->hash)
+    return fail(c, MPLX_ERR_ARG, "mplx_post_lists_device: the lists need count and hash");
+  // Lists without state rows: the heuristic needs positions, so only the identity (canon) can be asked for; a `flags`
+  // row is then taken as the one the expansion launch wrote (mplx_succ_lists::flags) and gets its bit 2 added.
+  if (!d_lists->state && (d_out->heur || !d_out->canon))
+    return fail(c, MPLX_ERR_ARG, "mplx_post_lists_device: lists without state rows can only be asked for canon (+ bit 2 of an existing flags row)");
   if (!c->has_U) return fail(c, MPLX_ERR_STATE, "mplx_post_lists_device: controls not set");
   if (n_nodes == 0) return MPLX_OK;
   if (int rc = bind_device(c)) return rc;
@@ -124,9 +128,14 @@ static int post_lists_impl(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t 
       // trip of the pass: did every run fit its bucket?  Heavy duplication of few lattice states can fill one bucket
       // beyond any fixed capacity; the exact form below has no capacities, and the (idempotent) heuristic / flags kernel
       // runs again on its canon[].
-      HIP_TRY(c, mplx::launch_post_lists(D, a, c->stream));
+      // (lists without state rows: the kernel only ORs the first-occurrence bit into an existing flags row, which is not
+      // idempotent on a canon[] that turns out wrong -- it runs once the outcome is known)
+      if (a.state) HIP_TRY(c, mplx::launch_post_lists(D, a, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
-      if (*(volatile int32_t *)c->id_ovf_host == 0) return MPLX_OK;
+      if (*(volatile int32_t *)c->id_ovf_host == 0) {
+        if (!a.state && a.flags) HIP_TRY(c, mplx::launch_post_lists(D, a, c->stream));
+        return MPLX_OK;
+      }
       *c->id_ovf_host = 0;
       exact = true;
       c->last_identity_form = 3;
@@ -155,7 +164,7 @@ static int post_lists_impl(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t 
     a.keys = (mplx::PostArgs::Slot *)c->post_keys.p;
     a.cap = cap;
   }
-  HIP_TRY(c, mplx::launch_post_lists(D, a, c->stream));
+  if (a.state || a.flags || a.keys) HIP_TRY(c, mplx::launch_post_lists(D, a, c->stream));
   return MPLX_OK;
 }
 

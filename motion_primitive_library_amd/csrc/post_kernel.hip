@@ -44,13 +44,19 @@ __global__ __launch_bounds__(256) void post_lists_kernel(const PostArgs A) {
   const uint64_t h = A.hash[g];
   const bool is_goal_state = (h == A.goal_hash);  // `goal_node_ == state` is a hash comparison (env_base.h:47)
   double m = 0;  // lpNorm<Infinity> of pos - goal.pos
+  if (A.state) {
 #pragma unroll
-  for (int i = 0; i < D; i++) {
-    const double d = fabs(A.state[(int64_t)i * A.sstride + g] - A.goal[i]);
-    m = d > m ? d : m;
+    for (int i = 0; i < D; i++) {
+      const double d = fabs(A.state[(int64_t)i * A.sstride + g] - A.goal[i]);
+      m = d > m ? d : m;
+    }
   }
   if (A.heur) A.heur[g] = is_goal_state ? 0.0 : (A.v_max > 0 ? A.w * m / A.v_max : A.w * m);
-  if (A.flags) {
+  if (A.flags && !A.state) {
+    // lists without state rows: `flags` was written by the expansion launch (mplx_succ_lists::flags, bits 0 - 1);
+    // only the first-occurrence bit is added (the table route does the same in post_canon_kernel)
+    if (!A.keys && A.canon && A.canon[g] == (int32_t)g) A.flags[g] |= 4;
+  } else if (A.flags) {
     bool goaled = m <= A.tol_pos;  // env_map.h:26-28
     if (goaled && A.tol_vel >= 0) {
       double mv = 0;
