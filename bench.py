@@ -320,7 +320,7 @@ def engine_plan(m, dim, origin, md, cells, res, U, start, goal, v_max, a_max, ba
     s = pl.summary()
     pl.close()
     sp = {k: round(split[k], 3) for k in ("provider_ms", "fill_ms", "pick_ms", "relax_ms", "recover_ms")}
-    sp.update({k: int(split[k]) for k in ("relaxed", "improved", "pushes", "materialised")})
+    sp.update({k: int(split[k]) for k in ("relaxed", "improved", "pushes", "materialised", "heur_from_device")})
     sp["what"] = ("provider = launches + completion + transfers (the device's share); relax = relaxation passes, node table, "
                   "heap and goal tests on one host thread; fill = lists moved out of the landing buffer; pick = choice of the "
                   "next launch's nodes")

@@ -482,8 +482,15 @@ typedef struct {
   int64_t improved;     /* ... of which lowered the child's g (graph_search.h:108)                                */
   int64_t pushes;       /* heap pushes (the rest of `improved` were updates in place)                             */
   int64_t materialised; /* nodes whose 4D+2 state was ever built on the host (picked for a launch or on the path) */
+  int64_t heur_from_device; /* new nodes whose heuristic came with their list from the expansion launch (the `heur`
+                               row of mplx_succ_lists) instead of being evaluated by the search                     */
 } mplx_plan_timing;
 int mplx_planner_timing(const mplx_planner *p, mplx_plan_timing *out);
+/* ABI v8.  on != 0: the plans of this planner call mplx_set_goal on the attached context and take the heuristic of new
+ * nodes from the `heur` row the expansion launches write (SURVEY.md 8f-2 with its consumer); 0 (the default): the search
+ * evaluates it itself from the successor's position.  Same search bit for bit either way (tests/test_gpu_plan.py); on
+ * the 3D problems of the bench line the row costs 3 % (8 bytes per successor over PCIe for a value 7 % of them need). */
+int mplx_planner_use_device_heuristic(mplx_planner *p, int on);
 
 /* ---- diagnostics -------------------------------------------------------- */
 /* The host search's evaluation of a successor state (Primitive<Dim>(node, u, dt).evaluate(dt),

@@ -19,7 +19,7 @@ SYMBOLS = [
     "mplx_set_map", "mplx_set_potential", "mplx_set_region", "mplx_set_params", "mplx_set_controls",
     "mplx_update_potential_map", "mplx_set_search_region_path",
     "mplx_expand_device", "mplx_expand", "mplx_expand_lists_device", "mplx_expand_lists", "mplx_get_succ",
-    "mplx_post_lists_device", "mplx_post_packed_device",
+    "mplx_set_goal", "mplx_post_lists_device", "mplx_post_packed_device",
     "mplx_pack_lists_device", "mplx_comm_unique_id", "mplx_comm_init", "mplx_comm_destroy", "mplx_comm_broadcast_map",
     "mplx_comm_allgather_lists", "mplx_comm_schedule",
     "mplx_check_edges",
@@ -27,7 +27,7 @@ SYMBOLS = [
     "mplx_synchronize", "mplx_timer_begin", "mplx_timer_end",
     "mplx_planner_create", "mplx_planner_destroy", "mplx_planner_attach_ctx", "mplx_planner_set_provider",
     "mplx_planner_set_map", "mplx_planner_set_controls", "mplx_planner_configure", "mplx_planner_plan",
-    "mplx_planner_trajectory", "mplx_planner_trajectory_end", "mplx_planner_closed_set", "mplx_planner_open_set", "mplx_planner_last_error", "mplx_planner_timing",
+    "mplx_planner_trajectory", "mplx_planner_trajectory_end", "mplx_planner_closed_set", "mplx_planner_open_set", "mplx_planner_last_error", "mplx_planner_timing", "mplx_planner_use_device_heuristic",
     "mplx_selftest_math", "mplx_selftest_forward_state", "mplx_set_lists_route", "mplx_last_lists_route", "mplx_last_grid_kernel", "mplx_last_identity_form", "mplx_debug_store_model", "mplx_yaw_pin_stats", "mplx_service", "mplx_device_info",
 ]
 
@@ -54,6 +54,7 @@ class SuccLists(C.Structure):
     _fields_ = [
         ("count", C.c_void_p), ("action", C.c_void_p), ("cost", C.c_void_p), ("hash", C.c_void_p),
         ("state", C.c_void_p), ("state_stride", C.c_int64), ("iters", C.c_void_p), ("node_stride", C.c_int64),
+        ("heur", C.c_void_p), ("flags", C.c_void_p),  # ABI v8: written by the expansion launch (mplx_set_goal)
     ]
 
 
@@ -110,7 +111,7 @@ class PlanSummary(C.Structure):
 
 class PlanTiming(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("total_ms", "provider_ms", "fill_ms", "pick_ms", "relax_ms", "recover_ms")] + \
-               [(k, C.c_int64) for k in ("relaxed", "improved", "pushes", "materialised")]
+               [(k, C.c_int64) for k in ("relaxed", "improved", "pushes", "materialised", "heur_from_device")]
 
 
 class MplxError(RuntimeError):
@@ -147,6 +148,7 @@ def lib():
         "mplx_set_region": (C.c_int, [vp, vp]),
         "mplx_set_params": (C.c_int, [vp, C.POINTER(Params)]),
         "mplx_set_controls": (C.c_int, [vp, vp, i32, i32]),
+        "mplx_set_goal": (C.c_int, [vp, C.POINTER(GoalSpec)]),
         "mplx_update_potential_map": (C.c_int, [vp, vp, vp, vp, dbl, vp]),
         "mplx_set_search_region_path": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "mplx_expand_device": (C.c_int, [vp, vp, i64, i64, C.POINTER(Succ)]),
@@ -186,6 +188,7 @@ def lib():
         "mplx_planner_open_set": (C.c_int, [vp, vp, i32, C.POINTER(i32)]),
         "mplx_planner_last_error": (C.c_char_p, [vp]),
         "mplx_planner_timing": (C.c_int, [vp, C.POINTER(PlanTiming)]),
+        "mplx_planner_use_device_heuristic": (C.c_int, [vp, C.c_int]),
         "mplx_selftest_math": (C.c_int, [vp, C.c_int, vp, vp, vp, i64]),
         "mplx_selftest_forward_state": (C.c_int, [i32, i32, vp, vp, C.c_double, vp]),
         "mplx_set_lists_route": (C.c_int, [vp, C.c_int]),

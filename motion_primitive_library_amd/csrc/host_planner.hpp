@@ -141,6 +141,7 @@ struct PackedView {
   const uint64_t *hash = nullptr;   // [total]
   const int32_t *action = nullptr;  // [total]
   const double *state = nullptr;    // [4D+2][total]
+  const double *heur = nullptr;     // [total] default heuristic of every successor (env_base.h:46-64), when the provider computes it
 };
 typedef int (*packed_fn)(void *user, const double *nodes, int64_t n, PackedView *out);
 
@@ -152,6 +153,7 @@ struct SuccView {
   const int32_t *act = nullptr;
   const double *state = nullptr;
   int64_t fs = 1, es = 1;
+  const double *heur = nullptr;    // the provider's heuristic of every successor, or null (then the search evaluates it)
 };
 
 // ---- the search's bookkeeping (StateSpace of the reference, state_space.h:37-104), laid out for the relaxation loop.
@@ -457,7 +459,7 @@ struct PlanResult {
   int64_t state_mismatches = 0;  // check_states: successors whose host-evaluated state differs from the device's
   // where the wall time went (ms) and what the relaxation loop did
   double t_total = 0, t_provider = 0, t_fill = 0, t_pick = 0, t_relax = 0, t_recover = 0;
-  int64_t relaxed = 0, improved = 0, pushes = 0, materialised = 0;
+  int64_t relaxed = 0, improved = 0, pushes = 0, materialised = 0, heur_from_provider = 0;
   double total_time = 0;
   double J[4] = {0, 0, 0, 0};  // J(VEL), J(ACC), J(JRK), J(SNP) of the trajectory
   std::vector<double> traj_nodes;  // [segments][4D+2] start state of each primitive
@@ -748,6 +750,7 @@ class Planner {
           c_curr = &coords[(size_t)cold[curr].coord * (size_t)f];  // (coords may have moved)
         }
         if (eps == 0 || key == goal_key) nd.h = 0;
+        else if (sv.heur) { nd.h = sv.heur[s]; last.heur_from_provider++; }  // computed where the successor was made
         else {
           if (!have_sc) forward_pos(dim, control, c_curr, &U[(size_t)sv.act[s] * udim], dt, sc);
           nd.h = heur_keyed(sc, key, goal, goal_key);
@@ -1209,6 +1212,10 @@ class Planner {
     for (size_t b = 0; b < m * 8; b += 64) __builtin_prefetch(c + b);
     if (cur_view.hash) for (size_t b = 0; b < m * 8; b += 64) __builtin_prefetch(h + b);
     for (size_t b = 0; b < m * 4; b += 64) __builtin_prefetch(a + b);
+    if (cur_view.heur) {
+      const char *hr = (const char *)(cur_view.heur + o);
+      for (size_t b = 0; b < m * 8; b += 64) __builtin_prefetch(hr + b);
+    }
   }
   void view_of(const CacheRec &c, SuccView *v) const {
     const int f = F();
@@ -1216,7 +1223,7 @@ class Planner {
       // still in the landing buffer of the latest launch: read in place
       const size_t o = (size_t)cur_view.offs[c.slot];
       *v = SuccView{cur_view.count[c.slot], cur_view.cost + o, cur_view.hash ? cur_view.hash + o : nullptr, cur_view.action + o,
-                    cur_view.state ? cur_view.state + o : nullptr, cur_view.total, 1};
+                    cur_view.state ? cur_view.state + o : nullptr, cur_view.total, 1, cur_view.heur ? cur_view.heur + o : nullptr};
       return;
     }
     const size_t m = (size_t)c.m;

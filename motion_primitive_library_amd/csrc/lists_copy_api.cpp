@@ -230,7 +230,7 @@ int copy_lists_to_host(mplx_ctx *c, const mplx_succ_lists &d, const mplx_succ_li
 }
 
 int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t node_stride, bool want_state,
-                        PackedLists *out) {
+                        PackedLists *out, bool want_heur) {
   if (!c || !out || !h_nodes || n_nodes <= 0 || node_stride < n_nodes) return fail(c, MPLX_ERR_ARG, "expand_lists_packed: bad arguments");
   if (int rc = ctx_ready(c)) return rc;
   const int F = 4 * c->dim + 2;
@@ -245,6 +245,7 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
     uint64_t dummy_h = 0;
     want.count = &dummy_i; want.action = &dummy_i; want.cost = &dummy_d; want.hash = &dummy_h;  // (names the rows only)
     if (want_state) want.state = &dummy_d;
+    if (want_heur) want.heur = &dummy_d;
     want.node_stride = S;
     bool handled = false;
     if (int rc = svc_request(c, h_nodes, n_nodes, node_stride, &want, &handled, &v)) return rc;
@@ -259,13 +260,14 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
       out->hash = v.hash;
       out->action = v.action;
       out->state = want_state ? v.state : nullptr;
+      out->heur = want_heur ? v.heur : nullptr;
       return MPLX_OK;
     }
     const int counted = c->svc.streak;  // (what svc_request made of it; bind_device resets it)
     if (int rc = bind_device(c)) return rc;
     c->svc.streak = counted;
   }
-  if (c->tune.zero_copy && (size_t)n_slots * (size_t)((want_state ? F * 8 : 0) + 24) <= ((size_t)32 << 20)) {
+  if (c->tune.zero_copy && (size_t)n_slots * (size_t)((want_state ? F * 8 : 0) + 24 + (want_heur ? 8 : 0)) <= ((size_t)32 << 20)) {
     // Batches of a search: the kernel reads the nodes from and writes the lists into one pinned host block itself
     // (only the used entries cross PCIe, while the kernel runs): the call is the kernel and one synchronisation.
     // The view then describes the strided lists as they are: offs[k] = k * S, row stride n_nodes * S.
@@ -275,7 +277,8 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
     const size_t o_act = o_off + up((size_t)(n_nodes + 1) * 8);
     const size_t o_cost = o_act + up((size_t)n_slots * 4);
     const size_t o_hash = o_cost + up((size_t)n_slots * 8);
-    const size_t o_state = o_hash + up((size_t)n_slots * 8);
+    const size_t o_heur = o_hash + up((size_t)n_slots * 8);
+    const size_t o_state = o_heur + (want_heur ? up((size_t)n_slots * 8) : 0);
     const size_t bytes = o_state + (want_state ? up((size_t)F * n_slots * 8) : 0);
     if (bytes > c->pk_hb_cap) {
       if (c->pk_hb) HIP_TRY(c, hipHostFree(c->pk_hb));
@@ -293,6 +296,7 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
     d.cost = (double *)(hb + o_cost);
     d.hash = (uint64_t *)(hb + o_hash);
     if (want_state) { d.state = (double *)(hb + o_state); d.state_stride = n_slots; }
+    if (want_heur) d.heur = (double *)(hb + o_heur);
     d.node_stride = S;
     c->want_done = true;  // the kernel tells the host itself when the lists are in the block (DoneSignal)
     const int rc_launch = lists_on_device(c, (const double *)hb, n_nodes, n_nodes, &d);
@@ -310,8 +314,11 @@ int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int
     out->hash = d.hash;
     out->action = d.action;
     out->state = d.state;
+    out->heur = d.heur;
     return MPLX_OK;
   }
+  // (larger batches are packed on the device and copied: the heuristic row does not travel that way -- the search
+  // evaluates it itself, host_planner.hpp, as it does for every provider without that row)
   // pinned host block: [nodes F x n][count n][offs n + 1]
   const size_t o_cnt = ((size_t)F * n_nodes * 8 + 255) & ~(size_t)255;
   const size_t o_off = (o_cnt + (size_t)n_nodes * 4 + 255) & ~(size_t)255;

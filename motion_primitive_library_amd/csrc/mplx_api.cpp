@@ -1486,6 +1486,9 @@ int mplx_expand_lists(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64
       return MPLX_OK;
     }
   }
+  if (h_out->heur || h_out->flags)
+    return fail(c, MPLX_ERR_ARG, "mplx_expand_lists: the heur / flags rows come back through host pointers for batches of up to "
+                                 "8 MiB of lists only (a search's); larger ones: mplx_expand_lists_device and a copy of the rows");
   if (int rc = ensure(c, c->s_nodes, (size_t)F * n_nodes * sizeof(double))) return rc;
   HIP_TRY(c, hipMemcpy2DAsync(c->s_nodes.p, (size_t)n_nodes * sizeof(double), h_nodes,
                               (size_t)node_stride * sizeof(double), (size_t)n_nodes * sizeof(double), F,

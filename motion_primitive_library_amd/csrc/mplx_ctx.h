@@ -233,9 +233,10 @@ struct PackedLists {
   const uint64_t *hash = nullptr;   // [total]
   const int32_t *action = nullptr;  // [total]
   const double *state = nullptr;    // [4D+2][total]
+  const double *heur = nullptr;     // [total] default heuristic of every successor (want_heur; needs mplx_set_goal)
 };
 int expand_lists_packed(mplx_ctx *c, const double *h_nodes, int64_t n_nodes, int64_t node_stride, bool want_state,
-                        PackedLists *out);  // want_state = false: out->state == nullptr, the kernel skips the states
+                        PackedLists *out, bool want_heur = false);  // want_state = false: out->state == nullptr, the kernel skips the states
 // mplx_api.cpp: readiness check and the route dispatch behind mplx_expand_lists*
 int ctx_ready(mplx_ctx *c);
 int lists_on_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t node_stride, const mplx_succ_lists *d);

@@ -10,6 +10,8 @@
 struct mplx_planner {
   mplx::host::Planner pl;
   mplx_ctx *ctx = nullptr;
+  bool device_heur = false;  // the expansion launches deliver the default heuristic of every successor (mplx_set_goal)
+  bool want_device_heur = getenv("MPLX_PLAN_DEVICE_HEUR") != nullptr && atoi(getenv("MPLX_PLAN_DEVICE_HEUR")) != 0;
   std::string err;
 };
 
@@ -46,7 +48,7 @@ int engine_lists(void *user, const double *nodes, int64_t n, int32_t *count, int
 int engine_packed(void *user, const double *nodes, int64_t n, mplx::host::PackedView *out) {
   mplx_planner *p = (mplx_planner *)user;
   mplx_detail::PackedLists pl;
-  if (int rc = mplx_detail::expand_lists_packed(p->ctx, nodes, n, n, !p->pl.edges_only || p->pl.check_states, &pl)) return rc;
+  if (int rc = mplx_detail::expand_lists_packed(p->ctx, nodes, n, n, !p->pl.edges_only || p->pl.check_states, &pl, p->device_heur)) return rc;
   out->total = pl.total;
   out->count = pl.count;
   out->offs = pl.offs;
@@ -54,6 +56,7 @@ int engine_packed(void *user, const double *nodes, int64_t n, mplx::host::Packed
   out->hash = pl.hash;
   out->action = pl.action;
   out->state = pl.state;
+  out->heur = pl.heur;
   return 0;
 }
 
@@ -153,6 +156,24 @@ int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, 
   if (p->pl.grid.cells.empty()) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: map not set");
   if (p->pl.nU <= 0) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: controls not set");
   if (!p->pl.single && !p->pl.batched && !p->pl.packed) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: no successor provider attached");
+  p->device_heur = false;
+  if (p->ctx && p->pl.packed && p->pl.eps != 0 && p->want_device_heur) {
+    // env_base::set_goal for the device (planner_base.h:301): the kernels compute what graph_search.h:84-88 asks of
+    // the env for every new successor -- the default heuristic -- while the successor is in registers.
+    // OFF by default (mplx_planner_use_device_heuristic / MPLX_PLAN_DEVICE_HEUR=1): one successor in fifteen creates a
+    // node, so the search needs 7 % of the row it pays 8 bytes per successor for on the PCIe link -- measured on the
+    // 3D problems 262.6 against 254.3 ms (160^3) and 13.2 against 13.0 ms (120^3) with the row
+    // (profiles/r05_device_heur_ab.txt); evaluating |pos - goal| of the few new successors costs the host less.
+    // The row pays where the consumer is on the device (mplx_post_*: no second pass over hash and position rows).
+    mplx_goal_spec g{};
+    g.goal = goal;
+    g.control = p->pl.control;
+    g.goal_control = p->pl.goal_control;
+    g.w = p->pl.w;
+    g.v_max = p->pl.v_max;
+    g.tol_pos = p->pl.tol_pos; g.tol_vel = p->pl.tol_vel; g.tol_acc = p->pl.tol_acc; g.tol_yaw = p->pl.tol_yaw;
+    if (mplx_set_goal(p->ctx, &g) == MPLX_OK) p->device_heur = true;
+  }
   int rc;
   try {
     rc = p->pl.plan(start, goal);
@@ -187,6 +208,12 @@ int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, 
   return MPLX_OK;
 }
 
+int mplx_planner_use_device_heuristic(mplx_planner *p, int on) {
+  if (!p) return MPLX_ERR_ARG;
+  p->want_device_heur = on != 0;
+  return MPLX_OK;
+}
+
 int mplx_planner_timing(const mplx_planner *p, mplx_plan_timing *out) {
   if (!p || !out) return MPLX_ERR_ARG;
   const mplx::host::PlanResult &r = p->pl.last;
@@ -200,6 +227,7 @@ int mplx_planner_timing(const mplx_planner *p, mplx_plan_timing *out) {
   out->improved = r.improved;
   out->pushes = r.pushes;
   out->materialised = r.materialised;
+  out->heur_from_device = r.heur_from_provider;
   return MPLX_OK;
 }
 

@@ -163,7 +163,7 @@ class Lists:
     """HBM-resident per-node successor lists (mplx_succ_lists)."""
 
     def __init__(self, env, n_nodes, nU, want_state=True, want_iters=False, want_hash=True, stride=None, alloc=None,
-                 state_pad=None):
+                 state_pad=None, want_heur=False, want_flags=False):
         self.n_nodes, self.nU = int(n_nodes), int(nU)
         # entries reserved per node: a multiple of 32 keeps every node's rows on 128-byte lines (and lets the
         # kernel complete the last line of each list instead of leaving a partial-line store)
@@ -179,6 +179,9 @@ class Lists:
         self.state_stride = n + (STATE_ROW_PAD if state_pad is None else int(state_pad))
         self.state = _alloc(env, self.state_stride * 8 * self.n_fields, alloc) if want_state else None
         self.iters = _alloc(env, n * 4, alloc) if want_iters else None
+        # rows the expansion launch fills for the search (mplx_set_goal): default heuristic, goal flags
+        self.heur = _alloc(env, n * 8, alloc) if want_heur else None
+        self.flags = _alloc(env, n, alloc) if want_flags else None
 
     def c_struct(self):
         s = _abi.SuccLists()
@@ -188,6 +191,8 @@ class Lists:
         s.state_stride = self.state_stride
         s.iters = self.iters.ptr if self.iters else None
         s.node_stride = self.stride
+        s.heur = self.heur.ptr if self.heur else None
+        s.flags = self.flags.ptr if self.flags else None
         return s
 
     def download(self):
@@ -204,6 +209,10 @@ class Lists:
             out["state"] = np.ascontiguousarray(st[:, :self.n_slots]) if self.state_stride != self.n_slots else st
         if self.iters:
             out["iters"] = self.iters.download(np.int32, (self.n_slots,))
+        if self.heur:
+            out["heur"] = self.heur.download(np.float64, (self.n_slots,))
+        if self.flags:
+            out["flags"] = self.flags.download(np.uint8, (self.n_slots,))
         return out
 
     def download_nodes(self, lo, hi):
@@ -229,7 +238,7 @@ class Lists:
         return out
 
     def free(self):
-        for b in (self.count, self.action, self.cost, self.hash, self.state, self.iters):
+        for b in (self.count, self.action, self.cost, self.hash, self.state, self.iters, self.heur, self.flags):
             if b is not None:
                 b.free()
 
@@ -525,8 +534,23 @@ class EnvMap:
         return out
 
     def alloc_lists(self, n_nodes, want_state=True, want_iters=False, want_hash=True, stride=None, alloc=None,
-                    state_pad=None):
-        return Lists(self, n_nodes, self.nU, want_state, want_iters, want_hash, stride, alloc, state_pad)
+                    state_pad=None, want_heur=False, want_flags=False):
+        return Lists(self, n_nodes, self.nU, want_state, want_iters, want_hash, stride, alloc, state_pad, want_heur, want_flags)
+
+    def set_goal(self, goal_row, w=None, v_max=None, tol_pos=0.5, tol_vel=-1.0, tol_acc=-1.0, tol_yaw=-1.0, goal_control=0):
+        """env_base::set_goal for the device (mplx_set_goal): the goal the `heur` / `flags` rows of the lists refer to.
+        goal_row=None clears it."""
+        self._flush()
+        if goal_row is None:
+            _abi.check(self._ctx, _abi.lib().mplx_set_goal(self._ctx, None))
+            return
+        goal = np.ascontiguousarray(goal_row, dtype=np.float64)
+        g = _abi.GoalSpec()
+        g.goal, g.control, g.goal_control = goal.ctypes.data, int(self._p.control), int(goal_control)
+        g.w = float(self._p.w if w is None else w)
+        g.v_max = float(self._p.v_max if v_max is None else v_max)
+        g.tol_pos, g.tol_vel, g.tol_acc, g.tol_yaw = float(tol_pos), float(tol_vel), float(tol_acc), float(tol_yaw)
+        _abi.check(self._ctx, _abi.lib().mplx_set_goal(self._ctx, C.byref(g)))
 
     def alloc_packed(self, n_nodes, capacity=None, want_state=True, want_hash=True, alloc=None):
         """Packed lists for n_nodes nodes; the default capacity n_nodes * nU always suffices."""

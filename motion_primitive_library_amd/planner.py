@@ -203,6 +203,11 @@ class MapPlanner:
                                            "pairs", "cost", "total_time", "segments")} | {
             "J": list(o.J), "state_mismatches": o.state_mismatches}
 
+    def useDeviceHeuristic(self, on=True):
+        """The heuristic of new nodes from the `heur` row the expansion launches write (mplx_set_goal) instead of the
+        search's own evaluation: same search, see mplx_planner_use_device_heuristic."""
+        self._check(self._L.mplx_planner_use_device_heuristic(self._p, 1 if on else 0))
+
     def timing(self):
         """Where the wall time of the last plan() went (ms) and what its relaxation loop did (mplx_plan_timing)."""
         t = _abi.PlanTiming()

@@ -35,7 +35,7 @@ def test_struct_layouts_match_the_header(engine):
     # mplx_params: 2 x int32 + 9 doubles; mplx_succ: 4 pointers + int64 + pointer
     assert C.sizeof(engine._abi.Params) == 8 + 9 * 8
     assert C.sizeof(engine._abi.Succ) == 6 * 8
-    assert C.sizeof(engine._abi.SuccLists) == 8 * 8  # 6 pointers + state_stride + node_stride
+    assert C.sizeof(engine._abi.SuccLists) == 10 * 8  # 8 pointers (heur, flags: ABI v8) + state_stride + node_stride
 
 
 def test_no_cpu_fallback(engine):

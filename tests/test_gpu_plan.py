@@ -348,3 +348,44 @@ def test_distance_map_planner_3d_with_yaw_three_ways(engine):
     pl.close()
     assert s["expansions"] == cpu[1]["expansions"] and s["closed"] == cpu[1]["closed"]
     assert abs(s["cost"] - cpu[1]["cost"]) <= 1e-9 * cpu[1]["cost"]
+
+
+def test_search_consumes_the_heuristic_the_expansion_launch_computed(engine):
+    """SURVEY.md 8f-2 with its consumer: the expansion launches of a plan() write the default heuristic of every
+    successor next to its edge (mplx_set_goal + the `heur` row of the lists, fused into the kernels' list stores), and
+    the search takes a new node's h from there instead of evaluating the successor's position itself
+    (graph_search.h:84-88; MapPlanner.useDeviceHeuristic -- off by default: the row costs more on the PCIe link than
+    the few evaluations it saves).  Same search as with the host evaluation, bit for bit: cost, expansions,
+    closed and open set, node count, trajectory.  (Lists that outlive their launch are kept without the row: nodes
+    created from those get the host evaluation, so not every node's h comes from the device.)"""
+    m = engine
+    W = m.workloads
+    runs = {}
+    for dim, edge, vals, ctrl in ((3, 56, np.linspace(-2.0, 2.0, 9), m.ACC), (2, 120, [-1.0, -0.5, 0.0, 0.5, 1.0], m.JRK)):
+        grid = W.box_map([edge] * dim, 0.1, 0.07, 77 + dim, side_m=(0.4, 1.2))
+        flat = grid.ravel().copy()
+        free = np.argwhere(grid.reshape([edge] * dim) == 0)
+        a, b = free[3][::-1], free[-3][::-1]
+        for host in (False, True):
+            pl = m.MapPlanner(dim, device=0)
+            pl.useDeviceHeuristic(not host)
+            mu = m.MapUtil(dim)
+            mu.setMap([0.0] * dim, [edge] * dim, flat, 0.1)
+            pl.setMapUtil(mu)
+            pl.setVmax(2.0)
+            pl.setAmax(2.0)
+            pl.setJmax(4.0)
+            pl.setDt(1.0)
+            pl.setU(W.grid_controls(vals, dim))
+            pl.setBatch(64)
+            ok = pl.plan(m.Waypoint(dim, ctrl, pos=(a + 0.5) * 0.1), m.Waypoint(dim, ctrl, pos=(b + 0.5) * 0.1))
+            s, t, tr = pl.summary(), pl.timing(), pl.getTraj()
+            closed = pl.getCloseSet()
+            pl.close()
+            assert ok and s["expansions"] > 100
+            runs[(dim, host)] = (s, t, tr, closed)
+        (s0, t0, tr0, c0), (s1, t1, tr1, c1) = runs[(dim, False)], runs[(dim, True)]
+        assert t0["heur_from_device"] > 0.2 * s0["nodes"] and t1["heur_from_device"] == 0, (t0, t1)
+        for k in ("cost", "expansions", "closed", "opened", "nodes", "segments", "total_time", "J"):
+            assert s0[k] == s1[k], (dim, k, s0[k], s1[k])
+        assert np.array_equal(tr0.actions, tr1.actions) and np.array_equal(tr0.nodes, tr1.nodes) and np.array_equal(c0, c1)

@@ -272,3 +272,112 @@ def test_identity_on_synthetic_hashes(engine, monkeypatch, shape, form):
     for b in (offs, hd, st):
         b.free()
     env.close()
+
+
+# ---------------------------------------------------------------- fused rows (ABI v8: mplx_set_goal + mplx_succ_lists::heur / flags)
+def _fused_vs_pass(engine, wl, route, kernel, tols=(0.6, -1.0, -1.0, -1.0), edges_only=False, monkeypatch=None):
+    """The heur / flags rows the expansion launch writes itself against mplx_post_lists_device on the same lists
+    (which reads hash and state rows back): bit-identical on every emitted successor."""
+    env = engine_env(engine, wl)
+    if route:
+        env.set_lists_route(route)
+    fr = env.upload_frontier(wl.nodes)
+    ref_lists = env.alloc_lists(wl.n_nodes, want_state=True)
+    env.expand_lists_resident(fr, ref_lists)
+    env.synchronize()
+    L = ref_lists.download()
+    idx = _emitted_indices(L)
+    assert idx.size > 200
+    goal = L["state"][:, idx[idx.size // 3]].copy()  # an emitted successor: "same lattice state" and the tolerances fire
+    w, v_max = 10.0, 1.5
+    want = env.post_lists(ref_lists, goal, w=w, v_max=v_max, tol_pos=tols[0], tol_vel=tols[1], tol_acc=tols[2], tol_yaw=tols[3],
+                          want_canon=True)
+    env.set_goal(goal, w=w, v_max=v_max, tol_pos=tols[0], tol_vel=tols[1], tol_acc=tols[2], tol_yaw=tols[3])
+    lists = env.alloc_lists(wl.n_nodes, want_state=not edges_only, want_heur=True, want_flags=True)
+    env.expand_lists_resident(fr, lists)
+    env.synchronize()
+    assert env.last_lists_route() == (route or env.last_lists_route()) and (kernel is None or env.last_grid_kernel() == kernel)
+    G = lists.download()
+    assert np.array_equal(G["count"], L["count"]) and np.array_equal(G["hash"][idx], L["hash"][idx])
+    assert np.array_equal(G["heur"][idx].view(np.uint64), want["heur"][idx].view(np.uint64))
+    assert np.array_equal(G["flags"][idx], want["flags"][idx] & 3)
+    assert (G["flags"][idx] & 1).any() and (G["flags"][idx] & 2).any() and (G["heur"][idx] > 0).any()
+    # node identity on lists WITHOUT state rows: canon as before, bit 2 merged into the row the launch wrote
+    import ctypes as C
+    from motion_primitive_library_amd import _abi
+    canon = engine.env.DeviceArray(env, lists.n_slots * 4)
+    g = _abi.GoalSpec()
+    gr = np.ascontiguousarray(goal)
+    g.goal, g.control, g.w, g.v_max = gr.ctypes.data, wl.control, w, v_max
+    g.tol_pos, g.tol_vel, g.tol_acc, g.tol_yaw = tols
+    o = _abi.Post()
+    o.heur, o.flags, o.canon = None, lists.flags.ptr, canon.ptr
+    s = lists.c_struct()
+    s.state = None
+    _abi.check(env._ctx, _abi.lib().mplx_post_lists_device(env._ctx, C.byref(s), wl.n_nodes, C.byref(g), C.byref(o)))
+    env.synchronize()
+    got_canon = canon.download(np.int32, (lists.n_slots,))
+    got_flags = lists.flags.download(np.uint8, (lists.n_slots,))
+    assert np.array_equal(got_canon[idx], want["canon"][idx])
+    assert np.array_equal(got_flags[idx], want["flags"][idx])
+    canon.free()
+    # without a goal the rows are refused, loudly
+    env.set_goal(None)
+    with pytest.raises(engine._abi.MplxError):
+        env.expand_lists_resident(fr, lists)
+    for b in (lists, ref_lists, fr):
+        b.free()
+    env.close()
+
+
+@pytest.mark.parametrize("dim,control,route,kernel", [(2, 0x03, "grid", "lex"), (3, 0x03, "grid", "lex"), (3, 0x07, "grid", "lex"),
+                                                      (2, 0x01, "grid", "lex"), (3, 0x03, "tile", "none"), (2, 0x07, "tile", "none"),
+                                                      (3, 0x03, "dense", "none"), (2, 0x13, "grid", "grid"), (3, 0x0F, "grid", "grid")])
+def test_fused_heuristic_and_flags_equal_the_stand_alone_pass(engine, dim, control, route, kernel):
+    wl = _small_world(engine, dim, control, seed=6100 + 10 * dim + control, n_nodes=150)
+    wl.nodes[:, 100:150] = wl.nodes[:, 0:50]
+    for tols in ((0.6, -1.0, -1.0, -1.0), (1.0, 1.0, 1.5, 0.6)):
+        _fused_vs_pass(engine, wl, route, kernel, tols=tols)
+
+
+def test_fused_rows_general_kernel_and_edges_only(engine, monkeypatch):
+    """The general factorised kernel on a table the lexicographic one would take (MPLX_GRID_LEX=0), and lists without
+    state rows (what the engine's own search asks for): the rows do not depend on the state rows being stored."""
+    wl = _small_world(engine, 3, 0x03, seed=6500, n_nodes=120)
+    _fused_vs_pass(engine, wl, "grid", "lex", edges_only=True)
+    _fused_vs_pass(engine, wl, "tile", "none", edges_only=True)
+    monkeypatch.setenv("MPLX_GRID_LEX", "0")
+    _fused_vs_pass(engine, wl, "grid", "grid")
+    _fused_vs_pass(engine, wl, "grid", "grid", edges_only=True)
+
+
+def test_fused_rows_through_host_pointers_and_the_service(engine):
+    """mplx_expand_lists on host pointers (the arena / zero-copy path and, from the second call in a row, the resident
+    kernel): the heur / flags rows come back with the lists; a new goal reaches a resident kernel too."""
+    import ctypes as C
+    from motion_primitive_library_amd import _abi
+    wl = engine.workloads.make("C4", scale=0.125, n_nodes=48)
+    env = engine_env(engine, wl)
+    L = _abi.lib()
+    nU, n = wl.U.shape[0], wl.n_nodes
+    S = (nU + 31) & ~31
+    ref = env.expand_lists(wl.nodes, want_state=True, want_iters=False, stride=S)
+    idx = _emitted_indices(ref)
+    for trial, gi in enumerate((idx[10], idx[idx.size // 2], idx[-5])):
+        goal = np.ascontiguousarray(ref["state"][:, gi])
+        env.set_goal(goal, w=10.0, v_max=2.0, tol_pos=0.5)
+        cnt = np.zeros(n, np.int32)
+        act, cost, hsh = np.zeros(n * S, np.int32), np.zeros(n * S), np.zeros(n * S, np.uint64)
+        heur, flags = np.full(n * S, -1.0), np.zeros(n * S, np.uint8)
+        o = _abi.SuccLists()
+        o.count, o.action, o.cost, o.hash = cnt.ctypes.data, act.ctypes.data, cost.ctypes.data, hsh.ctypes.data
+        o.heur, o.flags, o.node_stride = heur.ctypes.data, flags.ctypes.data, S
+        nodes = np.ascontiguousarray(wl.nodes)
+        for rep in range(3):  # the third call of a row is served by the resident kernel
+            _abi.check(env._ctx, L.mplx_expand_lists(env._ctx, nodes.ctypes.data, n, n, C.byref(o)))
+        d = np.abs(ref["state"][:3, idx] - goal[:3, None]).max(axis=0)
+        same = ref["hash"][idx] == ref["hash"][gi]
+        assert np.array_equal(cnt, ref["count"]) and np.array_equal(hsh[idx], ref["hash"][idx])
+        assert np.array_equal(heur[idx], np.where(same, 0.0, 10.0 * d / 2.0)), trial
+        assert np.array_equal(flags[idx] & 1, (d <= 0.5).astype(np.uint8)) and np.array_equal((flags[idx] & 2) != 0, same)
+    env.close()
