@@ -542,12 +542,54 @@ def extras(m, args, wl, out):
                 post[label] = post_identity(m, env, wl, lists)
         except Exception as e:  # noqa: BLE001 -- never lose the leg to the optional measurement
             post = {"error": "%s: %s" % (type(e).__name__, e)}
+        # ---- the same work FUSED into the expansion launch (ABI v8: mplx_set_goal + the heur / flags rows of the lists):
+        # lists-only against lists + heur + flags on the same allocation, and the identity pass on lists whose flags
+        # row the launch wrote (no second pass over hash and position rows)
+        fused = {}
+        try:
+            import ctypes as C
+            from motion_primitive_library_amd import _abi
+            ns = lists.n_slots
+            hb, fb, cb = m.env.DeviceArray(env, ns * 8), m.env.DeviceArray(env, ns), m.env.DeviceArray(env, ns * 4)
+            goal = np.ascontiguousarray(wl.nodes[:, 0], dtype=np.float64)
+            env.set_goal(goal, w=10.0, v_max=2.0, tol_pos=0.5)
+            for label, fr_x in (("random", fr_r), ("wavefront", fr_w)):
+                lists.heur = lists.flags = None
+                plain = sorted(time_lists(env, fr_x, lists, args.steps, 2) for _ in range(3))[1]
+                lists.heur, lists.flags = hb, fb
+                both = sorted(time_lists(env, fr_x, lists, args.steps, 2) for _ in range(3))[1]
+                g = _abi.GoalSpec()
+                g.goal, g.control, g.w, g.v_max = goal.ctypes.data, wl.control, 10.0, 2.0
+                g.tol_pos, g.tol_vel, g.tol_acc, g.tol_yaw = 0.5, -1.0, -1.0, -1.0
+                o = _abi.Post()
+                o.heur, o.flags, o.canon = None, fb.ptr, cb.ptr
+                st = lists.c_struct()
+                st.state = None  # the identity pass alone: canon + bit 2 of the flags row the launch wrote
+                loops = []
+                for _ in range(3):
+                    env.expand_lists_resident(fr_x, lists)  # (bit 2 is OR-ed in: a fresh row per measurement)
+                    env.synchronize()
+                    env.timer_begin()
+                    _abi.check(env._ctx, _abi.lib().mplx_post_lists_device(env._ctx, C.byref(st), wl.n_nodes, C.byref(g), C.byref(o)))
+                    loops.append(env.timer_end())
+                fused[label] = {"lists_only_ms": plain, "lists_heur_flags_ms": both, "ratio": both / plain,
+                                "identity_only_ms": sorted(loops)[1], "identity_form": env.last_identity_form()}
+            lists.heur = lists.flags = None
+            env.set_goal(None)
+            for b_ in (hb, fb, cb):
+                b_.free()
+            fused["what"] = ("lists_heur_flags_ms: the expansion launch writing heuristic (8 B) and goal flags (1 B) per successor "
+                             "itself, against lists_only_ms on the same allocation; identity_only_ms: mplx_post_lists_device for "
+                             "canon + the first-occurrence bit on those lists (no post_lists_kernel pass over hash and state rows). "
+                             "Compare lists_heur_flags_ms + identity_only_ms with kernel_ms + post.*.with_identity_ms")
+        except Exception as e:  # noqa: BLE001
+            fused = {"error": "%s: %s" % (type(e).__name__, e)}
         lists.free()
         fr_w.free()
         fr_r.free()
         env.close()
         b_alg = algorithmic_bytes(wl, wl.n_nodes, n_emit, n_samples)
-        return {"kernel_ms": ms_w, "post": post, "value": wl.n_pairs / (ms_w * 1e-3), "random_frontier_same_allocation_ms": ms_r,
+        return {"kernel_ms": ms_w, "post": post, "post_fused": fused, "value": wl.n_pairs / (ms_w * 1e-3), "random_frontier_same_allocation_ms": ms_r,
                 "ratio_to_random": ms_w / ms_r, "kernel_ms_cold": cold, "rounds_ms": [[round(a, 4), round(b, 4)] for a, b in rounds],
                 "algorithmic_bytes_per_launch": b_alg, "achieved_GBps": b_alg / (ms_w * 1e-3) / 1e9,
                 "frac": b_alg / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, "pairs": wl.n_pairs, "emitted": n_emit, "finite": n_fin,

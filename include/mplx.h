@@ -486,6 +486,32 @@ typedef struct {
                                row of mplx_succ_lists) instead of being evaluated by the search                     */
 } mplx_plan_timing;
 int mplx_planner_timing(const mplx_planner *p, mplx_plan_timing *out);
+
+/* ---- ABI v8: Lifelong Planning A* (PlannerBase::setLPAstar, planner_base.h:170-176; GraphSearch::LPAstar,
+ *      graph_search.h:194-365; StateSpace::updateNode / increaseCost / decreaseCost / getSubStateSpace,
+ *      state_space.h:116-281) in the engine's own planner.  With it on, the state space outlives mplx_planner_plan:
+ *      a map edit is translated into edge-cost changes through the voxel -> edge table and the next plan repairs
+ *      only what became inconsistent.  The caller edits its map, hands the new cells to mplx_planner_set_map (and to
+ *      the context: mplx_set_map), then names the edited cells:                                                     */
+int mplx_planner_set_lpastar(mplx_planner *p, int on);          /* PlannerBase::setLPAstar                        */
+int mplx_planner_reset(mplx_planner *p);                        /* PlannerBase::reset: forget the state space     */
+/* MapPlanner::getLinkedNodes (map_planner.cpp:125-157): (re)builds the voxel -> edge table from every stored edge --
+ * ONE mplx_check_edges call for all of them -- and returns the linked points (cell centres, D doubles each; up to
+ * cap_points are written, *n_points receives their number), the number of cells and of (cell, edge) entries.       */
+int mplx_planner_linked_nodes(mplx_planner *p, double *points, int64_t cap_points, int64_t *n_points, int64_t *n_cells,
+                              int64_t *n_entries);
+/* MapPlanner::updateBlockedNodes / updateClearedNodes (map_planner.cpp:160-185): cells = [n][D] integer cell
+ * coordinates that became occupied / free.  Cleared: is_free + intrinsic cost of all affected blocked edges in one
+ * mplx_check_edges call against the context's CURRENT map (set it first).                                          */
+int mplx_planner_update_blocked_nodes(mplx_planner *p, const int32_t *cells, int64_t n);
+int mplx_planner_update_cleared_nodes(mplx_planner *p, const int32_t *cells, int64_t n);
+/* StateSpace::getSubStateSpace (state_space.h:116-195): re-root the search tree at way point `time_step` of the last
+ * trajectory (a robot that has executed that many primitives).                                                     */
+int mplx_planner_sub_state_space(mplx_planner *p, int32_t time_step);
+/* Another implementation of the batched edge re-validation (tests: the CPU oracle), shape of mplx_check_edges.     */
+typedef int (*mplx_edges_fn)(void *user, const double *parents, const int32_t *actions, int64_t n_edges, uint8_t *free_flag,
+                             double *cost, int32_t *cells, int32_t *cell_count, int32_t cell_cap);
+int mplx_planner_set_edge_provider(mplx_planner *p, mplx_edges_fn fn, void *user);
 /* ABI v8.  on != 0: the plans of this planner call mplx_set_goal on the attached context and take the heuristic of new
  * nodes from the `heur` row the expansion launches write (SURVEY.md 8f-2 with its consumer); 0 (the default): the search
  * evaluates it itself from the successor's position.  Same search bit for bit either way (tests/test_gpu_plan.py); on

@@ -2,6 +2,7 @@
 // "host search" section) on top of host_planner.hpp.
 #include "../../include/mplx.h"
 #include "host_planner.hpp"
+#include "host_lpastar.hpp"
 #include "mplx_ctx.h"
 
 #include <new>
@@ -9,6 +10,9 @@
 
 struct mplx_planner {
   mplx::host::Planner pl;
+  mplx::host::LpaPlanner lpa;  // PlannerBase::setLPAstar(true): the state space that outlives plan()
+  bool use_lpa = false;
+  const mplx::host::PlanResult &result() const { return use_lpa ? lpa.last : pl.last; }
   mplx_ctx *ctx = nullptr;
   bool device_heur = false;  // the expansion launches deliver the default heuristic of every successor (mplx_set_goal)
   bool want_device_heur = getenv("MPLX_PLAN_DEVICE_HEUR") != nullptr && atoi(getenv("MPLX_PLAN_DEVICE_HEUR")) != 0;
@@ -60,6 +64,18 @@ int engine_packed(void *user, const double *nodes, int64_t n, mplx::host::Packed
   return 0;
 }
 
+int engine_edges(void *user, const double *parents, const int32_t *actions, int64_t n, uint8_t *free_flag, double *cost,
+                 int32_t *cells, int32_t *cell_count, int32_t cell_cap) {
+  mplx_planner *p = (mplx_planner *)user;
+  mplx_edges_out o{};
+  o.free_flag = free_flag;
+  o.cost = cost;
+  o.cells = cells;
+  o.cell_count = cell_count;
+  o.cell_cap = cell_cap;
+  return mplx_check_edges(p->ctx, parents, actions, n, n, &o);
+}
+
 int fail(mplx_planner *p, int code, const char *msg) {
   if (p) p->err = msg;
   return code;
@@ -75,6 +91,7 @@ int mplx_planner_create(int dim, mplx_planner **out) {
   if (!p) return MPLX_ERR_ARG;
   p->pl.dim = dim;
   p->pl.grid.dim = dim;
+  p->lpa.cfg = &p->pl;
   *out = p;
   return MPLX_OK;
 }
@@ -97,6 +114,8 @@ int mplx_planner_attach_ctx(mplx_planner *p, mplx_ctx *ctx) {
   p->pl.check_states = getenv("MPLX_PLAN_CHECK_STATES") != nullptr;
   p->pl.check_perturb = getenv("MPLX_PLAN_CHECK_PERTURB") ? atoi(getenv("MPLX_PLAN_CHECK_PERTURB")) : -1;
   p->pl.user = p;
+  p->lpa.edges = engine_edges;
+  p->lpa.edges_user = p;
   return MPLX_OK;
 }
 
@@ -176,7 +195,7 @@ int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, 
   }
   int rc;
   try {
-    rc = p->pl.plan(start, goal);
+    rc = p->use_lpa ? p->lpa.plan(start, goal) : p->pl.plan(start, goal);
   } catch (const std::exception &e) {  // no exception crosses the C ABI
     p->err = std::string("mplx_planner_plan: ") + e.what();
     return MPLX_ERR_NOMEM;
@@ -192,7 +211,7 @@ int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, 
     if (p->ctx) p->err += std::string(": ") + mplx_last_error(p->ctx);
     return rc < 0 ? rc : MPLX_ERR_HIP;
   }
-  const mplx::host::PlanResult &r = p->pl.last;
+  const mplx::host::PlanResult &r = p->result();
   out->ok = r.ok ? 1 : 0;
   out->expansions = r.expansions;
   out->closed = r.closed;
@@ -216,7 +235,7 @@ int mplx_planner_use_device_heuristic(mplx_planner *p, int on) {
 
 int mplx_planner_timing(const mplx_planner *p, mplx_plan_timing *out) {
   if (!p || !out) return MPLX_ERR_ARG;
-  const mplx::host::PlanResult &r = p->pl.last;
+  const mplx::host::PlanResult &r = p->result();
   out->total_ms = r.t_total;
   out->provider_ms = r.t_provider;
   out->fill_ms = r.t_fill;
@@ -233,7 +252,7 @@ int mplx_planner_timing(const mplx_planner *p, mplx_plan_timing *out) {
 
 int mplx_planner_trajectory(mplx_planner *p, double *nodes, int32_t *actions, int32_t cap) {
   if (!p || !nodes || !actions) return MPLX_ERR_ARG;
-  const mplx::host::PlanResult &r = p->pl.last;
+  const mplx::host::PlanResult &r = p->result();
   const int f = p->pl.F();
   const int32_t n = (int32_t)r.traj_actions.size();
   if (cap < n) return fail(p, MPLX_ERR_ARG, "mplx_planner_trajectory: capacity too small");
@@ -246,7 +265,7 @@ int mplx_planner_trajectory(mplx_planner *p, double *nodes, int32_t *actions, in
 
 int mplx_planner_trajectory_end(mplx_planner *p, double *node) {
   if (!p || !node) return MPLX_ERR_ARG;
-  const mplx::host::PlanResult &r = p->pl.last;
+  const mplx::host::PlanResult &r = p->result();
   if (!r.ok || (int)r.traj_end.size() != p->pl.F()) return fail(p, MPLX_ERR_STATE, "mplx_planner_trajectory_end: no trajectory");
   for (int k = 0; k < p->pl.F(); k++) node[k] = r.traj_end[(size_t)k];
   return MPLX_OK;
@@ -259,15 +278,80 @@ int mplx_selftest_forward_state(int32_t dim, int32_t control, const double *node
   return MPLX_OK;
 }
 
+int mplx_planner_set_lpastar(mplx_planner *p, int on) {
+  if (!p) return MPLX_ERR_ARG;
+  p->use_lpa = on != 0;
+  return MPLX_OK;
+}
+
+int mplx_planner_reset(mplx_planner *p) {
+  if (!p) return MPLX_ERR_ARG;
+  p->lpa.reset();
+  return MPLX_OK;
+}
+
+int mplx_planner_set_edge_provider(mplx_planner *p, mplx_edges_fn fn, void *user) {
+  if (!p || !fn) return MPLX_ERR_ARG;
+  p->lpa.edges = fn;
+  p->lpa.edges_user = user;
+  return MPLX_OK;
+}
+
+// LPA* bookkeeping calls: same error discipline as plan() (nothing throws across the ABI; the resident kernel of a
+// search leaves before another call synchronises the device)
+#define MPLX_LPA_CALL(expr, what)                                                                   \
+  if (!p) return MPLX_ERR_ARG;                                                                      \
+  if (!p->use_lpa) return fail(p, MPLX_ERR_STATE, what ": mplx_planner_set_lpastar(p, 1) first");   \
+  if (p->ctx) (void)mplx_detail::svc_stop(p->ctx);                                                  \
+  int rc;                                                                                           \
+  try { rc = (expr); } catch (...) { return fail(p, MPLX_ERR_NOMEM, what ": out of host memory"); } \
+  if (rc != 0) {                                                                                    \
+    p->err = what " failed";                                                                        \
+    if (p->ctx) p->err += std::string(": ") + mplx_last_error(p->ctx);                              \
+    return rc < 0 ? rc : MPLX_ERR_HIP;                                                              \
+  }
+
+int mplx_planner_linked_nodes(mplx_planner *p, double *points, int64_t cap_points, int64_t *n_points, int64_t *n_cells,
+                              int64_t *n_entries) {
+  std::vector<double> pts;
+  int64_t np = 0;
+  MPLX_LPA_CALL(p->lpa.linked_nodes(points ? &pts : nullptr, &np), "mplx_planner_linked_nodes")
+  if (points) {
+    const int64_t m = np < cap_points ? np : cap_points;
+    for (int64_t i = 0; i < m * p->pl.dim; i++) points[i] = pts[(size_t)i];
+  }
+  if (n_points) *n_points = np;
+  if (n_cells) *n_cells = (int64_t)p->lpa.linked_cells();
+  if (n_entries) *n_entries = p->lpa.linked_entries();
+  return MPLX_OK;
+}
+
+int mplx_planner_update_blocked_nodes(mplx_planner *p, const int32_t *cells, int64_t n) {
+  if (p && (n < 0 || (n > 0 && !cells))) return fail(p, MPLX_ERR_ARG, "mplx_planner_update_blocked_nodes: bad arguments");
+  MPLX_LPA_CALL(p->lpa.update_blocked(cells, n), "mplx_planner_update_blocked_nodes")
+  return MPLX_OK;
+}
+
+int mplx_planner_update_cleared_nodes(mplx_planner *p, const int32_t *cells, int64_t n) {
+  if (p && (n < 0 || (n > 0 && !cells))) return fail(p, MPLX_ERR_ARG, "mplx_planner_update_cleared_nodes: bad arguments");
+  MPLX_LPA_CALL(p->lpa.update_cleared(cells, n), "mplx_planner_update_cleared_nodes")
+  return MPLX_OK;
+}
+
+int mplx_planner_sub_state_space(mplx_planner *p, int32_t time_step) {
+  MPLX_LPA_CALL(p->lpa.sub_state_space(time_step), "mplx_planner_sub_state_space")
+  return MPLX_OK;
+}
+
 int mplx_planner_closed_set(mplx_planner *p, double *pos, int32_t cap, int32_t *n) {
   if (!p || !n) return MPLX_ERR_ARG;
-  *n = p->pl.closed_positions(pos, cap);
+  *n = p->use_lpa ? p->lpa.closed_positions(pos, cap) : p->pl.closed_positions(pos, cap);
   return MPLX_OK;
 }
 
 int mplx_planner_open_set(mplx_planner *p, double *states, int32_t cap, int32_t *n) {
   if (!p || !n) return MPLX_ERR_ARG;
-  *n = p->pl.open_states(states, cap);  // the heap, as planner_base.h:77-81 walks it
+  *n = p->use_lpa ? p->lpa.open_states(states, cap) : p->pl.open_states(states, cap);  // the heap, as planner_base.h:77-81 walks it
   return MPLX_OK;
 }
 

@@ -203,6 +203,57 @@ class MapPlanner:
                                            "pairs", "cost", "total_time", "segments")} | {
             "J": list(o.J), "state_mismatches": o.state_mismatches}
 
+    # ---- incremental re-planning (PlannerBase::setLPAstar, MapPlanner::getLinkedNodes / updateBlockedNodes /
+    #      updateClearedNodes, StateSpace::getSubStateSpace): the state space outlives plan()
+    def setLPAstar(self, on=True):
+        self._check(self._L.mplx_planner_set_lpastar(self._p, 1 if on else 0))
+
+    def reset(self):
+        self._check(self._L.mplx_planner_reset(self._p))
+
+    def getLinkedNodes(self, want_points=True):
+        """(Re)builds the voxel -> edge table; returns (points [n][D] or None, number of cells, number of entries)."""
+        n, cells, entries = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._L.mplx_planner_linked_nodes(self._p, None, 0, C.byref(n), C.byref(cells), C.byref(entries)))
+        pts = None
+        if want_points:
+            pts = np.empty((max(n.value, 1), self.dim), dtype=np.float64)
+            self._check(self._L.mplx_planner_linked_nodes(self._p, pts.ctypes.data, n.value, C.byref(n), C.byref(cells), C.byref(entries)))
+            pts = pts[:n.value]
+        return pts, cells.value, entries.value
+
+    def _edit_map(self, cells, value):
+        """The caller's side of a map edit (the reference's test edits its MapUtil and calls setMap): the planner's host
+        copy and the device map get the new cells."""
+        mu = self._map_util
+        cells = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, self.dim)
+        idx = cells[:, 0].astype(np.int64)
+        mul = 1
+        for i in range(1, self.dim):
+            mul *= mu.map_dim[i - 1]
+            idx = idx + mul * cells[:, i]
+        mu.cells = mu.cells.copy()
+        mu.cells[idx] = value
+        self.setMapUtil(mu)
+        return cells
+
+    def updateBlockedNodes(self, cells, edit_map=True):
+        cells = self._edit_map(cells, 100) if edit_map else np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, self.dim)
+        self._check(self._L.mplx_planner_update_blocked_nodes(self._p, cells.ctypes.data, cells.shape[0]))
+
+    def updateClearedNodes(self, cells, edit_map=True):
+        cells = self._edit_map(cells, 0) if edit_map else np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, self.dim)
+        if self.env is not None:
+            self.env._flush()
+        self._check(self._L.mplx_planner_update_cleared_nodes(self._p, cells.ctypes.data, cells.shape[0]))
+
+    def getSubStateSpace(self, time_step):
+        self._check(self._L.mplx_planner_sub_state_space(self._p, int(time_step)))
+
+    def setEdgeProvider(self, fn_ptr, user_ptr):
+        """Tests: another implementation of the batched edge re-validation (the CPU oracle's)."""
+        self._check(self._L.mplx_planner_set_edge_provider(self._p, fn_ptr, user_ptr))
+
     def useDeviceHeuristic(self, on=True):
         """The heuristic of new nodes from the `heur` row the expansion launches write (mplx_set_goal) instead of the
         search's own evaluation: same search, see mplx_planner_use_device_heuristic."""

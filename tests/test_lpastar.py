@@ -119,3 +119,163 @@ def test_device_failure_through_a_base_class_pointer_is_still_latched(engine):
                                                    C.byref(dev_ok), err, 512) == 0
         assert bool(ok.value) == want_ok and bool(dev_ok.value) == want_ok
         assert (err.value == b"") == want_ok, err.value
+
+
+# ---------------------------------------------------------------- the engine's own LPA* (csrc/host_lpastar.hpp, mplx_planner_*)
+def _engine_lpastar_scenario(m, oenv, s_row, g_row, box, provider=None, batch=1):
+    """The scenario of oracle/ref_planner_shim.cpp::run_lpastar on the engine's planner: plan, getLinkedNodes, block a box
+    of free cells around the middle of the trajectory + updateBlockedNodes, plan, getLinkedNodes, clear + updateClearedNodes,
+    plan.  provider: (single, batched, user, edges_fn) of another env implementation (CPU: the oracle); None: the MI355X."""
+    D = oenv.dim
+    cells = oenv.map  # (the very array the oracle env points at: edits must reach it)
+    pl = m.MapPlanner(D, provider=provider[:3] if provider else None)
+    mu = m.MapUtil(D)
+    mu.setMap(oenv.origin[:D], oenv.map_dim[:D], cells, oenv.res)
+    mu.cells = cells  # (no copy: a CPU provider's env reads this array)
+    pl.setMapUtil(mu)
+    pl.setVmax(oenv.v_max)
+    pl.setAmax(oenv.a_max)
+    pl.setDt(oenv.dt)
+    pl.setU(oenv.U)
+    pl.setBatch(batch)
+    pl.setLPAstar(True)
+    if provider:
+        pl.setEdgeProvider(provider[3], provider[2])
+    start, goal = m.Waypoint.from_row(D, m.ACC, s_row), m.Waypoint.from_row(D, m.ACC, g_row)
+    plans = []
+
+    def record(ok):
+        s = pl.summary()
+        tr = pl.getTraj()
+        plans.append({"ok": ok, "closed": s["closed"], "opened": s["opened"], "expansions": s["expansions"], "cost": s["cost"],
+                      "segments": s["segments"], "total_time": s["total_time"], "J": s["J"], "launches": s["device_launches"],
+                      "wps": tr.getWaypoints() if ok else None})
+
+    record(pl.plan(start, goal))
+    pts, n_cells, n_entries = pl.getLinkedNodes()
+    table = {"cells": n_cells, "entries": n_entries, "linked_points": len(pts)}
+    # the box, as the shim picks it
+    wps = plans[0]["wps"]
+    res, org, dims = oenv.res, np.array(oenv.origin[:D]), np.array(oenv.map_dim[:D])
+    c_round = lambda x: int(np.sign(x) * np.floor(abs(x) + 0.5))  # C round(): halves away from zero (numpy rounds them to even)
+    to_cell = lambda p: np.array([c_round((p[i] - org[i]) / res - 0.5) for i in range(D)])  # MapUtil::floatToInt
+    mid, sc, gc = to_cell(wps[len(wps) // 2][:D]), to_cell(s_row[:D]), to_cell(g_row[:D])
+    w = 2 * box + 1
+    edit = []
+    for q in range(w ** D):
+        r, pn = q, []
+        for i in range(D):
+            pn.append(mid[i] + (r % w) - box)
+            r //= w
+        pn = np.array(pn)
+        if np.any(pn < 0) or np.any(pn >= dims):
+            continue
+        idx = int(pn[0] + dims[0] * (pn[1] + (dims[1] * pn[2] if D == 3 else 0)))
+        if not (0 <= cells[idx] < 100):
+            continue
+        if np.all(np.abs(pn - sc) <= 2) or np.all(np.abs(pn - gc) <= 2):
+            continue
+        edit.append((pn, idx))
+    table["edited_cells"] = len(edit)
+    ecells = np.array([e[0] for e in edit], dtype=np.int32)
+    eidx = np.array([e[1] for e in edit], dtype=np.int64)
+    cells[eidx] = 100
+    pl.setMapUtil(mu)
+    pl.updateBlockedNodes(ecells, edit_map=False)
+    record(pl.plan(start, goal))
+    pl.getLinkedNodes(want_points=False)
+    cells[eidx] = 0
+    pl.setMapUtil(mu)
+    pl.updateClearedNodes(ecells, edit_map=False)
+    record(pl.plan(start, goal))
+    pl.close()
+    return plans, table
+
+
+def _oracle_provider(oenv):
+    lib = O.load()
+    ce = oenv._c()
+    user = C.cast(C.pointer(ce), C.c_void_p)
+    return (C.cast(lib.mpl_oracle_get_succ, C.c_void_p), C.cast(lib.mpl_oracle_batch, C.c_void_p), user,
+            C.cast(lib.mpl_oracle_check_edges, C.c_void_p)), ce
+
+
+@needs_ref
+@pytest.mark.parametrize("which", ["corridor", "voxel"])
+@pytest.mark.parametrize("batch", [1, 16])
+def test_engine_lpastar_equals_the_reference_on_the_cpu(engine, which, batch):
+    """The engine's LPA* (csrc/host_lpastar.hpp) with the CPU oracle as get_succ and as edge checker: the three plans of the
+    scenario and the voxel -> edge table against the reference's own LPA* (oracle/_ref)."""
+    oenv, s, g = (corridor_problem if which == "corridor" else voxel_problem)(engine)
+    oenv.map = oenv.map.copy()  # (edited in place by the scenario)
+    box = PINS[which][2]
+    ref_plans, ref_table = O.ref_lpastar(oenv, s, g, use_gpu=False, box_half=box)
+    prov, keep = _oracle_provider(oenv)
+    plans, table = _engine_lpastar_scenario(engine, oenv, s, g, box, provider=prov, batch=batch)
+    del keep
+    for k in ("cells", "entries", "linked_points", "edited_cells"):
+        assert table[k] == ref_table[k], (k, table[k], ref_table[k])
+    for i, (a, b) in enumerate(zip(plans, ref_plans)):
+        for k in ("ok", "closed", "opened", "expansions", "cost"):
+            assert a[k] == b[k], (which, "plan %d" % i, k, a[k], b[k])
+        if a["ok"]:
+            for k in ("segments", "total_time", "J"):
+                assert a[k] == b[k], (which, i, k)
+    assert [(p["closed"], p["expansions"], p["ok"], p["cost"]) for p in plans] == PINS[which][0]
+    if batch > 1:
+        assert plans[0]["launches"] < plans[0]["expansions"] / 3
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["corridor", "voxel"])
+def test_engine_lpastar_on_the_device_equals_the_reference(engine, which):
+    """The same scenario with get_succ and the edge work on the MI355X (mplx_planner_* with an attached context)."""
+    oenv, s, g = (corridor_problem if which == "corridor" else voxel_problem)(engine)
+    oenv.map = oenv.map.copy()  # (edited in place by the scenario)
+    box = PINS[which][2]
+    ref_plans, ref_table = O.ref_lpastar(oenv, s, g, use_gpu=False, box_half=box)
+    plans, table = _engine_lpastar_scenario(engine, oenv, s, g, box, provider=None, batch=16)
+    for k in ("cells", "entries", "linked_points", "edited_cells"):
+        assert table[k] == ref_table[k], (k, table[k], ref_table[k])
+    for i, (a, b) in enumerate(zip(plans, ref_plans)):
+        for k in ("ok", "closed", "opened", "expansions", "cost"):
+            assert a[k] == b[k], (which, "plan %d" % i, k, a[k], b[k])
+
+
+@pytest.mark.parametrize("which", ["corridor", "voxel"])
+def test_engine_lpastar_sub_state_space_re_roots_the_tree(engine, which):
+    """StateSpace::getSubStateSpace (state_space.h:116-195) through mplx_planner_sub_state_space: after the robot has
+    executed k primitives of the plan, the tree is re-rooted at way point k and the next plan from there costs what was
+    left of the first one -- found by repairing the kept tree, not by a search from scratch."""
+    m = engine
+    oenv, s, g = (corridor_problem if which == "corridor" else voxel_problem)(m)
+    prov, keep = _oracle_provider(oenv)
+    D = oenv.dim
+    pl = m.MapPlanner(D, provider=prov[:3])
+    mu = m.MapUtil(D)
+    mu.setMap(oenv.origin[:D], oenv.map_dim[:D], oenv.map, oenv.res)
+    pl.setMapUtil(mu)
+    pl.setVmax(oenv.v_max)
+    pl.setAmax(oenv.a_max)
+    pl.setDt(oenv.dt)
+    pl.setU(oenv.U)
+    pl.setLPAstar(True)
+    pl.setEdgeProvider(prov[3], prov[2])
+    assert pl.plan(m.Waypoint.from_row(D, m.ACC, s), m.Waypoint.from_row(D, m.ACC, g))
+    first = pl.summary()
+    tr = pl.getTraj()
+    wps = tr.getWaypoints()
+    k = 2
+    # cost of the first k primitives: w * dt + J(ACC) each
+    U = oenv.U
+    spent = sum(oenv.w * oenv.dt + float((U[a] ** 2).sum()) * oenv.dt for a in tr.actions[:k])
+    pl.getSubStateSpace(k)
+    assert pl.plan(m.Waypoint.from_row(D, m.ACC, wps[k]), m.Waypoint.from_row(D, m.ACC, g))
+    second = pl.summary()
+    tr2 = pl.getTraj()
+    pl.close()
+    del keep
+    assert abs(second["cost"] - (first["cost"] - spent)) <= 1e-9 * first["cost"]
+    assert second["segments"] == first["segments"] - k and np.array_equal(tr2.actions, tr.actions[k:])
+    assert second["expansions"] < first["expansions"] / 4  # repaired, not searched again
