@@ -473,6 +473,98 @@ def extra_plan(m):
                                                                 (best["wall_ms"] + best["potential_map_ms"]))
         return d
 
+    def replan_3d(edge):
+        """Incremental re-planning (LPA*, PlannerBase::setLPAstar): plan, MapPlanner::getLinkedNodes, a box of cells on the
+        trajectory becomes occupied + updateBlockedNodes, plan, the box is cleared + updateClearedNodes, plan
+        (map_planner.cpp:125-185; the scenario of tests/test_lpastar.py on a larger voxel map) -- the reference's LPA* on
+        one host core, the same with the drop-in adapter, and the engine's own LPA* (csrc/host_lpastar.hpp)."""
+        res = 0.1
+        flat = W.box_map([edge] * 3, res, 0.05, 78, side_m=(0.3, 0.8)).ravel().copy()
+        U3 = W.grid_controls([-1.0, 0.0, 1.0], 3)
+
+        def free_near(p):
+            cc = np.array([int(x / res) for x in p])
+            for r in range(0, 12):
+                for d in np.ndindex(2 * r + 1, 2 * r + 1, 2 * r + 1):
+                    q = cc + np.array(d) - r
+                    if np.all(q >= 0) and np.all(q < edge) and flat[q[0] + edge * (q[1] + edge * q[2])] == 0:
+                        return [(q[i] + 0.5) * res for i in range(3)]
+            raise RuntimeError("no free cell")
+
+        s3 = m.Waypoint(3, m.ACC, pos=free_near([0.5, 0.5, 0.5]))
+        g3 = m.Waypoint(3, m.ACC, pos=free_near([edge * res - 1.0, edge * res - 1.4, edge * res - 1.8]))
+        box = 3
+        rp = {"problem": "3D %d^3 voxels, ACC, |U| = 27, v_max 1: LPA* with a %d^3-cell box blocked on the trajectory, then cleared" % (edge, 2 * box + 1)}
+        # ---- the engine's own LPA*
+        pl = m.MapPlanner(3, device=0)
+        mu = m.MapUtil(3)
+        mu.setMap([0.0] * 3, [edge] * 3, flat.copy(), res)
+        pl.setMapUtil(mu)
+        pl.setVmax(1.0)
+        pl.setAmax(1.0)
+        pl.setDt(1.0)
+        pl.setU(U3)
+        pl.setBatch(16)
+        pl.setLPAstar(True)
+        plans, t_ms = [], {}
+
+        def timed(name, fn):
+            t0 = time.perf_counter()
+            r = fn()
+            t_ms[name] = (time.perf_counter() - t0) * 1e3
+            return r
+
+        def rec(ok):
+            s_ = pl.summary()
+            plans.append({"ok": bool(ok), "cost": s_["cost"], "expansions": s_["expansions"], "closed": s_["closed"]})
+
+        rec(timed("plan1_ms", lambda: pl.plan(s3, g3)))
+        wps = pl.getTraj().getWaypoints()
+        _, n_cells, n_entries = timed("linked_nodes_ms", lambda: pl.getLinkedNodes())
+        c_round = lambda x: int(np.sign(x) * np.floor(abs(x) + 0.5))
+        to_cell = lambda p: np.array([c_round(p[i] / res - 0.5) for i in range(3)])
+        mid, sc, gc = to_cell(wps[len(wps) // 2][:3]), to_cell(s3.pos), to_cell(g3.pos)
+        edit = []
+        w_ = 2 * box + 1
+        for q in range(w_ ** 3):
+            r_, pn = q, []
+            for i in range(3):
+                pn.append(mid[i] + (r_ % w_) - box)
+                r_ //= w_
+            pn = np.array(pn)
+            if np.any(pn < 0) or np.any(pn >= edge) or flat[pn[0] + edge * (pn[1] + edge * pn[2])] != 0:
+                continue
+            if np.all(np.abs(pn - sc) <= 2) or np.all(np.abs(pn - gc) <= 2):
+                continue
+            edit.append(pn)
+        edit = np.array(edit, dtype=np.int32)
+        timed("update_blocked_ms", lambda: pl.updateBlockedNodes(edit))
+        rec(timed("plan2_ms", lambda: pl.plan(s3, g3)))
+        pl.getLinkedNodes(want_points=False)
+        timed("update_cleared_ms", lambda: pl.updateClearedNodes(edit))
+        rec(timed("plan3_ms", lambda: pl.plan(s3, g3)))
+        pl.close()
+        rp["engine_lpastar"] = dict({k: round(v, 3) for k, v in t_ms.items()}, plans=plans, table_cells=n_cells, table_entries=n_entries,
+                                    edited_cells=int(edit.shape[0]))
+        if have_ref:
+            oenv = O.Env(3, O.ACC, U3, flat, [edge] * 3, [0.0] * 3, res, v_max=1.0, a_max=1.0, dt=1.0)
+            for label, gpu in (("reference_cpu", False), ("reference_planner_gpu_adapter", True)):
+                rp_, tb = O.ref_lpastar(oenv, s3.to_row(), g3.to_row(), use_gpu=gpu, box_half=box)
+                rp[label] = {"plan1_ms": rp_[0]["wall_ms"], "plan2_ms": rp_[1]["wall_ms"], "plan3_ms": rp_[2]["wall_ms"],
+                             "linked_nodes_ms": tb["get_linked_nodes_us"] / 1e3, "update_cleared_ms": tb["update_cleared_us"] / 1e3,
+                             "plans": [{"ok": p_["ok"], "cost": p_["cost"], "expansions": p_["expansions"], "closed": p_["closed"]} for p_ in rp_],
+                             "table_cells": tb["cells"], "table_entries": tb["entries"], "edited_cells": tb["edited_cells"]}
+            ref = rp["reference_cpu"]
+            rp["agree"] = bool(all(a == b for a, b in zip(plans, ref["plans"])) and n_cells == ref["table_cells"] and n_entries == ref["table_entries"])
+            tot = lambda d: d["plan2_ms"] + d["plan3_ms"] + d["linked_nodes_ms"] + d["update_cleared_ms"]
+            rp["speedup_replan_engine_vs_reference_cpu"] = tot(ref) / tot(rp["engine_lpastar"])
+            rp["what"] = "speedup_replan_*: (second + third plan + getLinkedNodes + updateClearedNodes) of the reference on one host core over the engine's"
+        return rp
+
+    try:
+        out["replan_3D"] = replan_3d(64)
+    except Exception as e:  # noqa: BLE001
+        out["replan_3D"] = {"error": "%s: %s" % (type(e).__name__, e)}
     out["3D"] = problem_3d(120, True, 64, 2)
     out["distance_map_3D"] = distance_3d(120, 64)
     # the larger problem: the reference's search alone takes ~20 s of one host core here, so one run each and no adapter leg

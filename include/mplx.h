@@ -486,6 +486,12 @@ typedef struct {
                                row of mplx_succ_lists) instead of being evaluated by the search                     */
 } mplx_plan_timing;
 int mplx_planner_timing(const mplx_planner *p, mplx_plan_timing *out);
+/* ABI v8.  PlannerBase::setPriorTrajectory (planner_base.h:249-252; env_map::set_prior_trajectory, env_map.h:189-226): the
+ * last trajectory of `from` (another planner, possibly with another control order) guides this planner's search -- a
+ * state at time t is drawn to where that trajectory is at t (env_base::get_heur, env_base.h:46-52).  Call it after this
+ * planner's map, v_max, w and dt are set, as the reference's programs do.  Occupancy maps (the potential-map terms need
+ * the device's map: the drop-in adapter covers those).  from == NULL: no prior trajectory.                            */
+int mplx_planner_set_prior_trajectory(mplx_planner *p, const mplx_planner *from);
 
 /* ---- ABI v8: Lifelong Planning A* (PlannerBase::setLPAstar, planner_base.h:170-176; GraphSearch::LPAstar,
  *      graph_search.h:194-365; StateSpace::updateNode / increaseCost / decreaseCost / getSubStateSpace,

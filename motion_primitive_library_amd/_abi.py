@@ -27,7 +27,7 @@ SYMBOLS = [
     "mplx_synchronize", "mplx_timer_begin", "mplx_timer_end",
     "mplx_planner_create", "mplx_planner_destroy", "mplx_planner_attach_ctx", "mplx_planner_set_provider",
     "mplx_planner_set_map", "mplx_planner_set_controls", "mplx_planner_configure", "mplx_planner_plan",
-    "mplx_planner_trajectory", "mplx_planner_trajectory_end", "mplx_planner_closed_set", "mplx_planner_open_set", "mplx_planner_last_error", "mplx_planner_timing", "mplx_planner_use_device_heuristic", "mplx_planner_set_lpastar", "mplx_planner_reset", "mplx_planner_linked_nodes", "mplx_planner_update_blocked_nodes", "mplx_planner_update_cleared_nodes", "mplx_planner_sub_state_space", "mplx_planner_set_edge_provider",
+    "mplx_planner_trajectory", "mplx_planner_trajectory_end", "mplx_planner_closed_set", "mplx_planner_open_set", "mplx_planner_last_error", "mplx_planner_timing", "mplx_planner_set_prior_trajectory", "mplx_planner_use_device_heuristic", "mplx_planner_set_lpastar", "mplx_planner_reset", "mplx_planner_linked_nodes", "mplx_planner_update_blocked_nodes", "mplx_planner_update_cleared_nodes", "mplx_planner_sub_state_space", "mplx_planner_set_edge_provider",
     "mplx_selftest_math", "mplx_selftest_forward_state", "mplx_set_lists_route", "mplx_last_lists_route", "mplx_last_grid_kernel", "mplx_last_identity_form", "mplx_debug_store_model", "mplx_yaw_pin_stats", "mplx_service", "mplx_device_info",
 ]
 
@@ -189,6 +189,7 @@ def lib():
         "mplx_planner_last_error": (C.c_char_p, [vp]),
         "mplx_planner_timing": (C.c_int, [vp, C.POINTER(PlanTiming)]),
         "mplx_planner_use_device_heuristic": (C.c_int, [vp, C.c_int]),
+        "mplx_planner_set_prior_trajectory": (C.c_int, [vp, vp]),
         "mplx_planner_set_lpastar": (C.c_int, [vp, C.c_int]),
         "mplx_planner_reset": (C.c_int, [vp]),
         "mplx_planner_linked_nodes": (C.c_int, [vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),

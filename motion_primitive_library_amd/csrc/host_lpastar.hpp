@@ -138,8 +138,9 @@ class LpaPlanner {
   }
 
   // PlannerBase::plan with use_lpastar_ (planner_base.h:275-325)
-  int plan(const double *start, const double *goal) {
+  int plan(const double *start, const double *goal_given) {
     Planner &P = *cfg;
+    const double *goal = P.effective_goal(goal_given);  // (a prior trajectory's end, env_base.h:295-298)
     last = PlanResult();
     const auto t0 = std::chrono::steady_clock::now();
     int pn[3];

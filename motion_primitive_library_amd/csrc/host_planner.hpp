@@ -536,13 +536,110 @@ class Planner {
   }
 
   double heur(const double *s, const double *goal) const {  // env_base.h:46-64
-    return heur_keyed(s, lattice_hash(dim, control, s), goal, lattice_hash(dim, goal_control ? goal_control : control, goal));
+    return heur_keyed(s, lattice_hash(dim, control, s), goal, lattice_hash(dim, effective_goal_control(), goal));
   }
-  double heur_keyed(const double *s, uint64_t s_key, const double *goal, uint64_t goal_key) const {
+  double heur_keyed(const double *s, uint64_t s_key, const double *goal, uint64_t goal_key) const {  // s: a full state
     if (s_key == goal_key) return 0;
-    double m = 0;
-    for (int i = 0; i < dim; i++) m = std::max(m, std::abs(s[i] - goal[i]));
-    return v_max > 0 ? w * m / v_max : w * m;
+    return heur_at(s, s[4 * dim + 1], goal);
+  }
+
+  // ---- prior trajectory (env_map::set_prior_trajectory, env_map.h:189-226; env_base::get_heur, env_base.h:46-52): a
+  // state at time t is guided towards where the prior trajectory is at that time -- h = cal_heur(state, prior(t)) + the
+  // prior's remaining cost -- instead of towards the goal.  Occupancy maps only (the potential-map terms of
+  // env_map.h:201-214 need the potential map, which lives on the device: use the drop-in adapter for those).
+  std::vector<double> prior_pos;   // [n][D] position of traj.evaluate(k dt)
+  std::vector<double> prior_togo;  // [n] total_cost - costs[k]
+  double prior_goal[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // traj.evaluate(total_time): THE goal while a prior is set
+  int prior_control = 0;           // ... and its control flag (the prior trajectory's)
+  bool has_prior() const { return !prior_togo.empty(); }
+  void clear_prior() { prior_pos.clear(); prior_togo.clear(); }
+  // env_base::set_goal (env_base.h:295-298) keeps the goal set_prior_trajectory installed (env_map.h:225): with a prior
+  // trajectory the search ends where THAT ends, whatever goal plan() is given.
+  const double *effective_goal(const double *goal) const { return has_prior() ? prior_goal : goal; }
+  int effective_goal_control() const { return has_prior() ? prior_control : (goal_control ? goal_control : control); }
+  // nodes: [segs][4D+2] segment start states, actions: [segs] rows of `pU` (udim entries each), the prior's control flag
+  // and primitive duration.  v_max, w, dt and the grid of THIS planner must be set (the reference's call order,
+  // test_planner_2d_with_prior_traj.cpp:60-70).
+  int set_prior_trajectory(const double *nodes, const int32_t *actions, int segs, int pcontrol, const double *pU, int pudim, double pdt) {
+    clear_prior();
+    if (segs <= 0) return 0;
+    const int f = F(), K = (pcontrol & 8) ? 4 : (pcontrol & 4) ? 3 : (pcontrol & 2) ? 2 : 1;
+    // Primitive1D coefficient vectors of every segment and axis (primitive.h:34-50), highest order first
+    std::vector<double> c((size_t)segs * dim * 6, 0.0), taus{0.0};
+    for (int s = 0; s < segs; s++) {
+      const double *nd = nodes + (size_t)s * f, *u = pU + (size_t)actions[s] * pudim;
+      for (int i = 0; i < dim; i++) {
+        double *ci = &c[((size_t)s * dim + i) * 6];
+        ci[5] = nd[i];
+        if (K == 1) ci[4] = u[i];
+        if (K == 2) { ci[4] = nd[dim + i]; ci[3] = u[i]; }
+        if (K == 3) { ci[4] = nd[dim + i]; ci[3] = nd[2 * dim + i]; ci[2] = u[i]; }
+        if (K == 4) { ci[4] = nd[dim + i]; ci[3] = nd[2 * dim + i]; ci[2] = nd[3 * dim + i]; ci[1] = u[i]; }
+      }
+      taus.push_back(pdt + taus.back());  // trajectory.h:52-56
+    }
+    const double total_time = taus.back();
+    auto p_of = [&](int s, int i, double t) {  // Primitive1D::p, primitive.h:128-131 (power() of math.h:197-205)
+      const double *ci = &c[((size_t)s * dim + i) * 6];
+      auto power = [](double x, int n) { double r = 1; while (n-- > 0) r *= x; return r; };
+      return ci[0] / 120 * power(t, 5) + ci[1] / 24 * power(t, 4) + ci[2] / 6 * power(t, 3) + ci[3] / 2 * t * t + ci[4] * t + ci[5];
+    };
+    auto clamp = [&](double tau) { if (tau < 0) tau = 0; if (tau > total_time) tau = total_time; return tau; };
+    // env_map::traverse_trajectory (env_map.h:229-255) without a potential map: +inf when a sample is outside or occupied
+    double traverse = 0;
+    {
+      const int n = (int)std::ceil(v_max * total_time / grid.res);
+      const double sdt = total_time / n;
+      int64_t prev_idx = -1;
+      for (int k = 0; k <= n && n > 0; k++) {  // Trajectory::sample(n): Command at k * dt (trajectory.h:230-236, 99-131)
+        double tau = clamp(k * sdt), pt[3] = {0, 0, 0};
+        for (int s = 0; s < segs; s++)
+          if (tau >= taus[(size_t)s] && tau <= taus[(size_t)s + 1]) {
+            tau -= taus[(size_t)s];
+            for (int i = 0; i < dim; i++) pt[i] = p_of(s, i, tau);
+            break;
+          }
+        int pn[3] = {0, 0, 0};
+        grid.to_cell(pt, pn);
+        const int64_t idx = (int)grid.index(pn);  // (MapUtil::getIndex is int arithmetic, also for cells outside)
+        if (idx == prev_idx) continue;
+        prev_idx = idx;
+        if (grid.outside(pn) || grid.is_occupied(pn)) { traverse = kInf; break; }
+      }
+    }
+    const double total_cost = traverse + w * total_time;
+    std::vector<double> costs;
+    for (double t = 0; t < total_time; t += dt) costs.push_back(w * t);  // (no potential map: potential_cost = 0)
+    for (double t = 0; t < total_time; t += dt) {
+      const int id = (int)(t / dt);
+      double tau = clamp(t);
+      for (int s = 0; s < segs; s++)  // Trajectory::evaluate(t) -> Waypoint, trajectory.h:67-86
+        if ((tau >= taus[(size_t)s] && tau < taus[(size_t)s + 1]) || s == segs - 1) {
+          tau -= taus[(size_t)s];
+          for (int i = 0; i < dim; i++) prior_pos.push_back(p_of(s, i, tau));
+          break;
+        }
+      prior_togo.push_back(total_cost - costs[(size_t)id]);
+    }
+    // goal_node_ = traj.evaluate(total_time) (env_map.h:225): the last segment at its full duration, the prior's flags
+    {
+      const int s = segs - 1;
+      forward_state(dim, pcontrol, nodes + (size_t)s * f, pU + (size_t)actions[s] * pudim, clamp(total_time) - taus[(size_t)s], prior_goal);
+      prior_goal[4 * dim + 1] = 0.0;  // (Trajectory::evaluate returns a fresh Waypoint: t = 0)
+      prior_control = pcontrol;
+    }
+    return 0;
+  }
+  // env_base::get_heur for a state at position `s` and time `t` whose lattice hash differs from the goal's
+  double heur_at(const double *s, double t, const double *goal) const {
+    auto linf = [&](const double *b) {
+      double m = 0;
+      for (int i = 0; i < dim; i++) m = std::max(m, std::abs(s[i] - b[i]));
+      return v_max > 0 ? w * m / v_max : w * m;
+    };
+    const size_t id = (size_t)(t / dt);  // env_base.h:48
+    if (has_prior() && id < prior_togo.size()) return linf(&prior_pos[id * (size_t)dim]) + prior_togo[id];
+    return linf(goal);
   }
 
   bool is_goal(const double *s, const double *goal) const {  // env_map.h:25-45
@@ -577,7 +674,8 @@ class Planner {
   }
 
   // PlannerBase::plan (A*), planner_base.h:275-325 + GraphSearch::Astar
-  int plan(const double *start, const double *goal) {
+  int plan(const double *start, const double *goal_given) {
+    const double *goal = effective_goal(goal_given);
     using clk = std::chrono::steady_clock;
     auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     const auto t_plan0 = clk::now();
@@ -610,7 +708,7 @@ class Planner {
     const int f = F();
     if (is_goal(start, goal)) { last.ok = true; last.cost = 0; return 0; }
 
-    const uint64_t goal_key = lattice_hash(dim, goal_control ? goal_control : control, goal);
+    const uint64_t goal_key = lattice_hash(dim, effective_goal_control(), goal);
     {
       bool fresh;
       const uint64_t key = lattice_hash(dim, control, start);
@@ -750,10 +848,10 @@ class Planner {
           c_curr = &coords[(size_t)cold[curr].coord * (size_t)f];  // (coords may have moved)
         }
         if (eps == 0 || key == goal_key) nd.h = 0;
-        else if (sv.heur) { nd.h = sv.heur[s]; last.heur_from_provider++; }  // computed where the successor was made
+        else if (sv.heur && !has_prior()) { nd.h = sv.heur[s]; last.heur_from_provider++; }  // computed where the successor was made
         else {
           if (!have_sc) forward_pos(dim, control, c_curr, &U[(size_t)sv.act[s] * udim], dt, sc);
-          nd.h = heur_keyed(sc, key, goal, goal_key);
+          nd.h = heur_at(sc, c_curr[4 * dim + 1] + dt, goal);  // (the successor's time: env_map.h:161)
         }
       }
       const uint64_t tp3 = pass_timing ? __builtin_ia32_rdtsc() : 0;

@@ -176,7 +176,7 @@ int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, 
   if (p->pl.nU <= 0) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: controls not set");
   if (!p->pl.single && !p->pl.batched && !p->pl.packed) return fail(p, MPLX_ERR_STATE, "mplx_planner_plan: no successor provider attached");
   p->device_heur = false;
-  if (p->ctx && p->pl.packed && p->pl.eps != 0 && p->want_device_heur) {
+  if (p->ctx && p->pl.packed && p->pl.eps != 0 && p->want_device_heur && !p->pl.has_prior()) {
     // env_base::set_goal for the device (planner_base.h:301): the kernels compute what graph_search.h:84-88 asks of
     // the env for every new successor -- the default heuristic -- while the successor is in registers.
     // OFF by default (mplx_planner_use_device_heuristic / MPLX_PLAN_DEVICE_HEUR=1): one successor in fifteen creates a
@@ -230,6 +230,22 @@ int mplx_planner_plan(mplx_planner *p, const double *start, const double *goal, 
 int mplx_planner_use_device_heuristic(mplx_planner *p, int on) {
   if (!p) return MPLX_ERR_ARG;
   p->want_device_heur = on != 0;
+  return MPLX_OK;
+}
+
+int mplx_planner_set_prior_trajectory(mplx_planner *p, const mplx_planner *from) {
+  if (!p) return MPLX_ERR_ARG;
+  if (!from) { p->pl.clear_prior(); return MPLX_OK; }
+  const mplx::host::PlanResult &r = from->result();
+  if (!r.ok || r.traj_actions.empty()) return fail(p, MPLX_ERR_STATE, "mplx_planner_set_prior_trajectory: the other planner holds no trajectory");
+  if (from->pl.dim != p->pl.dim) return fail(p, MPLX_ERR_ARG, "mplx_planner_set_prior_trajectory: dimensions differ");
+  if (p->pl.grid.cells.empty()) return fail(p, MPLX_ERR_STATE, "mplx_planner_set_prior_trajectory: set the map first");
+  try {
+    p->pl.set_prior_trajectory(r.traj_nodes.data(), r.traj_actions.data(), (int)r.traj_actions.size(), from->pl.control,
+                               from->pl.U.data(), from->pl.udim, from->pl.dt);
+  } catch (...) {
+    return fail(p, MPLX_ERR_NOMEM, "mplx_planner_set_prior_trajectory: out of host memory");
+  }
   return MPLX_OK;
 }
 

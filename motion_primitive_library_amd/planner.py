@@ -254,6 +254,12 @@ class MapPlanner:
         """Tests: another implementation of the batched edge re-validation (the CPU oracle's)."""
         self._check(self._L.mplx_planner_set_edge_provider(self._p, fn_ptr, user_ptr))
 
+    def setPriorTrajectory(self, other):
+        """PlannerBase::setPriorTrajectory: the last trajectory of another planner (still open) guides this one's
+        search; None clears it.  Set this planner's map, v_max, w and dt first."""
+        self._check(self._L.mplx_planner_configure(self._p, C.byref(self._cfg)))  # (v_max, w, dt reach the search)
+        self._check(self._L.mplx_planner_set_prior_trajectory(self._p, other._p if other is not None else None))
+
     def useDeviceHeuristic(self, on=True):
         """The heuristic of new nodes from the `heur` row the expansion launches write (mplx_set_goal) instead of the
         search's own evaluation: same search, see mplx_planner_use_device_heuristic."""

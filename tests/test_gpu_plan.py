@@ -389,3 +389,29 @@ def test_search_consumes_the_heuristic_the_expansion_launch_computed(engine):
         for k in ("cost", "expansions", "closed", "opened", "nodes", "segments", "total_time", "J"):
             assert s0[k] == s1[k], (dim, k, s0[k], s1[k])
         assert np.array_equal(tr0.actions, tr1.actions) and np.array_equal(tr0.nodes, tr1.nodes) and np.array_equal(c0, c1)
+
+
+def test_prior_trajectory_scenario_on_the_engine_planner_with_the_device(engine):
+    """test_planner_2d_with_prior_traj.cpp on the engine's planner with get_succ on the MI355X (VEL plan, then the
+    JRK-state plan guided by it: PlannerBase::setPriorTrajectory): what the reference's MapPlanner returns on the CPU
+    (tests/test_plan_known_answer.py pins 628 closed nodes, cost 353.5, T = 35)."""
+    from test_plan_known_answer import _prior_traj_scenario_on_the_engine_planner
+    m = engine
+    c = corridor()
+
+    def make(control, U):
+        pl = m.MapPlanner(2, device=0)
+        mu = m.MapUtil(2)
+        mu.setMap(c["origin"], c["dim"], c["cells"].copy(), c["res"])
+        pl.setMapUtil(mu)
+        pl.setVmax(1.0)
+        pl.setAmax(1.0)
+        pl.setDt(1.0)
+        pl.setU(U)
+        pl.setBatch(16)
+        return pl
+
+    ok, s1, s2, tr, s3 = _prior_traj_scenario_on_the_engine_planner(m, make)
+    assert ok and s1["closed"] == 248 and s1["cost"] == 382.0
+    assert s2["closed"] == 628 and s2["cost"] == 353.5 and tr.getTotalTime() == 35.0 and s2["J"][2] == 3.5
+    assert s3["cost"] == 363.0 and s3["closed"] == 3598

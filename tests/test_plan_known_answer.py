@@ -167,3 +167,65 @@ def test_c1_children_that_ride_along_change_nothing_but_the_launch_count(engine,
     ok, s, t, c = run_c1(engine, batch=16)      # the default: on for a 9-control table
     assert s["device_launches"] == launches[4] and s["closed"] == 615
 
+
+
+def _prior_traj_scenario_on_the_engine_planner(m, make_planner):
+    """test_planner_2d_with_prior_traj.cpp:29-102 on the engine's own planner: a VEL plan with unit controls, then a plan
+    with position + velocity + acceleration in the state (jerk control) guided by it (PlannerBase::setPriorTrajectory).
+    make_planner(control, U) -> a configured MapPlanner (provider of the caller's choice)."""
+    c = corridor()
+    vals = [-0.5, 0.0, 0.5]
+    U = m.workloads.grid_controls(vals, 2)
+    first = make_planner(m.VEL, 2.0 * U)
+    assert first.plan(m.Waypoint(2, m.VEL, pos=c["start"]), m.Waypoint(2, m.VEL, pos=c["goal"]))
+    s1 = first.summary()
+    second = make_planner(m.JRK, U)
+    second.setEpsilon(1.0)
+    second.setW(10)
+    second.setTol(0.5)
+    second.setPriorTrajectory(first)
+    ok = second.plan(m.Waypoint(2, m.JRK, pos=c["start"]), m.Waypoint(2, m.VEL, pos=c["goal"]))  # the goal keeps the VEL flag
+    s2, tr = second.summary(), second.getTraj()
+    # ... and without the prior trajectory the same planner searches towards the goal itself
+    second.setPriorTrajectory(None)
+    assert second.plan(m.Waypoint(2, m.JRK, pos=c["start"]), m.Waypoint(2, m.VEL, pos=c["goal"]))
+    s3 = second.summary()
+    first.close()
+    second.close()
+    return ok, s1, s2, tr, s3
+
+
+@pytest.mark.skipif(not os.path.exists(O.REF_PLANNER_SO), reason="oracle/_ref/libmpl_ref_planner.so not built")
+def test_prior_trajectory_heuristic_on_the_engine_planner(engine):
+    """env_base::get_heur with a prior trajectory (env_base.h:46-52, env_map::set_prior_trajectory env_map.h:189-226) in
+    csrc/host_planner.hpp, successors from the CPU oracle: the reference's own MapPlanner on the scenario of its test
+    program closes 628 nodes for cost 353.5 (pinned above); so must the engine's search."""
+    m = engine
+    c = corridor()
+    keep = []
+
+    def make(control, U):
+        oenv = O.Env(2, control, U, c["cells"], c["dim"], c["origin"], c["res"], v_max=1.0, a_max=1.0, dt=1.0)
+        prov, ce = provider_from_oracle(oenv)
+        keep.append((oenv, ce))
+        pl = m.MapPlanner(2, provider=prov)
+        mu = m.MapUtil(2)
+        mu.setMap(c["origin"], c["dim"], c["cells"], c["res"])
+        pl.setMapUtil(mu)
+        pl.setVmax(1.0)
+        pl.setAmax(1.0)
+        pl.setDt(1.0)
+        pl.setU(U)
+        return pl
+
+    ok, s1, s2, tr, s3 = _prior_traj_scenario_on_the_engine_planner(m, make)
+    U = m.workloads.grid_controls([-0.5, 0.0, 0.5], 2)
+    oenv = O.Env(2, O.ACC, U, c["cells"], c["dim"], c["origin"], c["res"], v_max=1.0, a_max=1.0, dt=1.0)
+    ref = O.ref_scenario(oenv, m.Waypoint(2, m.ACC, pos=c["start"]).to_row(), m.Waypoint(2, m.ACC, pos=c["goal"]).to_row(), "prior_traj")
+    assert ok and s1["closed"] == ref[0]["closed"] and s1["cost"] == ref[0]["cost"]
+    for k in ("closed", "expansions", "opened", "cost", "total_time", "segments", "J"):
+        assert s2[k] == ref[1][k], (k, s2[k], ref[1][k])
+    assert s2["closed"] == 628 and s2["cost"] == 353.5 and tr.getTotalTime() == 35.0
+    # without the prior trajectory the search ends in the goal's own region (with one, where the prior ends: env_base.h:295-298):
+    # the reference's MapPlanner on that problem (O.ref_plan with the JRK-state start) closes 3 598 nodes for 363.0
+    assert s3["cost"] == 363.0 and s3["closed"] == 3598 and s3["total_time"] == 36.0
