@@ -480,7 +480,7 @@ def extra_plan(m):
         one host core, the same with the drop-in adapter, and the engine's own LPA* (csrc/host_lpastar.hpp)."""
         res = 0.1
         flat = W.box_map([edge] * 3, res, 0.05, 78, side_m=(0.3, 0.8)).ravel().copy()
-        U3 = W.grid_controls([-1.0, 0.0, 1.0], 3)
+        U3 = W.grid_controls(np.linspace(-2.0, 2.0, 5), 3)
 
         def free_near(p):
             cc = np.array([int(x / res) for x in p])
@@ -494,14 +494,14 @@ def extra_plan(m):
         s3 = m.Waypoint(3, m.ACC, pos=free_near([0.5, 0.5, 0.5]))
         g3 = m.Waypoint(3, m.ACC, pos=free_near([edge * res - 1.0, edge * res - 1.4, edge * res - 1.8]))
         box = 3
-        rp = {"problem": "3D %d^3 voxels, ACC, |U| = 27, v_max 1: LPA* with a %d^3-cell box blocked on the trajectory, then cleared" % (edge, 2 * box + 1)}
+        rp = {"problem": "3D %d^3 voxels, ACC, |U| = 125, v_max 2: LPA* with a %d^3-cell box blocked on the trajectory, then cleared" % (edge, 2 * box + 1)}
         # ---- the engine's own LPA*
         pl = m.MapPlanner(3, device=0)
         mu = m.MapUtil(3)
         mu.setMap([0.0] * 3, [edge] * 3, flat.copy(), res)
         pl.setMapUtil(mu)
-        pl.setVmax(1.0)
-        pl.setAmax(1.0)
+        pl.setVmax(2.0)
+        pl.setAmax(2.0)
         pl.setDt(1.0)
         pl.setU(U3)
         pl.setBatch(16)
@@ -520,7 +520,7 @@ def extra_plan(m):
 
         rec(timed("plan1_ms", lambda: pl.plan(s3, g3)))
         wps = pl.getTraj().getWaypoints()
-        _, n_cells, n_entries = timed("linked_nodes_ms", lambda: pl.getLinkedNodes())
+        _, n_cells, n_entries = timed("linked_nodes_ms", lambda: pl.getLinkedNodes(want_points=False))
         c_round = lambda x: int(np.sign(x) * np.floor(abs(x) + 0.5))
         to_cell = lambda p: np.array([c_round(p[i] / res - 0.5) for i in range(3)])
         mid, sc, gc = to_cell(wps[len(wps) // 2][:3]), to_cell(s3.pos), to_cell(g3.pos)
@@ -547,7 +547,7 @@ def extra_plan(m):
         rp["engine_lpastar"] = dict({k: round(v, 3) for k, v in t_ms.items()}, plans=plans, table_cells=n_cells, table_entries=n_entries,
                                     edited_cells=int(edit.shape[0]))
         if have_ref:
-            oenv = O.Env(3, O.ACC, U3, flat, [edge] * 3, [0.0] * 3, res, v_max=1.0, a_max=1.0, dt=1.0)
+            oenv = O.Env(3, O.ACC, U3, flat, [edge] * 3, [0.0] * 3, res, v_max=2.0, a_max=2.0, dt=1.0)
             for label, gpu in (("reference_cpu", False), ("reference_planner_gpu_adapter", True)):
                 rp_, tb = O.ref_lpastar(oenv, s3.to_row(), g3.to_row(), use_gpu=gpu, box_half=box)
                 rp[label] = {"plan1_ms": rp_[0]["wall_ms"], "plan2_ms": rp_[1]["wall_ms"], "plan3_ms": rp_[2]["wall_ms"],
@@ -562,7 +562,7 @@ def extra_plan(m):
         return rp
 
     try:
-        out["replan_3D"] = replan_3d(64)
+        out["replan_3D"] = replan_3d(100)
     except Exception as e:  # noqa: BLE001
         out["replan_3D"] = {"error": "%s: %s" % (type(e).__name__, e)}
     out["3D"] = problem_3d(120, True, 64, 2)
@@ -658,12 +658,16 @@ def extras(m, args, wl, out):
                 st = lists.c_struct()
                 st.state = None  # the identity pass alone: canon + bit 2 of the flags row the launch wrote
                 loops = []
-                for _ in range(3):
-                    env.expand_lists_resident(fr_x, lists)  # (bit 2 is OR-ed in: a fresh row per measurement)
-                    env.synchronize()
-                    env.timer_begin()
+                env.expand_lists_resident(fr_x, lists)
+                env.synchronize()
+                for _ in range(2):
                     _abi.check(env._ctx, _abi.lib().mplx_post_lists_device(env._ctx, C.byref(st), wl.n_nodes, C.byref(g), C.byref(o)))
-                    loops.append(env.timer_end())
+                env.synchronize()
+                for _ in range(3):  # (bit 2 is OR-ed into the row: idempotent, so the calls can simply be repeated)
+                    env.timer_begin()
+                    for _ in range(5):
+                        _abi.check(env._ctx, _abi.lib().mplx_post_lists_device(env._ctx, C.byref(st), wl.n_nodes, C.byref(g), C.byref(o)))
+                    loops.append(env.timer_end() / 5)
                 fused[label] = {"lists_only_ms": plain, "lists_heur_flags_ms": both, "ratio": both / plain,
                                 "identity_only_ms": sorted(loops)[1], "identity_form": env.last_identity_form()}
             lists.heur = lists.flags = None

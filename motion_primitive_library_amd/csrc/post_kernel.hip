@@ -97,6 +97,17 @@ __global__ __launch_bounds__(256) void post_lists_kernel(const PostArgs A) {
   }
 }
 
+// Lists whose flags row the expansion launch wrote (mplx_succ_lists::flags), node identity by the partition
+// (identity_kernel.hip): all that is left to do is the first-occurrence bit -- count and canon are read, nothing else.
+__global__ __launch_bounds__(256) void post_first_flags_kernel(const PostArgs A) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= A.n_nodes * A.nstride) return;
+  const int64_t node = g / A.nstride;
+  const int j = (int)(g - node * A.nstride);
+  if (j >= A.count[node]) return;
+  if (A.canon[g] == (int32_t)g) A.flags[g] |= 4;
+}
+
 __global__ __launch_bounds__(256) void post_canon_kernel(const PostArgs A) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= A.n_nodes * A.nstride) return;
@@ -120,6 +131,10 @@ hipError_t launch_post_lists(int dim, const PostArgs &a, hipStream_t s) {
   const int64_t n = a.n_nodes * a.nstride;
   if (n == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (!a.state && !a.heur && !a.keys) {
+    if (a.flags && a.canon) hipLaunchKernelGGL(post_first_flags_kernel, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
   if (dim == 2) hipLaunchKernelGGL(post_lists_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(post_lists_kernel<3>, dim3(blocks), dim3(256), 0, s, a);
   if (a.keys && a.canon) hipLaunchKernelGGL(post_canon_kernel, dim3(blocks), dim3(256), 0, s, a);
