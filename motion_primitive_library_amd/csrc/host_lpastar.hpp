@@ -134,6 +134,7 @@ class LpaPlanner {
     ready_ = false;
     start_g_ = start_rhs_ = start_t_ = 0;
     expand_iteration_ = 0;
+    n_closed_ = 0;
     spec_.clear();
   }
 
@@ -151,8 +152,7 @@ class LpaPlanner {
     const int rc = lpastar(start, goal);
     last.t_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     last.nodes = (int)hm_.size();
-    for (const auto &kv : hm_)
-      if (kv.second && kv.second->closed) last.closed++;  // PlannerBase::getCloseSet
+    last.closed = n_closed_;  // PlannerBase::getCloseSet's size, kept up to date by set_closed()
     last.opened = (int)pq_.size();
     return rc;
   }
@@ -334,8 +334,10 @@ class LpaPlanner {
     }
     hm_.swap(new_hm);
     pq_.clear();
+    n_closed_ = 0;
     for (auto &kv : hm_) {
       LNode *nd = kv.second;
+      if (nd->closed) n_closed_++;
       if (nd->opened && !nd->closed) nd->handle = pq_.push(key_of(nd), nd);
     }
     lhm_.clear();
@@ -374,6 +376,8 @@ class LpaPlanner {
   bool ready_ = false;
   double start_g_ = 0, start_rhs_ = 0, start_t_ = 0;
   int expand_iteration_ = 0;  // StateSpace::expand_iteration_
+  int n_closed_ = 0;          // nodes with iterationclosed set
+  void set_closed(LNode *nd, bool v) { n_closed_ += (int)v - (int)nd->closed; nd->closed = v; }
 
   struct List { std::vector<double> coord, cost; std::vector<int32_t> act; std::vector<uint64_t> key; };
   std::unordered_map<const LNode *, List> spec_;  // get_succ results that rode along in a launch (valid for this plan)
@@ -398,12 +402,12 @@ class LpaPlanner {
     }
     if (nd->opened && !nd->closed) {
       pq_.erase(nd->handle);
-      nd->closed = true;
+      set_closed(nd, true);
     }
     if (nd->g != nd->rhs) {
       nd->handle = pq_.push(key_of(nd), nd);
       nd->opened = true;
-      nd->closed = false;
+      set_closed(nd, false);
     }
   }
 
@@ -543,7 +547,7 @@ class LpaPlanner {
       curr->h = P.eps == 0 ? 0 : P.heur(start, goal);
       curr->handle = pq_.push(key_of(curr), curr);
       curr->opened = true;
-      curr->closed = false;
+      set_closed(curr, false);
       sslot = curr;
     }
     LNode dummy;  // the goal node until one is reached: g = rhs = inf, h = 0
@@ -561,7 +565,7 @@ class LpaPlanner {
       expand_iteration++;
       curr = pq_.top().n;
       pq_.pop();
-      curr->closed = true;
+      set_closed(curr, true);
       if (curr->g > curr->rhs) curr->g = curr->rhs;
       else { curr->g = kInf; update_node(curr); }
       List L;

@@ -282,6 +282,44 @@ struct HugeAlloc {
   template <class O> bool operator!=(const HugeAlloc<O> &) const { return false; }
 };
 
+// An append-only array whose new elements are NOT initialised (std::vector::resize would write every element once
+// before the search writes it again): the predecessor pool grows by 300 entries per expansion, 14.5 M per 160^3 plan.
+template <class T>
+class RawVec {
+ public:
+  RawVec() = default;
+  RawVec(const RawVec &) = delete;
+  RawVec &operator=(const RawVec &) = delete;
+  ~RawVec() { std::free(p_); }
+  size_t size() const { return n_; }
+  void clear() { n_ = 0; }
+  T *data() { return p_; }
+  const T &operator[](size_t i) const { return p_[i]; }
+  // room for `more` further elements; returns where they start (the caller writes all of them)
+  T *grow(size_t more) {
+    if (n_ + more > cap_) {
+      size_t cap = cap_ ? cap_ : (size_t)1 << 16;
+      while (cap < n_ + more) cap *= 2;
+      void *q = nullptr;
+      if (posix_memalign(&q, 64, cap * sizeof(T)) != 0) throw std::bad_alloc();
+#ifdef MADV_HUGEPAGE
+      if (cap * sizeof(T) >= ((size_t)4 << 20)) (void)madvise(q, cap * sizeof(T), MADV_HUGEPAGE);
+#endif
+      if (n_) std::memcpy(q, p_, n_ * sizeof(T));
+      std::free(p_);
+      p_ = (T *)q;
+      cap_ = cap;
+    }
+    T *at = p_ + n_;
+    n_ += more;
+    return at;
+  }
+
+ private:
+  T *p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+};
+
 struct Cold {            // per node, indexed by node index
   double g = kInf;       // copy of the slot's g (heap tie-breaks of re-opened nodes, recoverTraj)
   double h = kInf;       // State::h
@@ -493,8 +531,8 @@ class Planner {
   struct PredRec { double cost; uint32_t parent; int32_t next; };  // pred_coord / pred_action_cost of state_space.h:49-53
   NodeTable hm;
   std::vector<Cold, HugeAlloc<Cold>> cold;  // nodes in creation order
-  std::vector<PredRec> preds;    // every relaxed edge (graph_search.h:97-99), newest first per child
-  std::vector<int32_t> pred_act; // pred_action_id, parallel to preds
+  RawVec<PredRec> preds;         // every relaxed edge (graph_search.h:97-99), newest first per child
+  RawVec<int32_t> pred_act;      // pred_action_id, parallel to preds
   std::vector<double> coords;    // [materialised][4D+2]
   OpenList pq;
   PlanResult last;
@@ -780,10 +818,8 @@ class Planner {
       if (cold.capacity() < cold.size() + (size_t)nf) cold.reserve(std::max(cold.capacity() * 2, cold.size() + (size_t)nf));
       const size_t rec0 = preds.size();
       if (rec0 + (size_t)nf > (size_t)0x7fffffff) return -2;  // (32-bit record indices)
-      preds.resize(rec0 + (size_t)nf);
-      pred_act.resize(rec0 + (size_t)nf);
-      PredRec *const P = preds.data() + rec0;
-      int32_t *const A = pred_act.data() + rec0;
+      PredRec *const P = preds.grow((size_t)nf);
+      int32_t *const A = pred_act.grow((size_t)nf);
       const Cold *const cold0 = cold.data();
       // 1a: the probes.  The only data-dependent branches of the relaxation are the ends of the probe sequences; a
       // mispredicted one discards nothing but other probes.
@@ -802,8 +838,10 @@ class Planner {
         const int s = r_fin[(size_t)j];
         Slot *sl = r_slot[(size_t)j];
         const double c_s = sv.cost[s];
-        P[j] = PredRec{c_s, curr, sl->pred_head};
-        A[j] = sv.act[s];
+        // (the records are written once and read again only by recoverTraj, for a few dozen nodes: streamed past the
+        // caches, 20 bytes per edge that would otherwise cost a line fetch for ownership each)
+        stream_record(&P[j], c_s, curr, sl->pred_head);
+        stream_i32(&A[j], sv.act[s]);
         sl->pred_head = (int32_t)(rec0 + (size_t)j);
         const double tentative = g_curr + c_s;
         const bool better = tentative < sl->g;
@@ -887,6 +925,9 @@ class Planner {
       if (nd.closed) last.closed++;
     // PlannerBase::getOpenSet walks the heap (planner_base.h:77-81): a closed node that was pushed again counts
     last.opened = (int)pq.size();
+#if defined(__x86_64__)
+    _mm_sfence();  // (the streamed predecessor records are globally visible before anything reads them back)
+#endif
     const auto t_r0 = clk::now();
     if (reached && recover(curr, start)) { last.ok = true; last.cost = cold[curr].g; }
     last.t_recover = ms_since(t_r0);
@@ -914,6 +955,23 @@ class Planner {
   std::vector<int32_t> r_fin, r_new, r_imp;  // scratch of the relaxation passes (one successor list)
   std::vector<double> r_tent;
   std::vector<Slot *> r_slot;
+  static void stream_record(PredRec *p, double cost, uint32_t parent, int32_t next) {
+#if defined(__x86_64__)
+    static_assert(sizeof(PredRec) == 16, "one 16-byte store");
+    uint64_t lo, hi = (uint64_t)parent | ((uint64_t)(uint32_t)next << 32);
+    std::memcpy(&lo, &cost, 8);
+    _mm_stream_si128((__m128i *)p, _mm_set_epi64x((long long)hi, (long long)lo));
+#else
+    *p = PredRec{cost, parent, next};
+#endif
+  }
+  static void stream_i32(int32_t *p, int32_t v) {
+#if defined(__x86_64__)
+    _mm_stream_si32(p, v);
+#else
+    *p = v;
+#endif
+  }
   // pass 0 of the relaxation: the indices of the finite entries of a cost list, in order.  One entry in three is
   // blocked, at random: a compare-and-compress per 8 entries where the host has AVX-512 (every EPYC an MI355X sits
   // in), a branch-free scalar loop elsewhere.

@@ -298,6 +298,7 @@ struct PostArgs {
   uint64_t cap;            // (keys == null and canon != null: canon was filled by launch_identity before this launch)
 };
 hipError_t launch_post_lists(int dim, const PostArgs &args, hipStream_t s);
+hipError_t launch_post_clear_first_flags(const PostArgs &args, hipStream_t s);  // bit 2 of every emitted entry's flags back to 0
 
 // Node identity by radix partition + per-bucket LDS tables (identity_kernel.hip): canon[g] = smallest list index with
 // the same lattice hash, for every emitted successor g.  The lists are the strided form (packed lists: n_nodes = 1,

@@ -128,14 +128,13 @@ static int post_lists_impl(mplx_ctx *c, const mplx_succ_lists *d_lists, int64_t 
       // trip of the pass: did every run fit its bucket?  Heavy duplication of few lattice states can fill one bucket
       // beyond any fixed capacity; the exact form below has no capacities, and the (idempotent) heuristic / flags kernel
       // runs again on its canon[].
-      // (lists without state rows: the kernel only ORs the first-occurrence bit into an existing flags row, which is not
-      // idempotent on a canon[] that turns out wrong -- it runs once the outcome is known)
-      if (a.state) HIP_TRY(c, mplx::launch_post_lists(D, a, c->stream));
+      // (lists without state rows: the pass only ORs the first-occurrence bit into the flags row the expansion launch
+      // wrote, which is not idempotent on a canon[] that turns out wrong -- queued all the same, and undone below in
+      // the one case that needs it)
+      HIP_TRY(c, mplx::launch_post_lists(D, a, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
-      if (*(volatile int32_t *)c->id_ovf_host == 0) {
-        if (!a.state && a.flags) HIP_TRY(c, mplx::launch_post_lists(D, a, c->stream));
-        return MPLX_OK;
-      }
+      if (*(volatile int32_t *)c->id_ovf_host == 0) return MPLX_OK;
+      if (!a.state && a.flags) HIP_TRY(c, mplx::launch_post_clear_first_flags(a, c->stream));
       *c->id_ovf_host = 0;
       exact = true;
       c->last_identity_form = 3;

@@ -108,6 +108,17 @@ __global__ __launch_bounds__(256) void post_first_flags_kernel(const PostArgs A)
   if (A.canon[g] == (int32_t)g) A.flags[g] |= 4;
 }
 
+// ... and its undo, for the one case in which the bit was set from a canon[] that turned out wrong (the claimed identity
+// pass overflowed a bucket after this launch's first-occurrence pass had been queued behind it).
+__global__ __launch_bounds__(256) void post_clear_first_flags_kernel(const PostArgs A) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= A.n_nodes * A.nstride) return;
+  const int64_t node = g / A.nstride;
+  const int j = (int)(g - node * A.nstride);
+  if (j >= A.count[node]) return;
+  A.flags[g] &= (uint8_t)~4u;
+}
+
 __global__ __launch_bounds__(256) void post_canon_kernel(const PostArgs A) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= A.n_nodes * A.nstride) return;
@@ -126,6 +137,13 @@ __global__ __launch_bounds__(256) void post_canon_kernel(const PostArgs A) {
 }
 
 }  // namespace
+
+hipError_t launch_post_clear_first_flags(const PostArgs &a, hipStream_t s) {
+  const int64_t n = a.n_nodes * a.nstride;
+  if (n == 0 || !a.flags) return hipSuccess;
+  hipLaunchKernelGGL(post_clear_first_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
 
 hipError_t launch_post_lists(int dim, const PostArgs &a, hipStream_t s) {
   const int64_t n = a.n_nodes * a.nstride;
