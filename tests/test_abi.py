@@ -55,3 +55,36 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "mpl_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_planner_entry_points_fail_loudly_without_their_preconditions(engine):
+    """The host-search side of the ABI needs no device for its argument and state checks: LPA* bookkeeping before
+    mplx_planner_set_lpastar, a prior trajectory from a planner that holds none, plan() without map / controls /
+    provider -- each a negative return code and a message, never a crash or a silent no-op."""
+    L = engine._abi.lib()
+    p, q = C.c_void_p(), C.c_void_p()
+    assert L.mplx_planner_create(2, C.byref(p)) == 0 and L.mplx_planner_create(2, C.byref(q)) == 0
+    n = C.c_int64()
+    assert L.mplx_planner_linked_nodes(p, None, 0, C.byref(n), None, None) == engine._abi.ERR_STATE
+    assert b"set_lpastar" in L.mplx_planner_last_error(p)
+    cells = (C.c_int32 * 2)(1, 1)
+    assert L.mplx_planner_update_blocked_nodes(p, cells, 1) == engine._abi.ERR_STATE
+    assert L.mplx_planner_update_cleared_nodes(p, cells, 1) == engine._abi.ERR_STATE
+    assert L.mplx_planner_sub_state_space(p, 0) == engine._abi.ERR_STATE
+    assert L.mplx_planner_set_lpastar(p, 1) == 0
+    assert L.mplx_planner_update_blocked_nodes(p, None, 3) == engine._abi.ERR_ARG
+    assert L.mplx_planner_linked_nodes(p, None, 0, C.byref(n), None, None) == 0 and n.value == 0  # an empty state space
+    assert L.mplx_planner_sub_state_space(p, 0) == 0                                               # no trajectory yet: a no-op
+    assert L.mplx_planner_reset(p) == 0
+    assert L.mplx_planner_set_prior_trajectory(p, q) == engine._abi.ERR_STATE  # q holds no trajectory
+    assert b"no trajectory" in L.mplx_planner_last_error(p)
+    assert L.mplx_planner_set_prior_trajectory(p, None) == 0
+    out = engine._abi.PlanSummary()
+    row = (C.c_double * 10)()
+    assert L.mplx_planner_plan(p, row, row, C.byref(out)) == engine._abi.ERR_STATE  # map not set
+    t = engine._abi.PlanTiming()
+    assert L.mplx_planner_timing(p, C.byref(t)) == 0 and t.relaxed == 0
+    assert L.mplx_planner_timing(None, C.byref(t)) == engine._abi.ERR_ARG
+    assert L.mplx_planner_use_device_heuristic(p, 1) == 0
+    L.mplx_planner_destroy(p)
+    L.mplx_planner_destroy(q)
