@@ -102,6 +102,14 @@ int mplx_abi_version(void);
  * (getIndex, map_util.h:34-41); dim/origin have `dim` entries.               */
 int mplx_set_map(mplx_ctx *ctx, const int8_t *cells, const int32_t *dim, const double *origin,
                  double res);
+/* ABI v8.  An edit of a few cells of the map that is already on the device (a sensor update between two plans:
+ * MapPlanner::updateBlockedNodes / updateClearedNodes, map_planner.cpp:160-185, follow such an edit): cell_index[i]
+ * (x + dim0 * (y + dim1 * z), MapUtil::getIndex) takes values[i].  The int8 cells and the blocked-bit map derived from
+ * them are patched in place -- no 128-MiB upload and no rebuild of the derived structures per edit at 512^3; the
+ * free-box table of the factorised kernels is rebuilt by the first launch of >= 4 096 nodes after the edit.  Same
+ * results as mplx_set_map with the edited array (tests/test_map_prep.py).                                           */
+int mplx_edit_map(mplx_ctx *ctx, const int64_t *cell_index, const int8_t *values, int64_t n);
+
 /* env_map::set_potential_map, env_map.h:181-183.  NULL clears it.  Same size
  * as the map.                                                                */
 int mplx_set_potential(mplx_ctx *ctx, const int8_t *cells_or_null);

@@ -16,7 +16,7 @@ ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_STATE = -1, -2, -3, -4
 # every symbol include/mplx.h declares, in declaration order
 SYMBOLS = [
     "mplx_create", "mplx_destroy", "mplx_last_error", "mplx_abi_version",
-    "mplx_set_map", "mplx_set_potential", "mplx_set_region", "mplx_set_params", "mplx_set_controls",
+    "mplx_set_map", "mplx_edit_map", "mplx_set_potential", "mplx_set_region", "mplx_set_params", "mplx_set_controls",
     "mplx_update_potential_map", "mplx_set_search_region_path",
     "mplx_expand_device", "mplx_expand", "mplx_expand_lists_device", "mplx_expand_lists", "mplx_get_succ",
     "mplx_set_goal", "mplx_post_lists_device", "mplx_post_packed_device",
@@ -148,6 +148,7 @@ def lib():
         "mplx_set_region": (C.c_int, [vp, vp]),
         "mplx_set_params": (C.c_int, [vp, C.POINTER(Params)]),
         "mplx_set_controls": (C.c_int, [vp, vp, i32, i32]),
+        "mplx_edit_map": (C.c_int, [vp, vp, vp, i64]),
         "mplx_set_goal": (C.c_int, [vp, C.POINTER(GoalSpec)]),
         "mplx_update_potential_map": (C.c_int, [vp, vp, vp, vp, dbl, vp]),
         "mplx_set_search_region_path": (C.c_int, [vp, vp, i32, i32, vp, vp]),

@@ -20,6 +20,37 @@ inline int float_to_int(double pt, double origin, double res) { return (int)std:
 
 extern "C" {
 
+int mplx_edit_map(mplx_ctx *c, const int64_t *cell_index, const int8_t *values, int64_t n) {
+  if (!c) return MPLX_ERR_ARG;
+  if (n < 0 || (n > 0 && (!cell_index || !values))) return fail(c, MPLX_ERR_ARG, "mplx_edit_map: bad arguments");
+  if (!c->has_map) return fail(c, MPLX_ERR_STATE, "mplx_edit_map: set the map first");
+  for (int64_t i = 0; i < n; i++)
+    if (cell_index[i] < 0 || cell_index[i] >= c->n_cells)
+      return fail(c, MPLX_ERR_ARG, "mplx_edit_map: cell index %lld outside the map of %lld cells", (long long)cell_index[i], (long long)c->n_cells);
+  if (n == 0) return MPLX_OK;
+  if (int rc = bind_device(c)) return rc;
+  if (int rc = resolve_pending(c)) return rc;  // a pending launch read the old cells
+  if (int rc = svc_stop(c)) return rc;         // a resident kernel may hold the old cells in its XCD's L2
+  const size_t ib = (((size_t)n * 8) + 255) & ~(size_t)255;
+  if (int rc = ensure(c, c->edit_buf, ib + (size_t)n)) return rc;
+  char *d = (char *)c->edit_buf.p;
+  HIP_TRY(c, hipMemcpyAsync(d, cell_index, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d + ib, values, (size_t)n, hipMemcpyHostToDevice, c->stream));
+  // the blocked bits follow the occupancy map cell by cell; with a potential map installed they are derived from THAT
+  // map (env_map.h:113-118 does not consult the occupancy), so the occupancy edit leaves them alone
+  uint32_t *blk = (c->blk_ok && !c->has_pot) ? (uint32_t *)c->blk.p : nullptr;
+  HIP_TRY(c, mplx::launch_edit_map((const int64_t *)d, (const int8_t *)(d + ib), n, c->n_cells, (int8_t *)c->map.p, blk,
+                                   c->has_region ? (const uint32_t *)c->region_bits.p : nullptr, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller may free its arrays on return
+  if (blk && c->sat_ok) {
+    // the summed-area table (free-box shortcut of the factorised kernels) changes in every entry behind an edited cell:
+    // it is switched off and rebuilt by the first launch large enough to be worth it (mplx_api.cpp, lists_device)
+    c->sat_ok = false;
+    c->sat_stale = true;
+  }
+  return MPLX_OK;
+}
+
 int mplx_update_potential_map(mplx_ctx *c, const double *pos, const double *radius, const double *range, double pow_,
                               int8_t *h_map_out) {
   if (!c) return MPLX_ERR_ARG;

@@ -125,6 +125,27 @@ __global__ void unpack_region_kernel(const uint32_t *bits, int64_t n_cells, uint
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+
+// An edit of a few cells of the occupancy map (a sensor update between two plans of an LPA* search, map_planner.cpp:
+// 160-185): the int8 cells and -- where the blocked-bit map is current -- its bits are patched in place instead of
+// uploading the map again and rebuilding every derived structure (512^3: 128 MiB over PCIe + 1.6 ms of kernels per edit).
+// Several edited cells may share a word of the bit map: atomics.
+__global__ void edit_map_kernel(const int64_t *idx, const int8_t *val, int64_t n, int64_t n_cells, int8_t *map, uint32_t *blk,
+                                const uint32_t *region) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const int64_t c = idx[g];
+  if (c < 0 || c >= n_cells) return;  // (checked on the host as well)
+  const int8_t v = val[g];
+  map[c] = v;
+  if (blk) {
+    const uint32_t bit = 1u << (c & 31);
+    const bool in_region = !region || ((region[c >> 5] >> (c & 31)) & 1u);
+    if (v == 100 || !in_region) atomicOr(&blk[c >> 5], bit);  // build_blocked_bits_kernel's rule for occupancy maps
+    else atomicAnd(&blk[c >> 5], ~bit);
+  }
+}
+
 }  // namespace
 
 hipError_t launch_potential_passes(const int8_t *map, const int32_t *d, const int32_t *c1, const int32_t *c2, int rn,
@@ -146,6 +167,13 @@ hipError_t launch_region_boxes(const int *cells, int n_path_cells, int dim, cons
   if (total == 0) return hipSuccess;
   hipLaunchKernelGGL(region_box_kernel, dim3(blocks_for(total)), dim3(256), 0, s, cells, n_path_cells, dim, d[0], d[1],
                      d[2], rn[0], rn[1], rn[2], bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_edit_map(const int64_t *idx, const int8_t *val, int64_t n, int64_t n_cells, int8_t *map, uint32_t *blk,
+                           const uint32_t *region, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(edit_map_kernel, dim3(blocks_for(n)), dim3(256), 0, s, idx, val, n, n_cells, map, blk, region);
   return hipGetLastError();
 }
 

@@ -821,8 +821,21 @@ int yaw_fix_pass(mplx_ctx *c, const mplx_ctx::YawPending &p, const int32_t *ids,
   return MPLX_OK;
 }
 
+// (Re)build the summed-area table of the CURRENT blocked bits (after mplx_edit_map patched them).
+int rebuild_sat(mplx_ctx *c) {
+  c->sat_stale = false;
+  const int d2p = c->dim == 3 ? c->mdim[2] + 1 : 2;
+  const int64_t sat_n = (int64_t)(c->mdim[0] + 1) * (c->mdim[1] + 1) * d2p;
+  if (c->tune.no_sat || sat_n * 4 > (16LL << 30)) return MPLX_OK;
+  if (int rc = ensure(c, c->sat, (size_t)sat_n * 4)) return rc;
+  HIP_TRY(c, mplx::launch_build_sat(c->dim, (const uint32_t *)c->blk.p, c->mdim, (uint32_t *)c->sat.p, c->stream));
+  c->sat_ok = true;
+  return MPLX_OK;
+}
+
 int ensure_blocked_bits(mplx_ctx *c) {
   if (c->blk_ok) return MPLX_OK;
+  c->sat_stale = false;
   const int64_t words = (c->n_cells + 31) >> 5;
   if (int rc = ensure(c, c->blk, (size_t)words * 4)) return rc;
   HIP_TRY(c, mplx::launch_build_blocked_bits((const int8_t *)(c->has_pot ? c->pot.p : c->map.p),
@@ -913,6 +926,10 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     if (int rc = ensure_tables(c)) return rc;
     mplx::GridArgs a{};
     if (int rc = ensure_blocked_bits(c)) return rc;
+    // blocked bits patched by mplx_edit_map: the free-box shortcut is off until a launch of at least a few thousand
+    // nodes makes its table (1.3 ms of scans at 512^3) worth rebuilding; a search's batches sample every node meanwhile
+    if (c->sat_stale && n_nodes >= 4096)
+      if (int rc = rebuild_sat(c)) return rc;
     a.blk = (const uint32_t *)c->blk.p;
     a.blk_words = (c->n_cells + 31) >> 5;
     a.pot = c->has_pot ? (const int8_t *)c->pot.p : nullptr;

@@ -138,6 +138,8 @@ struct mplx_ctx {
   std::vector<YawPending> yaw_pending;
   int32_t *yaw_any_host = nullptr;  // pinned word: some launch since the last resolve flagged a node
   int32_t *id_ovf_host = nullptr;   // pinned word: a bucket of the claimed identity pass overflowed (post_api.cpp)
+  mplx_detail::DevBuf edit_buf;     // cell indices + values of mplx_edit_map
+  bool sat_stale = false;           // the blocked bits were patched by mplx_edit_map: the summed-area table waits for a launch worth rebuilding it for
   int id_backoff = 0;               // calls left that skip the claimed identity form after an overflow (post_api.cpp)
   int last_identity_form = 0;       // 0 none / table in HBM, 1 claimed, 2 exact partition, 3 claimed then exact (overflow)
   mplx_detail::DevBuf yaw_ring, yaw_ids, yaw_tab;  // flagged nodes per pending launch; node list + trig table of a fix pass

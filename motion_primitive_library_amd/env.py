@@ -385,6 +385,17 @@ class EnvMap:
         self.map_dim = [int(x) for x in dim]
         self._ncell = n
 
+    def editMap(self, cell_index, values):
+        """A few cells of the map already on the device take new values (mplx_edit_map): cell_index = x + dim0 * (y +
+        dim1 * z) as MapUtil::getIndex numbers them."""
+        idx = np.ascontiguousarray(cell_index, dtype=np.int64).ravel()
+        val = np.ascontiguousarray(values, dtype=np.int8).ravel()
+        if val.size == 1 and idx.size > 1:
+            val = np.full(idx.size, val[0], dtype=np.int8)
+        if idx.size != val.size:
+            raise ValueError("editMap: %d indices, %d values" % (idx.size, val.size))
+        _abi.check(self._ctx, _abi.lib().mplx_edit_map(self._ctx, idx.ctypes.data, val.ctypes.data, idx.size))
+
     # ---- env_base / env_map setters
     def set_control(self, control):
         """The control flag of the search (Waypoint::control of the start node)."""

@@ -234,7 +234,12 @@ class MapPlanner:
             idx = idx + mul * cells[:, i]
         mu.cells = mu.cells.copy()
         mu.cells[idx] = value
-        self.setMapUtil(mu)
+        # the planner's host copy (start / goal tests) and, on the device, only the edited cells (mplx_edit_map)
+        d = (C.c_int32 * 3)(*(mu.map_dim + [1] * (3 - len(mu.map_dim))))
+        o = (C.c_double * 3)(*(mu.origin + [0.0] * (3 - len(mu.origin))))
+        self._check(self._L.mplx_planner_set_map(self._p, mu.cells.ctypes.data, d, o, mu.res))
+        if self.env is not None:
+            self.env.editMap(idx, value)
         return cells
 
     def updateBlockedNodes(self, cells, edit_map=True):

@@ -150,3 +150,50 @@ def test_drop_in_adapter_runs_the_reference_api_on_the_device(case):
         a = O.search_region(md, org, res, path, sr, dense, ref="gpu")
         b = O.search_region(md, org, res, path, sr, dense)
         assert np.array_equal(a, b), "adapter region %s" % (sr,)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,with_region", [(2, False), (3, False), (3, True)])
+def test_edit_map_equals_a_full_upload(engine, oracle_lib, dim, with_region):
+    """mplx_edit_map (a few cells of the device's map patched in place, blocked bits with them, the free-box table
+    rebuilt lazily) against mplx_set_map with the edited array: the same lists from every list kernel -- small batches
+    (no free-box table after an edit) and a batch large enough to rebuild it -- and the same as the oracle on the edited map."""
+    from helpers import assert_lists_equal, engine_env, oracle_env
+    from test_gpu_parity import _small_world
+    wl = _small_world(engine, dim, 0x03, seed=8800 + dim, n_nodes=200, region=with_region)
+    rng = np.random.default_rng(3)
+    flat = np.ascontiguousarray(wl.grid).ravel().copy()
+    env = engine_env(engine, wl)
+    before = env.expand_lists(wl.nodes)            # (makes the blocked bits and the free-box table of the ORIGINAL map)
+    assert env.last_lists_route() == "grid"
+    # block cells around the nodes' own neighbourhoods, free some occupied ones
+    occ, free = np.nonzero(flat == 100)[0], np.nonzero(flat == 0)[0]
+    idx = np.concatenate([rng.choice(free, 400, replace=False), rng.choice(occ, 300, replace=False)])
+    val = np.concatenate([np.full(400, 100, np.int8), np.zeros(300, np.int8)])
+    env.editMap(idx, val)
+    flat[idx] = val
+    wl2 = _small_world(engine, dim, 0x03, seed=8800 + dim, n_nodes=200, region=with_region)
+    wl2.grid = flat.reshape(np.asarray(wl.grid).shape)
+    ref = oracle_lib.expand(oracle_env(wl2), wl.nodes, threads=8)
+    changed = False
+    for route in ("grid", "tile", "dense"):
+        env.set_lists_route(route)
+        got = env.expand_lists(wl.nodes)
+        assert_lists_equal(got, ref, wl.n_nodes, wl.U.shape[0], what="edited map, route %s" % route)
+        changed = changed or not np.array_equal(got["cost"], before["cost"]) or not np.array_equal(got["count"], before["count"])
+    assert changed, "the edit did not touch a single successor"
+    # a batch large enough for the free-box table to be rebuilt from the patched bits
+    env.set_lists_route("grid")
+    big = np.ascontiguousarray(np.tile(wl.nodes, (1, 25)))  # 5 000 nodes
+    got_big = env.expand_lists(big)
+    ref_big = oracle_lib.expand(oracle_env(wl2), big, threads=8)
+    assert_lists_equal(got_big, ref_big, big.shape[1], wl.U.shape[0], what="edited map, 5 000 nodes (free-box table rebuilt)")
+    # ... and the same context against a fresh one that got the edited array whole
+    env2 = engine_env(engine, wl2)
+    whole = env2.expand_lists(big)
+    for k in ("count", "action", "hash", "cost"):
+        assert np.array_equal(got_big[k], whole[k]), k
+    env2.close()
+    with pytest.raises(engine._abi.MplxError):
+        env.editMap([flat.size], [0])
+    env.close()
