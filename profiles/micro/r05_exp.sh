@@ -1,1 +1,1 @@
-timeout 600 python -m pytest tests/test_map_prep.py tests/test_lpastar.py tests/test_gpu_post.py -x -q -m gpu 2>&1 | grep -a "passed\|failed\|rc=\|Error\|assert\|what" | tail -8
+MPLX_PLAN_PASS_TIMING=1 MPLX_PLAN_TIMING=1 python profiles/plan_split.py --edges 120,160 --batches 256 --reps 4 2>&1 | grep "passes\|\^3" | cut -c1-300
