@@ -196,31 +196,56 @@ class LpaPlanner {
         if (need <= cap) break;
         cap = need;  // a row was truncated: once more with room for the longest
       }
-      for (int64_t e = 0; e < n; e++) {
-        for (int k = 0; k < cnt[(size_t)e]; k++) {
-          const int32_t id = cells[(size_t)e * cap + k];
-          lhm_[id].push_back(std::make_pair(owner[(size_t)e], slot[(size_t)e]));
-          if (points) {  // intToFloat(floatToInt(w.pos)), map_util.h:110-113: the cell's centre
-            int64_t r = id;
-            for (int i = 0; i < D; i++) {
-              const int64_t c = r % P.grid.n[i];
-              r /= P.grid.n[i];
-              points->push_back(((double)c + 0.5) * P.grid.res + P.grid.origin[i]);
-            }
+      // sweep 1: the distinct cells, sorted; sweep 2: every cell's entries in the order the edges were met
+      for (int64_t e = 0; e < n; e++) total += cnt[(size_t)e];
+      std::vector<int32_t> ids;
+      ids.reserve((size_t)total);
+      for (int64_t e = 0; e < n; e++)
+        for (int k = 0; k < cnt[(size_t)e]; k++) ids.push_back(cells[(size_t)e * cap + k]);
+      lhm_.key = ids;
+      std::sort(lhm_.key.begin(), lhm_.key.end());
+      lhm_.key.erase(std::unique(lhm_.key.begin(), lhm_.key.end()), lhm_.key.end());
+      const size_t nk = lhm_.key.size();
+      // (cell -> rank: a dense look-up table over the cells the edges touch, [min, max] of the sorted keys)
+      std::vector<int64_t> fill(nk + 1, 0);
+      const int32_t id_lo = nk ? lhm_.key.front() : 0, id_hi = nk ? lhm_.key.back() : -1;
+      std::vector<int32_t> rank;
+      const bool dense = nk && (int64_t)id_hi - id_lo < ((int64_t)1 << 28);
+      if (dense) {
+        rank.assign((size_t)((int64_t)id_hi - id_lo + 1), -1);
+        for (size_t k = 0; k < nk; k++) rank[(size_t)(lhm_.key[k] - id_lo)] = (int32_t)k;
+      }
+      auto rank_of = [&](int32_t id) -> size_t {
+        if (dense) return (size_t)rank[(size_t)(id - id_lo)];
+        return (size_t)(std::lower_bound(lhm_.key.begin(), lhm_.key.end(), id) - lhm_.key.begin());
+      };
+      std::vector<int32_t> rk(ids.size());
+      for (size_t q = 0; q < ids.size(); q++) { rk[q] = (int32_t)rank_of(ids[q]); fill[(size_t)rk[q] + 1]++; }
+      for (size_t k = 0; k < nk; k++) fill[k + 1] += fill[k];
+      lhm_.off = fill;
+      lhm_.ent.resize(ids.size());
+      {
+        size_t q = 0;
+        for (int64_t e = 0; e < n; e++)
+          for (int k = 0; k < cnt[(size_t)e]; k++, q++) lhm_.ent[(size_t)fill[(size_t)rk[q]]++] = std::make_pair(owner[(size_t)e], slot[(size_t)e]);
+      }
+      if (points) {  // intToFloat(floatToInt(w.pos)), map_util.h:110-113: the cell's centre, in the order of the edges
+        points->reserve(ids.size() * (size_t)D);
+        for (int32_t id : ids) {
+          int64_t r = id;
+          for (int i = 0; i < D; i++) {
+            const int64_t c = r % P.grid.n[i];
+            r /= P.grid.n[i];
+            points->push_back(((double)c + 0.5) * P.grid.res + P.grid.origin[i]);
           }
-          total++;
         }
       }
     }
     if (n_points) *n_points = total;
     return 0;
   }
-  size_t linked_cells() const { return lhm_.size(); }
-  int64_t linked_entries() const {
-    int64_t m = 0;
-    for (const auto &kv : lhm_) m += (int64_t)kv.second.size();
-    return m;
-  }
+  size_t linked_cells() const { return lhm_.cells(); }
+  int64_t linked_entries() const { return (int64_t)lhm_.ent.size(); }
 
   // MapPlanner::updateBlockedNodes (map_planner.cpp:160-171) + StateSpace::increaseCost (state_space.h:198-220).
   // cells: [n][D] integer cell coordinates.
@@ -372,7 +397,24 @@ class LpaPlanner {
   std::vector<std::unique_ptr<LNode>> pool_;
   Heap pq_;
   std::vector<LNode *> best_child_;
-  std::unordered_map<int32_t, std::vector<std::pair<LNode *, int32_t>>> lhm_;  // linkedHashMap, map_planner.h:15-17
+  // linkedHashMap (map_planner.h:15-17: cell index -> the (node, predecessor slot) pairs whose edge passes through the
+  // cell, in the order getLinkedNodes met them).  Only ever looked up by cell, never iterated: a compressed row
+  // storage built in two sweeps over the device's cell lists (1 M entries in a few ms where a hash map of vectors took
+  // 40) -- lhm_key_ sorted cell indices of the non-empty cells, lhm_off_ their entry ranges.
+  struct LinkedTable {
+    std::vector<int32_t> key;
+    std::vector<int64_t> off;  // [key.size() + 1]
+    std::vector<std::pair<LNode *, int32_t>> ent;
+    void clear() { key.clear(); off.clear(); ent.clear(); }
+    size_t cells() const { return key.size(); }
+    // entries of cell `id`: [first, last)
+    std::pair<const std::pair<LNode *, int32_t> *, const std::pair<LNode *, int32_t> *> find(int32_t id) const {
+      const auto it = std::lower_bound(key.begin(), key.end(), id);
+      if (it == key.end() || *it != id) return {nullptr, nullptr};
+      const size_t k = (size_t)(it - key.begin());
+      return {ent.data() + off[k], ent.data() + off[k + 1]};
+    }
+  } lhm_;
   bool ready_ = false;
   double start_g_ = 0, start_rhs_ = 0, start_t_ = 0;
   int expand_iteration_ = 0;  // StateSpace::expand_iteration_
@@ -417,9 +459,8 @@ class LpaPlanner {
       int c[3] = {0, 0, 0};
       for (int i = 0; i < P.dim; i++) c[i] = cells[(size_t)k * P.dim + i];
       const int32_t id = (int32_t)P.grid.index(c);  // MapUtil::getIndex
-      auto it = lhm_.find(id);
-      if (it != lhm_.end())
-        for (const auto &e : it->second) hit->push_back(e);
+      const auto range = lhm_.find(id);
+      for (const auto *e = range.first; e != range.second; e++) hit->push_back(*e);
     }
   }
 
