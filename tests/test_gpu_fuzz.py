@@ -30,12 +30,44 @@ def test_fuzz_slice_against_the_reference(engine, monkeypatch, block):
         env = engine_env(engine, wl)
         rtol = 1e-6 if control & 0x10 else 0.0  # xYAW: per-sample heading cost uses device trig (north_star: 1e-6)
         fr = env.upload_frontier(wl.nodes)
-        lists = env.alloc_lists(n_nodes, want_state=True, want_iters=True)
+        lists = env.alloc_lists(n_nodes, want_state=True, want_iters=True, want_heur=True, want_flags=True)
+        hb, fb = lists.heur, lists.flags
         for launch in range(2):
+            # the second launch also writes the search's per-successor rows (mplx_set_goal: heuristic, goal flags) --
+            # the lists themselves must not depend on them
+            fused = launch == 1
+            lists.heur, lists.flags = (hb, fb) if fused else (None, None)
+            if fused:
+                D = wl.dim
+                goal = np.ascontiguousarray(wl.nodes[:, int(rng.integers(0, n_nodes))])
+                tols = (float(rng.uniform(0.05, 2.0)), float(rng.choice([-1.0, 0.4, 3.0])), float(rng.choice([-1.0, 2.5])),
+                        float(rng.choice([-1.0, 0.7])))
+                w_h, v_h = float(rng.uniform(0.5, 12.0)), float(rng.choice([-1.0, 0.0, 1.7]))
+                env.set_goal(goal, w=w_h, v_max=v_h, tol_pos=tols[0], tol_vel=tols[1], tol_acc=tols[2], tol_yaw=tols[3])
             env.expand_lists_resident(fr, lists)
             env.synchronize()
-            assert_lists_equal(lists.download(), ref, n_nodes, wl.U.shape[0], cost_rtol=rtol,
+            got = lists.download()
+            assert_lists_equal(got, ref, n_nodes, wl.U.shape[0], cost_rtol=rtol,
                                what="fuzz seed %d launch %d route %s" % (seed, launch, env.last_lists_route()))
+            if fused:
+                # env_base.h:46-64 and env_map.h:25-37 restated on the successor states the same launch wrote
+                S = got["stride"]
+                live = (np.arange(S)[None, :] < got["count"][:, None]).ravel()
+                st = got["state"][:, live]
+                linf = lambda lo: np.abs(st[lo:lo + D] - goal[lo:lo + D, None]).max(axis=0)
+                m = linf(0)
+                same = got["hash"][live] == np.uint64(O.lattice_hash(D, control, goal))
+                want_h = np.where(same, 0.0, (w_h * m / v_h) if v_h > 0 else w_h * m)
+                assert np.array_equal(got["heur"][live], want_h), "fuzz seed %d: heur row" % seed
+                ok = m <= tols[0]
+                if tols[1] >= 0:
+                    ok &= linf(D) <= tols[1]
+                if tols[2] >= 0:
+                    ok &= linf(2 * D) <= tols[2]
+                if tols[3] >= 0:
+                    ok &= np.abs(st[4 * D] - goal[4 * D]) <= tols[3]
+                assert np.array_equal(got["flags"][live], ok.astype(np.uint8) | (same.astype(np.uint8) << 1)), "fuzz seed %d: flags row" % seed
+        lists.heur, lists.flags = hb, fb
         seen.add((wl.dim, control, env.last_lists_route(), pot is not None))
         lists.free()
         fr.free()
