@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import motion_primitive_library_amd as m  # noqa: E402
-from helpers import assert_lists_equal, engine_env, odd_world, oracle_env  # noqa: E402
+from helpers import assert_lists_equal, check_fused_rows, engine_env, odd_world, oracle_env  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -43,12 +43,26 @@ for seed in range(first, first + count):
         env = engine_env(m, wl)
         rtol = 1e-6 if control & 0x10 else 0.0
         fr = env.upload_frontier(wl.nodes)
-        lists = env.alloc_lists(n_nodes, want_state=True, want_iters=True)
+        lists = env.alloc_lists(n_nodes, want_state=True, want_iters=True, want_heur=True, want_flags=True)
+        hb, fb = lists.heur, lists.flags
         for launch in range(2):
+            # round 5: the second launch also writes the search's per-successor rows (mplx_set_goal: heuristic, goal flags)
+            fused = launch == 1
+            lists.heur, lists.flags = (hb, fb) if fused else (None, None)
+            if fused:
+                goal = np.ascontiguousarray(wl.nodes[:, int(rng.integers(0, n_nodes))])
+                tols = (float(rng.uniform(0.05, 2.0)), float(rng.choice([-1.0, 0.4, 3.0])), float(rng.choice([-1.0, 2.5])),
+                        float(rng.choice([-1.0, 0.7])))
+                w_h, v_h = float(rng.uniform(0.5, 12.0)), float(rng.choice([-1.0, 0.0, 1.7]))
+                env.set_goal(goal, w=w_h, v_max=v_h, tol_pos=tols[0], tol_vel=tols[1], tol_acc=tols[2], tol_yaw=tols[3])
             env.expand_lists_resident(fr, lists)
             env.synchronize()
-            assert_lists_equal(lists.download(), ref, n_nodes, wl.U.shape[0], cost_rtol=rtol,
+            got = lists.download()
+            assert_lists_equal(got, ref, n_nodes, wl.U.shape[0], cost_rtol=rtol,
                                what="seed %d launch %d route %s" % (seed, launch, env.last_lists_route()))
+            if fused:
+                check_fused_rows(got, goal, control, wl.dim, w_h, v_h, tols, what="seed %d" % seed)
+        lists.heur, lists.flags = hb, fb
         route = env.last_lists_route() + ("/" + env.last_grid_kernel() if env.last_lists_route() == "grid" else "")
         lists.free()
         fr.free()

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_lists_equal, engine_env, odd_world, oracle_env, require_reference_build
+from helpers import assert_lists_equal, check_fused_rows, engine_env, odd_world, oracle_env, require_reference_build
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -50,23 +50,7 @@ def test_fuzz_slice_against_the_reference(engine, monkeypatch, block):
             assert_lists_equal(got, ref, n_nodes, wl.U.shape[0], cost_rtol=rtol,
                                what="fuzz seed %d launch %d route %s" % (seed, launch, env.last_lists_route()))
             if fused:
-                # env_base.h:46-64 and env_map.h:25-37 restated on the successor states the same launch wrote
-                S = got["stride"]
-                live = (np.arange(S)[None, :] < got["count"][:, None]).ravel()
-                st = got["state"][:, live]
-                linf = lambda lo: np.abs(st[lo:lo + D] - goal[lo:lo + D, None]).max(axis=0)
-                m = linf(0)
-                same = got["hash"][live] == np.uint64(O.lattice_hash(D, control, goal))
-                want_h = np.where(same, 0.0, (w_h * m / v_h) if v_h > 0 else w_h * m)
-                assert np.array_equal(got["heur"][live], want_h), "fuzz seed %d: heur row" % seed
-                ok = m <= tols[0]
-                if tols[1] >= 0:
-                    ok &= linf(D) <= tols[1]
-                if tols[2] >= 0:
-                    ok &= linf(2 * D) <= tols[2]
-                if tols[3] >= 0:
-                    ok &= np.abs(st[4 * D] - goal[4 * D]) <= tols[3]
-                assert np.array_equal(got["flags"][live], ok.astype(np.uint8) | (same.astype(np.uint8) << 1)), "fuzz seed %d: flags row" % seed
+                check_fused_rows(got, goal, control, D, w_h, v_h, tols, what="fuzz seed %d" % seed)
         lists.heur, lists.flags = hb, fb
         seen.add((wl.dim, control, env.last_lists_route(), pot is not None))
         lists.free()
