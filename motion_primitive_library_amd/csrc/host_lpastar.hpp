@@ -202,26 +202,39 @@ class LpaPlanner {
       ids.reserve((size_t)total);
       for (int64_t e = 0; e < n; e++)
         for (int k = 0; k < cnt[(size_t)e]; k++) ids.push_back(cells[(size_t)e * cap + k]);
-      lhm_.key = ids;
-      std::sort(lhm_.key.begin(), lhm_.key.end());
-      lhm_.key.erase(std::unique(lhm_.key.begin(), lhm_.key.end()), lhm_.key.end());
-      const size_t nk = lhm_.key.size();
-      // (cell -> rank: a dense look-up table over the cells the edges touch, [min, max] of the sorted keys)
-      std::vector<int64_t> fill(nk + 1, 0);
-      const int32_t id_lo = nk ? lhm_.key.front() : 0, id_hi = nk ? lhm_.key.back() : -1;
-      std::vector<int32_t> rank;
-      const bool dense = nk && (int64_t)id_hi - id_lo < ((int64_t)1 << 28);
-      if (dense) {
-        rank.assign((size_t)((int64_t)id_hi - id_lo + 1), -1);
-        for (size_t k = 0; k < nk; k++) rank[(size_t)(lhm_.key[k] - id_lo)] = (int32_t)k;
-      }
-      auto rank_of = [&](int32_t id) -> size_t {
-        if (dense) return (size_t)rank[(size_t)(id - id_lo)];
-        return (size_t)(std::lower_bound(lhm_.key.begin(), lhm_.key.end(), id) - lhm_.key.begin());
-      };
+      // The distinct cells in ascending order and every cell's entry range: a counting pass over the span of cell
+      // indices the edges touch when that span is moderate (the usual case: a sort of a million indices was 40 of this
+      // call's 54 ms), a sort otherwise.
+      int32_t id_lo = 0x7fffffff, id_hi = (int32_t)0x80000000;
+      for (int32_t id : ids) { id_lo = id < id_lo ? id : id_lo; id_hi = id > id_hi ? id : id_hi; }
+      const bool dense = !ids.empty() && (int64_t)id_hi - id_lo < ((int64_t)1 << 26);
+      std::vector<int64_t> fill;
       std::vector<int32_t> rk(ids.size());
-      for (size_t q = 0; q < ids.size(); q++) { rk[q] = (int32_t)rank_of(ids[q]); fill[(size_t)rk[q] + 1]++; }
-      for (size_t k = 0; k < nk; k++) fill[k + 1] += fill[k];
+      if (dense) {
+        const size_t span = (size_t)((int64_t)id_hi - id_lo + 1);
+        std::vector<uint32_t> per_cell(span, 0u);
+        for (int32_t id : ids) per_cell[(size_t)(id - id_lo)]++;
+        std::vector<int32_t> rank(span, -1);
+        lhm_.key.clear();
+        fill.assign(1, 0);
+        for (size_t c = 0; c < span; c++)
+          if (per_cell[c]) {
+            rank[c] = (int32_t)lhm_.key.size();
+            lhm_.key.push_back((int32_t)((int64_t)c + id_lo));
+            fill.push_back(fill.back() + per_cell[c]);
+          }
+        for (size_t q = 0; q < ids.size(); q++) rk[q] = rank[(size_t)(ids[q] - id_lo)];
+      } else {
+        lhm_.key = ids;
+        std::sort(lhm_.key.begin(), lhm_.key.end());
+        lhm_.key.erase(std::unique(lhm_.key.begin(), lhm_.key.end()), lhm_.key.end());
+        fill.assign(lhm_.key.size() + 1, 0);
+        for (size_t q = 0; q < ids.size(); q++) {
+          rk[q] = (int32_t)(std::lower_bound(lhm_.key.begin(), lhm_.key.end(), ids[q]) - lhm_.key.begin());
+          fill[(size_t)rk[q] + 1]++;
+        }
+        for (size_t k = 0; k + 1 < fill.size(); k++) fill[k + 1] += fill[k];
+      }
       lhm_.off = fill;
       lhm_.ent.resize(ids.size());
       {
