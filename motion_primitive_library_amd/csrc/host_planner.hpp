@@ -601,6 +601,7 @@ class Planner {
   int set_prior_trajectory(const double *nodes, const int32_t *actions, int segs, int pcontrol, const double *pU, int pudim, double pdt) {
     clear_prior();
     if (segs <= 0) return 0;
+    if (!(dt > 0) || !(pdt > 0) || !(grid.res > 0)) return -1;  // (the loops below step by dt)
     const int f = F(), K = (pcontrol & 8) ? 4 : (pcontrol & 4) ? 3 : (pcontrol & 2) ? 2 : 1;
     // Primitive1D coefficient vectors of every segment and axis (primitive.h:34-50), highest order first
     std::vector<double> c((size_t)segs * dim * 6, 0.0), taus{0.0};
@@ -675,7 +676,7 @@ class Planner {
       for (int i = 0; i < dim; i++) m = std::max(m, std::abs(s[i] - b[i]));
       return v_max > 0 ? w * m / v_max : w * m;
     };
-    const size_t id = (size_t)(t / dt);  // env_base.h:48
+    const size_t id = t > 0 ? (size_t)(t / dt) : 0;  // env_base.h:48 (a size_t there: times are never negative)
     if (has_prior() && id < prior_togo.size()) return linf(&prior_pos[id * (size_t)dim]) + prior_togo[id];
     return linf(goal);
   }

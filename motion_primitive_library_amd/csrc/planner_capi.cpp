@@ -241,8 +241,9 @@ int mplx_planner_set_prior_trajectory(mplx_planner *p, const mplx_planner *from)
   if (from->pl.dim != p->pl.dim) return fail(p, MPLX_ERR_ARG, "mplx_planner_set_prior_trajectory: dimensions differ");
   if (p->pl.grid.cells.empty()) return fail(p, MPLX_ERR_STATE, "mplx_planner_set_prior_trajectory: set the map first");
   try {
-    p->pl.set_prior_trajectory(r.traj_nodes.data(), r.traj_actions.data(), (int)r.traj_actions.size(), from->pl.control,
-                               from->pl.U.data(), from->pl.udim, from->pl.dt);
+    if (p->pl.set_prior_trajectory(r.traj_nodes.data(), r.traj_actions.data(), (int)r.traj_actions.size(), from->pl.control,
+                                   from->pl.U.data(), from->pl.udim, from->pl.dt) != 0)
+      return fail(p, MPLX_ERR_STATE, "mplx_planner_set_prior_trajectory: configure dt (> 0) and the map of this planner first");
   } catch (...) {
     return fail(p, MPLX_ERR_NOMEM, "mplx_planner_set_prior_trajectory: out of host memory");
   }
