@@ -584,6 +584,69 @@ int run_lpastar(const mpl_oracle_env *e, const double *start_row, const double *
 
 }  // namespace
 
+/* ---- StateSpace::getSubStateSpace (state_space.h:116-195) through PlannerBase::getSubStateSpace (planner_base.h:155): plan
+ * with LPA*, re-root the tree at way point `time_step` of the trajectory (a robot that has executed that many
+ * primitives), plan again from there.  out2[0]: the first plan, out2[1]: the plan from the new root. ---- */
+namespace {
+template <int D>
+int run_substate(const mpl_oracle_env *e, const double *start_row, const double *goal_row, int time_step, mpl_ref_plan_out *out2,
+                 double *checksum2) {
+  std::shared_ptr<MPL::MapUtil<D>> mu = std::make_shared<MPL::MapUtil<D>>();
+  Vecf<D> ori;
+  Veci<D> dim;
+  size_t n = 1;
+  for (int i = 0; i < D; i++) { ori(i) = e->origin[i]; dim(i) = e->map_dim[i]; n *= (size_t)e->map_dim[i]; }
+  mu->setMap(ori, dim, MPL::Tmap(e->map, e->map + n), e->res);
+  vec_E<VecDf> U;
+  for (int i = 0; i < e->nU; i++) {
+    VecDf u(e->udim);
+    for (int k = 0; k < e->udim; k++) u(k) = e->U[(size_t)i * e->udim + k];
+    U.push_back(u);
+  }
+  auto load = [&](const double *r) {
+    Waypoint<D> w((Control::Control)e->control);
+    for (int i = 0; i < D; i++) { w.pos(i) = r[i]; w.vel(i) = r[D + i]; w.acc(i) = r[2 * D + i]; w.jrk(i) = r[3 * D + i]; }
+    w.yaw = r[4 * D];
+    w.t = r[4 * D + 1];
+    return w;
+  };
+  const Waypoint<D> start = load(start_row), goal = load(goal_row);
+  MPL::MapPlanner<D> pl(false);
+  pl.setMapUtil(mu);
+  pl.setVmax(e->v_max);
+  pl.setAmax(e->a_max);
+  pl.setJmax(e->j_max);
+  pl.setDt(e->dt);
+  pl.setW(e->w);
+  pl.setEpsilon(1.0);
+  pl.setU(U);
+  pl.setLPAstar(true);
+  for (int i = 0; i < 2; i++) { out2[i] = mpl_ref_plan_out{}; checksum2[i] = 0; }
+  auto t0 = std::chrono::steady_clock::now();
+  auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  bool ok = pl.plan(start, goal);
+  fill_out<D>(pl, ok, ms(), 0, &out2[0], &checksum2[0]);
+  if (!ok) return 0;
+  const auto wps = pl.getTraj().getWaypoints();
+  if (time_step < 0 || (size_t)time_step >= wps.size()) return -2;
+  pl.getSubStateSpace(time_step);
+  Waypoint<D> from = wps[(size_t)time_step];
+  from.control = start.control;  // (Trajectory::getWaypoints carries the primitives' control flag: the same here)
+  t0 = std::chrono::steady_clock::now();
+  ok = pl.plan(from, goal);
+  fill_out<D>(pl, ok, ms(), 0, &out2[1], &checksum2[1]);
+  return 0;
+}
+}  // namespace
+
+extern "C" int mpl_ref_lpastar_substate(const mpl_oracle_env *env, const double *start, const double *goal, int time_step,
+                                        mpl_ref_plan_out *out2, double *checksum2) {
+  if (!env || !start || !goal || !out2 || !checksum2) return -1;
+  if (env->dim == 2) return run_substate<2>(env, start, goal, time_step, out2, checksum2);
+  if (env->dim == 3) return run_substate<3>(env, start, goal, time_step, out2, checksum2);
+  return -1;
+}
+
 extern "C" int mpl_ref_lpastar(const mpl_oracle_env *env, const double *start, const double *goal, int use_gpu,
                                int box_half, mpl_ref_plan_out *out3, double *checksum3, int64_t *stats8) {
   if (!env || !start || !goal || !out3 || !checksum3 || !stats8) return -1;

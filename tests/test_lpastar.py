@@ -276,6 +276,13 @@ def test_engine_lpastar_sub_state_space_re_roots_the_tree(engine, which):
     tr2 = pl.getTraj()
     pl.close()
     del keep
+    if os.path.exists(O.REF_PLANNER_SO):
+        # ... and it is the reference's own re-rooting (getSubStateSpace rebuilds the open list in its hash map's order):
+        # both plans against MapPlanner::getSubStateSpace + plan of oracle/_ref
+        ref = O.ref_lpastar_substate(oenv, s, g, k)
+        for mine, theirs in ((first, ref[0]), (second, ref[1])):
+            for key in ("ok", "closed", "opened", "expansions", "cost", "segments", "total_time", "J"):
+                assert mine[key] == theirs[key], (which, key, mine[key], theirs[key])
     assert abs(second["cost"] - (first["cost"] - spent)) <= 1e-9 * first["cost"]
     assert second["segments"] == first["segments"] - k and np.array_equal(tr2.actions, tr.actions[k:])
     assert second["expansions"] < first["expansions"] / 4  # repaired, not searched again
