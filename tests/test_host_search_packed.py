@@ -38,3 +38,29 @@ def test_packed_search_equals_the_reference_planner(prof, edge, nu):
     assert ref["ok"] and ref["cost"] == r0["cost"] and ref["expansions"] == r0["expansions"]
     assert ref["closed"] == r0["closed"] and ref["opened"] == r0["opened"] and ref["segments"] == r0["segments"]
     assert ref["J"] == r0["J"] and ref["total_time"] == r0["total_time"]
+
+
+@pytest.mark.parametrize("eps", [1.0, 2.0])
+def test_packed_search_with_reopened_nodes_equals_the_reference(prof, eps):
+    """Without a velocity bound the default heuristic is w * distance (env_base.h:62), far above the true cost: closed
+    nodes are improved and pushed again (graph_search.h:108-141), some twice before their second pop -- two heap entries
+    of one node, handles and the live tie-break of csrc/host_planner.hpp::OpenList.  Same search as the reference's
+    planner, whatever the launch size."""
+    from test_plan_known_answer import corridor
+    import motion_primitive_library_amd as m
+    c = corridor()
+    U = m.workloads.grid_controls([-0.5, 0.0, 0.5], 2)
+    env = O.Env(2, O.ACC, U, c["cells"], c["dim"], c["origin"], c["res"], v_max=-1.0, a_max=1.0, dt=1.0)
+    start, goal = m.Waypoint(2, m.ACC, pos=c["start"]).to_row(), m.Waypoint(2, m.ACC, pos=c["goal"]).to_row()
+    runs = {b: prof.run(env, start, goal, batch=b, eps=eps, reps=2, threads=4) for b in (1, 32)}
+    r0 = runs[1][0]
+    assert r0["ok"] and r0["expansions"] > r0["closed"], r0  # the premise: nodes were expanded more than once
+    for b, rs in runs.items():
+        for r in rs:
+            for k in ("ok", "cost", "expansions", "closed", "opened", "nodes", "segments", "closed_checksum", "traj_checksum", "J"):
+                assert r[k] == r0[k], (b, k, r[k], r0[k])
+    if not os.path.exists(O.REF_PLANNER_SO):
+        pytest.skip("oracle/_ref/libmpl_ref_planner.so not built")
+    ref = O.ref_plan(env, start, goal, use_gpu=False, epsilon=eps)
+    for k in ("ok", "cost", "expansions", "closed", "opened", "segments", "J", "total_time"):
+        assert ref[k] == r0[k], (k, ref[k], r0[k])
