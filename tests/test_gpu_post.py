@@ -381,3 +381,70 @@ def test_fused_rows_through_host_pointers_and_the_service(engine):
         assert np.array_equal(heur[idx], np.where(same, 0.0, 10.0 * d / 2.0)), trial
         assert np.array_equal(flags[idx] & 1, (d <= 0.5).astype(np.uint8)) and np.array_equal((flags[idx] & 2) != 0, same)
     env.close()
+
+
+@pytest.mark.parametrize("form", ["claimed", "claimed_overflow", "sticky", "exact"])
+def test_identity_on_lists_without_state_rows_partition_forms(engine, monkeypatch, form):
+    """Lists of >= 256 k slots whose flags row the expansion launch wrote, node identity by the radix partition: canon[] and
+    the first-occurrence bit OR-ed into that row -- by the claimed form (the bit pass is queued before the host learns
+    whether a bucket overflowed), by the claimed form that DOES overflow (bits undone, exact form, bits again) and by the
+    exact form -- against the stand-alone pass on the same lists with state rows."""
+    import ctypes as C
+    from motion_primitive_library_amd import _abi
+    if form == "exact":
+        monkeypatch.setenv("MPLX_POST_CLAIMED", "0")
+    elif form == "sticky":
+        monkeypatch.delenv("MPLX_POST_CLAIMED", raising=False)  # the default choice, with its memory of an overflow
+    else:
+        monkeypatch.setenv("MPLX_POST_CLAIMED", "1")
+    if form in ("claimed_overflow", "sticky"):
+        monkeypatch.setenv("MPLX_POST_CAP", "64,64")
+    wl = engine.workloads.make("C4", scale=0.25, n_nodes=900)
+    wl.nodes[:, 450:] = wl.nodes[:, :450]  # every successor twice
+    env = engine.EnvMap(wl.dim, 0)
+    wl.apply(env)
+    fr = env.upload_frontier(wl.nodes)
+    goal = np.ascontiguousarray(wl.nodes[:, 7])
+    ref_lists = env.alloc_lists(wl.n_nodes, want_state=True)
+    env.expand_lists_resident(fr, ref_lists)
+    env.synchronize()
+    assert ref_lists.n_slots >= 1 << 18
+    want = env.post_lists(ref_lists, goal, w=10.0, v_max=2.0, tol_pos=0.6)
+    want_form = env.last_identity_form()
+    L = ref_lists.download()
+    idx = _emitted_indices(L)
+    env.set_goal(goal, w=10.0, v_max=2.0, tol_pos=0.6)
+    lists = env.alloc_lists(wl.n_nodes, want_state=False, want_heur=True, want_flags=True)
+    canon = engine.env.DeviceArray(env, lists.n_slots * 4)
+    g = _abi.GoalSpec()
+    g.goal, g.control, g.w, g.v_max = goal.ctypes.data, wl.control, 10.0, 2.0
+    g.tol_pos, g.tol_vel, g.tol_acc, g.tol_yaw = 0.6, -1.0, -1.0, -1.0
+    o = _abi.Post()
+    o.heur, o.flags, o.canon = None, lists.flags.ptr, canon.ptr
+    for rep in range(2):  # (the second call of a context after an overflow takes the exact form directly)
+        env.expand_lists_resident(fr, lists)
+        s = lists.c_struct()
+        _abi.check(env._ctx, _abi.lib().mplx_post_lists_device(env._ctx, C.byref(s), wl.n_nodes, C.byref(g), C.byref(o)))
+        env.synchronize()
+        got_form = env.last_identity_form()
+        got_canon = canon.download(np.int32, (lists.n_slots,))
+        got_flags = lists.flags.download(np.uint8, (lists.n_slots,))
+        got_heur = lists.heur.download(np.float64, (lists.n_slots,))
+        assert np.array_equal(got_canon[idx], want["canon"][idx]), (form, rep)
+        assert np.array_equal(got_flags[idx], want["flags"][idx]), (form, rep)
+        assert np.array_equal(got_heur[idx].view(np.uint64), want["heur"][idx].view(np.uint64))
+        assert 0 < np.count_nonzero(got_flags[idx] & 4) <= idx.size // 2  # duplicates: at most every second is a first
+        if form == "claimed":
+            assert got_form == "claimed"
+        elif form == "claimed_overflow":
+            assert got_form == "claimed+exact", got_form
+        elif form == "sticky":
+            # the stand-alone pass above was this context's first call: it overflowed, and the context remembers --
+            # its next calls take the exact form directly (and stay asynchronous)
+            assert want_form == "claimed+exact" and got_form == "exact", (rep, want_form, got_form)
+        else:
+            assert got_form == "exact"
+    canon.free()
+    for b in (lists, ref_lists, fr):
+        b.free()
+    env.close()
