@@ -1182,7 +1182,13 @@ class Planner {
       std::vector<int> &aux = aux_buf;
       aux.clear();
       if (!h.empty()) aux.push_back(0);
-      auto push = [&](int pos) { aux.push_back(pos); std::push_heap(aux.begin(), aux.end(), worse); };
+      // (a visited position reads its node's cold record -- has it lists already? -- a cache miss each at a million
+      // nodes: requested when the position enters the walk, two to three visits before it is looked at)
+      auto push = [&](int pos) {
+        __builtin_prefetch(&cold[h[(size_t)pos].idx]);
+        aux.push_back(pos);
+        std::push_heap(aux.begin(), aux.end(), worse);
+      };
       size_t visited = 0;
       while (!aux.empty() && group.size() - 1 < want && visited < 2 * want + 16) {
         std::pop_heap(aux.begin(), aux.end(), worse);
