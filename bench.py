@@ -1154,7 +1154,9 @@ def main():
                                     "fast_mode": {"ms": 0.480, "frac": 0.75}, "slow_mode": {"ms": 0.555, "frac": 0.65},
                                     "source": "profiles/r04_placement_per_box.txt (6 boxes, first allocations: 4 slow, 2 fast)"},
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_alg,
-                "issue_frac": bound_of(committed_counters(args.workload, out_kernel), kernel_ms, achieved / HBM_PEAK_GBS).get("issue_frac"),
+                # (the committed instruction count is that of the whole frontier in one launch: N = 1 only)
+                "issue_frac": (bound_of(committed_counters(args.workload, out_kernel), kernel_ms, achieved / HBM_PEAK_GBS).get("issue_frac")
+                               if world == 1 and args.scale == 1.0 and args.nodes is None and args.frontier == "random" else None),
                 # what a process that allocates its output lists ONCE and never probes measures: the first probe (after
                 # the clock spin-up, before any other allocation existed)
                 "ms_per_step_first_allocation": placement["probe_ms"][0] if placement["probe_ms"] else kernel_ms,
