@@ -1150,9 +1150,11 @@ def main():
                 "traffic_source": "committed rocprofv3 --pmc passes of this workload + kernel (profiles/), not collected in this run",
                 # the launch's time is the write bandwidth of the pages its 2.7 GB of list entries landed in, and that has
                 # two modes per allocation (profiles/README.md, rounds 2 - 4): this run's, and the committed figures of both
-                "placement_modes": {"this_run_ms": kernel_ms, "this_run_frac": achieved / HBM_PEAK_GBS,
-                                    "fast_mode": {"ms": 0.480, "frac": 0.75}, "slow_mode": {"ms": 0.555, "frac": 0.65},
-                                    "source": "profiles/r04_placement_per_box.txt (6 boxes, first allocations: 4 slow, 2 fast)"},
+                "placement_modes": ({"this_run_ms": kernel_ms, "this_run_frac": achieved / HBM_PEAK_GBS,
+                                     "fast_mode": {"ms": 0.480, "frac": 0.75}, "slow_mode": {"ms": 0.555, "frac": 0.65},
+                                     "source": "profiles/r04_placement_per_box.txt (6 boxes, first allocations: 4 slow, 2 fast); round 5: "
+                                               "profiles/r05_bench_c4_first.json (fast), r05_bench_c4_final.json (slow)"}
+                                    if args.workload == "C4" and world == 1 and args.scale == 1.0 and args.nodes is None else None),
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_alg,
                 # (the committed instruction count is that of the whole frontier in one launch: N = 1 only)
                 "issue_frac": (bound_of(committed_counters(args.workload, out_kernel), kernel_ms, achieved / HBM_PEAK_GBS).get("issue_frac")
