@@ -207,7 +207,9 @@ class LpaPlanner {
       // call's 54 ms), a sort otherwise.
       int32_t id_lo = 0x7fffffff, id_hi = (int32_t)0x80000000;
       for (int32_t id : ids) { id_lo = id < id_lo ? id : id_lo; id_hi = id > id_hi ? id : id_hi; }
-      const bool dense = !ids.empty() && (int64_t)id_hi - id_lo < ((int64_t)1 << 26);
+      // (two span-sized arrays: only while the span stays a small multiple of the entries -- stored edges on a 512^3 map
+      // can span tens of millions of cell indices while touching a few thousand cells)
+      const bool dense = !ids.empty() && (int64_t)id_hi - id_lo < ((int64_t)1 << 26) && (int64_t)id_hi - id_lo <= (int64_t)16 * (int64_t)ids.size();
       std::vector<int64_t> fill;
       std::vector<int32_t> rk(ids.size());
       if (dense) {
@@ -352,9 +354,20 @@ class LpaPlanner {
       curr = epq.top().n;
       epq.pop();
       for (size_t i = 0; i < curr->succ.size(); i++) {
-        LNode *sn = curr->succ[i];
-        LNode *&slot = new_hm[sn->key];
-        if (!slot) slot = sn;
+        // new_hm[succ_coord], else hm_[succ_coord] (state_space.h:152-153).  A stored pointer to a node that an EARLIER
+        // re-rooting dropped from hm_ is not that node any more: the reference prints "critical bug" and dereferences
+        // a null pointer there; here the coordinate gets a fresh node (g = rhs = inf, never opened).
+        LNode *&slot = new_hm[curr->succ[i]->key];
+        if (!slot) {
+          const auto it = hm_.find(curr->succ[i]->key);
+          if (it != hm_.end() && it->second) slot = it->second;
+          else {
+            slot = make(curr->succ[i]->coord, curr->succ[i]->key);
+            slot->h = curr->succ[i]->h;  // (same coordinate, same goal: the heuristic of the node it replaces)
+          }
+        }
+        LNode *sn = slot;
+        curr->succ[i] = sn;
         if (std::find(sn->pred.begin(), sn->pred.end(), curr) == sn->pred.end()) {
           sn->pred.push_back(curr);
           sn->pred_cost.push_back(curr->succ_cost[i]);
@@ -612,9 +625,13 @@ class LpaPlanner {
     double cost = kInf;
     bool finished = false;
     for (;;) {
-      // (the reference reads pq_.top() of an EMPTY queue here when nothing is left to repair: undefined there, "no
-      // trajectory" here)
-      if (pq_.empty()) break;
+      // (the reference reads pq_.top() of an EMPTY queue here when nothing is left to repair: undefined there.  Here:
+      // a goal node that is consistent with a finite g needs no repair -- its trajectory is recovered again; anything
+      // else is "no trajectory")
+      if (pq_.empty()) {
+        finished = goal_node != &dummy && goal_node->g == goal_node->rhs && !std::isinf(goal_node->g);
+        break;
+      }
       if (!(pq_.top().f < key_of(goal_node) || goal_node->rhs != goal_node->g)) { finished = true; break; }
       expand_iteration++;
       curr = pq_.top().n;
@@ -639,7 +656,17 @@ class LpaPlanner {
         double c_s;
         int32_t a_s;
         if (explored) {
-          sn = curr->succ[s];
+          // hm_[succ_coord[s]] of the reference (graph_search.h:285-290), not the stored pointer: getSubStateSpace drops
+          // the nodes it did not reach from hm_ and clears the queue, and a re-opened parent may still list one of them
+          // -- the reference then starts a FRESH State for that coordinate (g = rhs = inf, never opened).  The dropped
+          // node keeps opened / handle of the cleared queue: relaxing it would erase a stale heap position.
+          LNode *&slot = hm_[curr->succ[s]->key];
+          if (!slot) {
+            slot = make(curr->succ[s]->coord, curr->succ[s]->key);
+            slot->h = P.eps == 0 ? 0 : P.heur(slot->coord, goal);
+          }
+          sn = slot;
+          curr->succ[s] = sn;
           c_s = curr->succ_cost[s];
           a_s = curr->succ_act[s];
         } else {
@@ -671,7 +698,7 @@ class LpaPlanner {
     // getExpandedNum at the previous plan's figure)
     if (finished) expand_iteration_ = expand_iteration;
     last.expansions = expand_iteration_;
-    if (!finished) return 0;  // max expansions or an empty queue: infinite cost, the trajectory of the last plan stays
+    if (!finished) return 0;  // max expansions or an empty queue: infinite cost, no trajectory in `last` (ok = false)
     if (recover(goal_node, start_key)) {
       cost = goal_node->g - start_g_;
       last.ok = !std::isinf(cost);

@@ -385,6 +385,28 @@ def ref_lpastar_substate(env, start_row, goal_row, time_step):
              "cost": o.cost, "total_time": o.total_time, "J": list(o.J), "traj_checksum": chk[i]} for i, o in enumerate(out)]
 
 
+def ref_lpastar_edit_substate(env, start_row, goal_row, box_half, time_step):
+    """The reference's LPA*: plan, getLinkedNodes, block a box around the middle of the trajectory + updateBlockedNodes,
+    getSubStateSpace(time_step), plan from way point `time_step`.  Returns the two plans' summaries and the number of
+    edited cells."""
+    lib = _LIBS.setdefault("ref_planner", C.CDLL(REF_PLANNER_SO))
+    lib.mpl_ref_lpastar_edit_substate.restype = C.c_int
+    lib.mpl_ref_lpastar_edit_substate.argtypes = [C.POINTER(_Env), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                  C.POINTER(RefPlanOut), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    s = np.ascontiguousarray(start_row, dtype=np.float64)
+    g = np.ascontiguousarray(goal_row, dtype=np.float64)
+    out = (RefPlanOut * 2)()
+    chk = (C.c_double * 2)()
+    ed = C.c_int64(0)
+    ce = env._c()
+    rc = lib.mpl_ref_lpastar_edit_substate(C.byref(ce), s.ctypes.data, g.ctypes.data, int(box_half), int(time_step), out, chk,
+                                           C.byref(ed))
+    if rc != 0:
+        raise RuntimeError("mpl_ref_lpastar_edit_substate failed: %d" % rc)
+    return [{"ok": bool(o.ok), "closed": o.closed, "opened": o.opened, "expansions": o.expansions, "segments": o.segments,
+             "cost": o.cost, "total_time": o.total_time, "J": list(o.J), "traj_checksum": chk[i]} for i, o in enumerate(out)], ed.value
+
+
 def ref_lpastar(env, start_row, goal_row, use_gpu=False, box_half=3):
     """The reference's LPA* (PlannerBase::setLPAstar) with a map edit between plans: plan, getLinkedNodes, block a box
     of (2 box_half + 1)^D free cells around the middle of the trajectory + updateBlockedNodes, plan, clear the box +

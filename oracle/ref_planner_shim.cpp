@@ -639,6 +639,95 @@ int run_substate(const mpl_oracle_env *e, const double *start_row, const double 
 }
 }  // namespace
 
+/* ---- a map edit AND a re-rooting between two plans: plan, getLinkedNodes, block a box of free cells around the middle of
+ * the trajectory + updateBlockedNodes, getSubStateSpace(time_step), plan from way point `time_step`.  getSubStateSpace drops
+ * the nodes it does not reach from the hash map while re-opened parents still list them as successors
+ * (state_space.h:116-195, graph_search.h:285-290 look them up again).  out2[0]: first plan, out2[1]: the plan after both. ---- */
+namespace {
+template <int D>
+int run_edit_substate(const mpl_oracle_env *e, const double *start_row, const double *goal_row, int box_half, int time_step,
+                      mpl_ref_plan_out *out2, double *checksum2, int64_t *edited) {
+  std::shared_ptr<MPL::MapUtil<D>> mu = std::make_shared<MPL::MapUtil<D>>();
+  Vecf<D> ori;
+  Veci<D> dim;
+  size_t n = 1;
+  for (int i = 0; i < D; i++) { ori(i) = e->origin[i]; dim(i) = e->map_dim[i]; n *= (size_t)e->map_dim[i]; }
+  MPL::Tmap cells(e->map, e->map + n);
+  mu->setMap(ori, dim, cells, e->res);
+  vec_E<VecDf> U;
+  for (int i = 0; i < e->nU; i++) {
+    VecDf u(e->udim);
+    for (int k = 0; k < e->udim; k++) u(k) = e->U[(size_t)i * e->udim + k];
+    U.push_back(u);
+  }
+  auto load = [&](const double *r) {
+    Waypoint<D> w((Control::Control)e->control);
+    for (int i = 0; i < D; i++) { w.pos(i) = r[i]; w.vel(i) = r[D + i]; w.acc(i) = r[2 * D + i]; w.jrk(i) = r[3 * D + i]; }
+    w.yaw = r[4 * D];
+    w.t = r[4 * D + 1];
+    return w;
+  };
+  const Waypoint<D> start = load(start_row), goal = load(goal_row);
+  MPL::MapPlanner<D> pl(false);
+  pl.setMapUtil(mu);
+  pl.setVmax(e->v_max);
+  pl.setAmax(e->a_max);
+  pl.setJmax(e->j_max);
+  pl.setDt(e->dt);
+  pl.setW(e->w);
+  pl.setEpsilon(1.0);
+  pl.setU(U);
+  pl.setLPAstar(true);
+  for (int i = 0; i < 2; i++) { out2[i] = mpl_ref_plan_out{}; checksum2[i] = 0; }
+  *edited = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  bool ok = pl.plan(start, goal);
+  fill_out<D>(pl, ok, ms(), 0, &out2[0], &checksum2[0]);
+  if (!ok) return 0;
+  const auto wps = pl.getTraj().getWaypoints();
+  if (time_step < 0 || (size_t)time_step >= wps.size()) return -2;
+  pl.getLinkedNodes();
+  const Veci<D> mid = mu->floatToInt(wps[wps.size() / 2].pos);
+  const Veci<D> sc = mu->floatToInt(wps[(size_t)time_step].pos), gc = mu->floatToInt(goal.pos);
+  vec_Veci<D> edit;
+  {
+    Veci<D> pn;
+    const int w = 2 * box_half + 1;
+    int total = 1;
+    for (int i = 0; i < D; i++) total *= w;
+    for (int q = 0; q < total; q++) {
+      int r = q;
+      for (int i = 0; i < D; i++) { pn(i) = mid(i) + (r % w) - box_half; r /= w; }
+      if (mu->isOutside(pn) || !mu->isFree(pn)) continue;
+      bool near_s = true, near_g = true;
+      for (int i = 0; i < D; i++) { near_s = near_s && std::abs(pn(i) - sc(i)) <= 2; near_g = near_g && std::abs(pn(i) - gc(i)) <= 2; }
+      if (near_s || near_g) continue;
+      edit.push_back(pn);
+    }
+  }
+  *edited = (int64_t)edit.size();
+  for (const auto &pn : edit) cells[(size_t)mu->getIndex(pn)] = 100;
+  mu->setMap(ori, dim, cells, e->res);
+  pl.updateBlockedNodes(edit);
+  pl.getSubStateSpace(time_step);
+  Waypoint<D> from = wps[(size_t)time_step];
+  from.control = start.control;
+  t0 = std::chrono::steady_clock::now();
+  ok = pl.plan(from, goal);
+  fill_out<D>(pl, ok, ms(), 0, &out2[1], &checksum2[1]);
+  return 0;
+}
+}  // namespace
+
+extern "C" int mpl_ref_lpastar_edit_substate(const mpl_oracle_env *env, const double *start, const double *goal, int box_half,
+                                             int time_step, mpl_ref_plan_out *out2, double *checksum2, int64_t *edited) {
+  if (!env || !start || !goal || !out2 || !checksum2 || !edited) return -1;
+  if (env->dim == 2) return run_edit_substate<2>(env, start, goal, box_half, time_step, out2, checksum2, edited);
+  if (env->dim == 3) return run_edit_substate<3>(env, start, goal, box_half, time_step, out2, checksum2, edited);
+  return -1;
+}
+
 extern "C" int mpl_ref_lpastar_substate(const mpl_oracle_env *env, const double *start, const double *goal, int time_step,
                                         mpl_ref_plan_out *out2, double *checksum2) {
   if (!env || !start || !goal || !out2 || !checksum2) return -1;

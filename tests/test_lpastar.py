@@ -286,3 +286,72 @@ def test_engine_lpastar_sub_state_space_re_roots_the_tree(engine, which):
     assert abs(second["cost"] - (first["cost"] - spent)) <= 1e-9 * first["cost"]
     assert second["segments"] == first["segments"] - k and np.array_equal(tr2.actions, tr.actions[k:])
     assert second["expansions"] < first["expansions"] / 4  # repaired, not searched again
+
+
+@needs_ref
+@pytest.mark.parametrize("which,box,k", [("corridor", 1, 3), ("corridor", 3, 3), ("corridor", 5, 6), ("voxel", 2, 2)])
+def test_engine_lpastar_map_edit_then_re_rooting(engine, which, box, k):
+    """plan, getLinkedNodes, updateBlockedNodes, getSubStateSpace(k), plan -- a map edit COMBINED with re-rooting.
+    getSubStateSpace drops the nodes it does not reach from the hash map and clears the queue while a re-opened parent
+    still lists them as successors; the reference looks every successor up again (graph_search.h:285-290) and starts a
+    fresh State for a dropped one.  (An engine that relaxed the stored node instead erased a heap position of the
+    cleared queue: memory corruption, round-5 advisor.)  Both plans against the reference's own LPA*."""
+    m = engine
+    oenv, s, g = (corridor_problem if which == "corridor" else voxel_problem)(m)
+    oenv.map = oenv.map.copy()
+    ref, ref_edited = O.ref_lpastar_edit_substate(oenv, s, g, box, k)
+    prov, keep = _oracle_provider(oenv)
+    D = oenv.dim
+    cells = oenv.map
+    pl = m.MapPlanner(D, provider=prov[:3])
+    mu = m.MapUtil(D)
+    mu.setMap(oenv.origin[:D], oenv.map_dim[:D], cells, oenv.res)
+    mu.cells = cells
+    pl.setMapUtil(mu)
+    pl.setVmax(oenv.v_max)
+    pl.setAmax(oenv.a_max)
+    pl.setDt(oenv.dt)
+    pl.setU(oenv.U)
+    pl.setLPAstar(True)
+    pl.setEdgeProvider(prov[3], prov[2])
+    assert pl.plan(m.Waypoint.from_row(D, m.ACC, s), m.Waypoint.from_row(D, m.ACC, g))
+    first = pl.summary()
+    wps = pl.getTraj().getWaypoints()
+    pl.getLinkedNodes(want_points=False)
+    res, org, dims = oenv.res, np.array(oenv.origin[:D]), np.array(oenv.map_dim[:D])
+    c_round = lambda x: int(np.sign(x) * np.floor(abs(x) + 0.5))
+    to_cell = lambda p: np.array([c_round((p[i] - org[i]) / res - 0.5) for i in range(D)])
+    mid, sc, gc = to_cell(wps[len(wps) // 2][:D]), to_cell(wps[k][:D]), to_cell(g[:D])
+    w = 2 * box + 1
+    ecells, eidx = [], []
+    for q in range(w ** D):
+        r, pn = q, []
+        for i in range(D):
+            pn.append(mid[i] + (r % w) - box)
+            r //= w
+        pn = np.array(pn)
+        if np.any(pn < 0) or np.any(pn >= dims):
+            continue
+        idx = int(pn[0] + dims[0] * (pn[1] + (dims[1] * pn[2] if D == 3 else 0)))
+        if not (0 <= cells[idx] < 100):
+            continue
+        if np.all(np.abs(pn - sc) <= 2) or np.all(np.abs(pn - gc) <= 2):
+            continue
+        ecells.append(pn)
+        eidx.append(idx)
+    assert len(ecells) == ref_edited
+    cells[np.array(eidx, dtype=np.int64)] = 100
+    pl.setMapUtil(mu)
+    pl.updateBlockedNodes(np.array(ecells, dtype=np.int32), edit_map=False)
+    pl.getSubStateSpace(k)
+    ok = pl.plan(m.Waypoint.from_row(D, m.ACC, wps[k]), m.Waypoint.from_row(D, m.ACC, g))
+    second = pl.summary()
+    second["ok"], first["ok"] = ok, True
+    pl.close()
+    del keep
+    for mine, theirs in ((first, ref[0]), (second, ref[1])):
+        for key in ("ok", "closed", "opened", "expansions", "cost"):
+            assert mine[key] == theirs[key], (which, box, k, key, mine[key], theirs[key])
+        if mine["ok"]:
+            for key in ("segments", "total_time", "J"):
+                assert mine[key] == theirs[key], (which, key, mine[key], theirs[key])
