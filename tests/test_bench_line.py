@@ -1,0 +1,60 @@
+"""The ONE JSON line bench.py prints: from a long-form result (a committed bench output of round 5) the compact line
+must keep the contract's keys, `roofline`, `cpu_baseline`, the per-configuration numbers, and stay under 8 KB -- a record
+that keeps only the tail of stdout must keep all of it (round-5 review: the 30 KB line was cut)."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _long_form():
+    path = os.path.join(ROOT, "profiles", "r05_bench_c4_final.json")
+    return json.loads([l for l in open(path) if l.startswith("{")][-1])
+
+
+def test_compact_line_is_small_and_complete():
+    b = _bench()
+    long_form = _long_form()
+    assert len(json.dumps(long_form)) > 16000  # the problem being solved (the driver keeps 8 KB)
+    line = b.compact_line(long_form, "bench_detail.json")
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 8000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "detail"):
+        assert k in line, k
+    assert line["config"]["workload"].startswith("C4") and "model" not in line["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert abs(line["roofline"]["frac"] - long_form["roofline"]["frac"]) < 1e-5
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    for name in ("C2", "C3", "C5"):
+        e = line["other_configs"][name]
+        assert e["kernel_ms"] > 0 and "cpu_baseline" in e and "bound" in e and "issue_frac" in e
+    assert [c["gpus"] for c in line["strong_scaling_compute_bound"]] == [1, 2, 4, 8]
+    assert set(line["plan"]["3D_160"]["engine_host_search"]["timing_split"]) == {"provider_ms", "fill_ms", "pick_ms", "relax_ms", "recover_ms"}
+    # numbers only: no prose legs on the line
+    def walk(d, path=""):
+        for k, v in d.items():
+            assert k not in ("what", "timing", "speedup_note"), path + k
+            if isinstance(v, dict):
+                walk(v, path + k + ".")
+    walk(line)
+
+
+def test_compact_line_survives_failed_legs():
+    b = _bench()
+    long_form = _long_form()
+    long_form["wavefront"] = {"error": "RuntimeError: boom"}
+    long_form["other_configs"] = {"error": "x"}
+    long_form["plan"]["3D"] = {"error": "y"}
+    line = b.compact_line(long_form, "d.json")
+    assert line["wavefront"] == {"error": "RuntimeError: boom"} and line["plan"]["3D"] == {"error": "y"}
