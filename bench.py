@@ -564,7 +564,10 @@ def extra_plan(m):
                 rp[label] = {"plan1_ms": rp_[0]["wall_ms"], "plan2_ms": rp_[1]["wall_ms"], "plan3_ms": rp_[2]["wall_ms"],
                              "linked_nodes_ms": tb["get_linked_nodes_us"] / 1e3, "update_cleared_ms": tb["update_cleared_us"] / 1e3,
                              "plans": [{"ok": p_["ok"], "cost": p_["cost"], "expansions": p_["expansions"], "closed": p_["closed"]} for p_ in rp_],
-                             "table_cells": tb["cells"], "table_entries": tb["entries"], "edited_cells": tb["edited_cells"]}
+                             "table_cells": tb["cells"], "table_entries": tb["entries"], "edited_cells": tb["edited_cells"],
+                             # map bytes moved to the device by (updateBlockedNodes + plan 2), (updateClearedNodes + plan 3):
+                             # the adapter patches the edited cells (round 6; before: the whole map, twice)
+                             "replan_upload_bytes": tb.get("replan_upload_bytes")}
             ref = rp["reference_cpu"]
             rp["agree"] = bool(all(a == b for a, b in zip(plans, ref["plans"])) and n_cells == ref["table_cells"] and n_entries == ref["table_entries"])
             tot = lambda d: d["plan2_ms"] + d["plan3_ms"] + d["linked_nodes_ms"] + d["update_cleared_ms"]
@@ -887,8 +890,9 @@ def compact_line(out, detail_path):
                 if not isinstance(d, dict):
                     continue
                 e[who] = pick(d, ("wall_ms", "cost", "expansions", "launches", "potential_map_ms", "first_plan_ms", "plan1_ms",
-                                  "plan2_ms", "plan3_ms", "linked_nodes_ms", "update_blocked_ms", "update_cleared_ms",
-                                  "map_upload_bytes_per_replan"))
+                                  "plan2_ms", "plan3_ms", "linked_nodes_ms", "update_blocked_ms", "update_cleared_ms"))
+                if isinstance(d.get("replan_upload_bytes"), list):
+                    e[who]["replan_upload_bytes"] = d["replan_upload_bytes"]
                 ts = d.get("timing_split")
                 if isinstance(ts, dict):
                     e[who]["timing_split"] = {k: _r(ts.get(k), 4) for k in ("provider_ms", "fill_ms", "pick_ms", "relax_ms", "recover_ms")}

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MPLX_ABI_VERSION 8
+#define MPLX_ABI_VERSION 9
 
 typedef struct mplx_ctx mplx_ctx;
 
@@ -109,6 +109,11 @@ int mplx_set_map(mplx_ctx *ctx, const int8_t *cells, const int32_t *dim, const d
  * free-box table of the factorised kernels is rebuilt by the first launch of >= 4 096 nodes after the edit.  Same
  * results as mplx_set_map with the edited array (tests/test_map_prep.py).                                           */
 int mplx_edit_map(mplx_ctx *ctx, const int64_t *cell_index, const int8_t *values, int64_t n);
+/* ABI v9.  A cell named more than once in one mplx_edit_map call takes its LAST value (= mplx_set_map with the edited
+ * array).  Host -> device bytes the context's map calls have moved since mplx_create (mplx_set_map, _set_potential,
+ * _set_region: one byte per cell; mplx_edit_map: 9 bytes per edited cell): what a re-planning loop checks to see that an
+ * edit of k cells cost k cells, not the map (tests/test_lpastar.py).                                                   */
+int mplx_map_upload_bytes(mplx_ctx *ctx, uint64_t *bytes);
 
 /* env_map::set_potential_map, env_map.h:181-183.  NULL clears it.  Same size
  * as the map.                                                                */
@@ -458,6 +463,9 @@ int mplx_planner_set_provider(mplx_planner *p, mplx_succ_fn single, mplx_batch_f
 /* Host copy of the map for the start / goal tests (env_map.h:25-51).         */
 int mplx_planner_set_map(mplx_planner *p, const int8_t *cells, const int32_t *dim,
                          const double *origin, double res);
+/* ABI v9.  A few cells of that host copy take new values (the planner's side of mplx_edit_map: O(edited cells), not a
+ * second copy of the map per updateBlockedNodes / updateClearedNodes).  Last value wins for a repeated cell.          */
+int mplx_planner_edit_map(mplx_planner *p, const int64_t *cell_index, const int8_t *values, int64_t n);
 int mplx_planner_set_controls(mplx_planner *p, const double *U, int32_t nU, int32_t udim);
 int mplx_planner_configure(mplx_planner *p, const mplx_planner_config *cfg);
 /* start / goal: 4D+2 doubles each.  Returns 0 when the search ran (see
@@ -532,25 +540,13 @@ int mplx_planner_set_edge_provider(mplx_planner *p, mplx_edges_fn fn, void *user
  * the 3D problems of the bench line the row costs 3 % (8 bytes per successor over PCIe for a value 7 % of them need). */
 int mplx_planner_use_device_heuristic(mplx_planner *p, int on);
 
-/* ---- diagnostics -------------------------------------------------------- */
-/* The host search's evaluation of a successor state (Primitive<Dim>(node, u, dt).evaluate(dt),
- * primitive.h:220-256, 321-331): node and out 4D+2 doubles, u one row of the control table.  Pure host
- * arithmetic (no device needed); the tests compare it with the oracle and with the device's states.   */
-int mplx_selftest_forward_state(int32_t dim, int32_t control, const double *node, const double *u, double dt,
-                                double *out);
-/* Element-wise device evaluation of the libm-class operations the path uses,
- * for checking them against the host libm: op 0 a/b, 1 sqrt(a), 2 cos(a),
- * 3 sin(a), 4 round(a), 5 ceil(a).  Host pointers, n elements.               */
-int mplx_selftest_math(mplx_ctx *ctx, int op, const double *a, const double *b, double *out,
-                       int64_t n);
 /* Yaw controls: validate_yaw (primitive.h:504-525) compares with cos(yaw_max) and the reference's cos / sin are the
  * host libm's, the device's differ from them in the last place on a few per cent of arguments.  The engine therefore
  * flags every node with a heading-limit decision within rounding noise (2^-46) of its threshold and re-expands exactly
  * those nodes with trig values the HOST computes with its libm, at the next synchronising call (mplx_synchronize,
  * mplx_timer_end, mplx_memcpy_d2h, any host-pointer entry point): the successor SET is the reference's for every input,
  * not only for the tested ones.  The results of an asynchronous *_device launch are final after such a call.
- * Statistics since mplx_create: nodes flagged, fix passes launched (both 0 on the BASELINE configurations).        */
-int mplx_yaw_pin_stats(const mplx_ctx *ctx, int64_t *flagged_nodes, int64_t *fix_passes);
+ * (Statistics of that pass: mplx_yaw_pin_stats in mplx_debug.h.)                                                    */
 /* Which kernel serves mplx_expand_lists*: AUTO picks the fastest one that
  * covers the configuration (GRID: controls with <= 16 distinct values per axis,
  * no yaw, no potential, bounded velocity; TILE: any control table, otherwise the
@@ -574,13 +570,6 @@ int mplx_last_grid_kernel(const mplx_ctx *ctx);
  * claimed one followed by the exact one because a bucket overflowed (heavy duplication of few lattice states).      */
 enum { MPLX_IDENTITY_TABLE = 0, MPLX_IDENTITY_CLAIMED = 1, MPLX_IDENTITY_EXACT = 2, MPLX_IDENTITY_CLAIMED_THEN_EXACT = 3 };
 int mplx_last_identity_form(const mplx_ctx *ctx);
-/* ABI v6, diagnostic.  The list stores of an expansion launch on their own: for every node k the first count[k] entries
- * (rounded up to whole 128-byte lines as the kernels do) of every row present in d_lists are written with UNSPECIFIED
- * values, in the expansion kernels' order and with their store policy; count[] is read, not written.  A launch whose
- * lists stay in HBM is bound by exactly this once its arithmetic is cheaper (C4: DESIGN.md 5), and how long it takes
- * depends on the memory behind the allocation: bench.py times it on the lists of the timed launches
- * (roofline.store_only_ms).  Asynchronous on the context's stream.  OVERWRITES the successor entries.               */
-int mplx_debug_store_model(mplx_ctx *ctx, const mplx_succ_lists *d_lists, int64_t n_nodes);
 /* The service: how mplx_expand_lists (and mplx_get_succ, which calls it) serves
  * the small synchronous batches of a search -- at most MPLX_SERVICE_MAX_NODES
  * (256) nodes, control tables without yaw, no potential map, bounded velocity.

@@ -37,7 +37,8 @@
 // (map_planner.cpp:125-157, 174-185) walk every stored edge with Primitive::sample /
 // env_map::is_free(Primitive); GpuMapPlanner shadows both with ONE batched device call
 // each (mplx_check_edges) and leaves lhm_ and the state space exactly as the
-// reference's loops would (updateBlockedNodes is pure host bookkeeping and is inherited).
+// reference's loops would; updateBlockedNodes runs the reference's bookkeeping unchanged.  All three also hand the
+// edited cells to the device copy of the map (mplx_edit_map), so a re-plan after an edit of k cells uploads k cells.
 // Errors never throw: a failed device call prints the engine's message, latches it
 // (device_ok() / device_error(); GpuMapPlanner::plan then returns false with the
 // message instead of looking like "no trajectory exists") and returns an empty
@@ -97,11 +98,42 @@ class env_map_hip : public env_map<Dim> {
   bool record_edges() const { return record_edges_ < 0 ? batch_ <= 1 : record_edges_ != 0; }
   int launches() const { return launches_; }
   /// Re-upload the map / potential / region before the next expansion.
-  void notify_map_changed() { maps_stale_ = true; }
+  void notify_map_changed() { maps_stale_ = true; cells_synced_ = false; }
+  /// The application has edited exactly these cells of the MapUtil since the maps were last in step (the incremental
+  /// loop of map_planner.cpp:160-185: edit, updateBlockedNodes / updateClearedNodes, plan): the device copy is patched
+  /// with their current values (mplx_edit_map: 9 bytes per cell, blocked bits included) instead of being uploaded
+  /// whole, and the NEXT plan() does not mark the maps stale -- it has just been told what changed.  A plan() without
+  /// such a call before it uploads the map as before (an application may have edited the MapUtil in place).
+  bool edit_cells(const vec_Veci<Dim> &pns) const {
+    if (!ctx_) return latch("no device context (mplx_create failed)");
+    if (maps_stale_) return true;  // a whole upload is pending (never uploaded, or notify_map_changed): it carries the edit
+    const Tmap &cells = peek_map();
+    std::vector<int64_t> idx;
+    std::vector<int8_t> val;
+    idx.reserve(pns.size());
+    val.reserve(pns.size());
+    for (const auto &pn : pns) {
+      if (this->map_util_->isOutside(pn)) continue;
+      const int id = this->map_util_->getIndex(pn);
+      idx.push_back(id);
+      val.push_back(cells[(size_t)id]);
+    }
+    drop_cache();
+    if (!idx.empty() && mplx_edit_map(ctx_, idx.data(), val.data(), (int64_t)idx.size()) != MPLX_OK) return complain();
+    cells_synced_ = true;
+    return true;
+  }
+  /// Host -> device bytes this env's map calls have moved so far (mplx_map_upload_bytes).
+  uint64_t map_upload_bytes() const {
+    uint64_t b = 0;
+    if (ctx_) mplx_map_upload_bytes(ctx_, &b);
+    return b;
+  }
 
   /// First virtual call of every PlannerBase::plan (planner_base.h:283).
   bool is_free(const Vecf<Dim> &pt) const override {
-    maps_stale_ = true;
+    if (cells_synced_) cells_synced_ = false;  // (one plan: the edit the application named is on the device already)
+    else maps_stale_ = true;
     return env_map<Dim>::is_free(pt);
   }
   bool is_free(const Primitive<Dim> &pr) const override { return env_map<Dim>::is_free(pr); }
@@ -486,6 +518,13 @@ class env_map_hip : public env_map<Dim> {
     return h;
   }
 
+  // MapUtil::map_ without the copy getMap() makes: a pointer to the protected member, formed through a derived class
+  // (the standard's own rule for protected access), applied to the MapUtil itself
+  struct MapPeek : MapUtil<Dim> {
+    static const Tmap &of(const MapUtil<Dim> &m) { return m.*(&MapPeek::map_); }
+  };
+  const Tmap &peek_map() const { return MapPeek::of(*this->map_util_); }
+
   bool sync_maps() const {
     {
       const uint64_t fp = region_fingerprint();
@@ -496,7 +535,7 @@ class env_map_hip : public env_map<Dim> {
       drop_cache();
       const Veci<Dim> dim = this->map_util_->getDim();
       const Vecf<Dim> ori = this->map_util_->getOrigin();
-      const Tmap cells = this->map_util_->getMap();
+      const Tmap &cells = peek_map();  // (MapUtil::getMap returns a copy: 128 MiB at 512^3)
       int32_t d[3] = {1, 1, 1};
       double o[3] = {0, 0, 0};
       for (int i = 0; i < Dim; i++) { d[i] = dim(i); o[i] = ori(i); }
@@ -557,6 +596,7 @@ class env_map_hip : public env_map<Dim> {
   mutable std::string first_error_;
   mutable uint64_t region_fp_ = 0;
   mutable bool maps_stale_ = true, have_params_ = false;
+  mutable bool cells_synced_ = false;  // edit_cells has patched the device copy since the last plan() started
   mutable mplx_params params_{};
   mutable std::vector<double> flatU_, sentU_, buf_succ_, buf_cost_;
   mutable std::vector<int32_t> buf_act_;
@@ -696,6 +736,16 @@ class GpuMapPlanner : public MapPlanner<Dim> {
     return linked_pts;
   }
 
+  /// Shadows MapPlanner::updateBlockedNodes (map_planner.cpp:160-171): the reference's host bookkeeping unchanged
+  /// (increaseCost over lhm_), plus the cells themselves -- the application has just blocked them in the MapUtil --
+  /// patched into the device copy (env_map_hip::edit_cells) instead of a whole-map upload at the next plan().
+  void updateBlockedNodes(const vec_Veci<Dim> &blocked_pns) {
+    MapPlanner<Dim>::updateBlockedNodes(blocked_pns);
+    env()->edit_cells(blocked_pns);
+  }
+  /// Host -> device bytes of the env's map calls so far (a re-plan after an edit of k cells moves 9 k).
+  uint64_t mapUploadBytes() const { return this->ENV_ ? env()->map_upload_bytes() : 0; }
+
   /// Shadows MapPlanner::updateClearedNodes (map_planner.cpp:174-185) + StateSpace::decreaseCost
   /// (state_space.h:230-253): the affected edges are re-validated in ONE device call (is_free(Primitive) and
   /// calculate_intrinsic_cost), then the state space is updated by the reference's own statements in the
@@ -709,6 +759,9 @@ class GpuMapPlanner : public MapPlanner<Dim> {
       if (search != this->lhm_.end())
         for (const auto &node : search->second) cleared_nodes.push_back(node);
     }
+    // the cells were cleared in the MapUtil: patched into the device copy (not a whole-map upload) before the edges
+    // through them are re-validated there
+    env()->edit_cells(cleared_pns);
     const size_t n = cleared_nodes.size();
     if (n == 0) return;
     auto &hm = this->ss_ptr_->hm_;
@@ -722,7 +775,6 @@ class GpuMapPlanner : public MapPlanner<Dim> {
       for (int f = 0; f < F; f++) parents[(size_t)f * n + e] = row[f];
       actions[e] = succ->pred_action_id[i];
     }
-    env()->notify_map_changed();  // the cells were cleared in the MapUtil: the device copy is stale
     std::vector<uint8_t> free_flag;
     std::vector<double> cost;
     if (!env()->device_check_edges(cleared_nodes[0].first.control, parents, actions, &free_flag, &cost, nullptr, nullptr,

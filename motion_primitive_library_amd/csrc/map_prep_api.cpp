@@ -8,6 +8,8 @@
 #include <array>
 #include <cmath>
 #include <cstring>
+#include <unordered_map>
+#include <vector>
 
 using namespace mplx_detail;
 
@@ -28,6 +30,30 @@ int mplx_edit_map(mplx_ctx *c, const int64_t *cell_index, const int8_t *values, 
     if (cell_index[i] < 0 || cell_index[i] >= c->n_cells)
       return fail(c, MPLX_ERR_ARG, "mplx_edit_map: cell index %lld outside the map of %lld cells", (long long)cell_index[i], (long long)c->n_cells);
   if (n == 0) return MPLX_OK;
+  // A cell named twice takes its LAST value (what mplx_set_map with the edited array would hold): the kernel writes the
+  // cell and its blocked bit from independent threads, so duplicates with different values must not reach it.
+  std::vector<int64_t> u_idx;
+  std::vector<int8_t> u_val;
+  {
+    bool sorted_unique = true;
+    for (int64_t i = 1; i < n && sorted_unique; i++) sorted_unique = cell_index[i] > cell_index[i - 1];
+    if (!sorted_unique) {
+      try {
+        std::unordered_map<int64_t, int64_t> last;  // cell -> position of its last mention
+        last.reserve((size_t)n * 2);
+        for (int64_t i = 0; i < n; i++) last[cell_index[i]] = i;
+        if ((int64_t)last.size() < n) {
+          u_idx.reserve(last.size());
+          u_val.reserve(last.size());
+          for (int64_t i = 0; i < n; i++)
+            if (last[cell_index[i]] == i) { u_idx.push_back(cell_index[i]); u_val.push_back(values[i]); }
+          cell_index = u_idx.data();
+          values = u_val.data();
+          n = (int64_t)u_idx.size();
+        }
+      } catch (...) { return fail(c, MPLX_ERR_NOMEM, "mplx_edit_map: out of host memory"); }
+    }
+  }
   if (int rc = bind_device(c)) return rc;
   if (int rc = resolve_pending(c)) return rc;  // a pending launch read the old cells
   if (int rc = svc_stop(c)) return rc;         // a resident kernel may hold the old cells in its XCD's L2
@@ -36,6 +62,7 @@ int mplx_edit_map(mplx_ctx *c, const int64_t *cell_index, const int8_t *values, 
   char *d = (char *)c->edit_buf.p;
   HIP_TRY(c, hipMemcpyAsync(d, cell_index, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(d + ib, values, (size_t)n, hipMemcpyHostToDevice, c->stream));
+  c->map_upload_bytes += (uint64_t)n * 9;
   // the blocked bits follow the occupancy map cell by cell; with a potential map installed they are derived from THAT
   // map (env_map.h:113-118 does not consult the occupancy), so the occupancy edit leaves them alone
   uint32_t *blk = (c->blk_ok && !c->has_pot) ? (uint32_t *)c->blk.p : nullptr;
@@ -48,6 +75,12 @@ int mplx_edit_map(mplx_ctx *c, const int64_t *cell_index, const int8_t *values, 
     c->sat_ok = false;
     c->sat_stale = true;
   }
+  return MPLX_OK;
+}
+
+int mplx_map_upload_bytes(mplx_ctx *c, uint64_t *bytes) {
+  if (!c || !bytes) return MPLX_ERR_ARG;
+  *bytes = c->map_upload_bytes;
   return MPLX_OK;
 }
 

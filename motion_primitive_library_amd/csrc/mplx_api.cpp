@@ -235,6 +235,7 @@ int mplx_set_map(mplx_ctx *c, const int8_t *cells, const int32_t *dim, const dou
   }
   if (int rc = ensure(c, c->map, (size_t)n)) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->map.p, cells, (size_t)n, hipMemcpyHostToDevice, c->stream));
+  c->map_upload_bytes += (uint64_t)n;
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller may free `cells` on return
   for (int i = 0; i < 3; i++) {
     c->mdim[i] = i < c->dim ? dim[i] : 1;
@@ -255,6 +256,7 @@ int mplx_set_potential(mplx_ctx *c, const int8_t *cells) {
   if (int rc = bind_device(c)) return rc;
   if (int rc = ensure(c, c->pot, (size_t)c->n_cells)) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->pot.p, cells, (size_t)c->n_cells, hipMemcpyHostToDevice, c->stream));
+  c->map_upload_bytes += (uint64_t)c->n_cells;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->has_pot = true;
   c->blk_ok = false;
@@ -271,6 +273,7 @@ int mplx_set_region(mplx_ctx *c, const uint8_t *cells) {
   if (int rc = ensure(c, c->region_bytes, (size_t)c->n_cells)) return rc;
   if (int rc = ensure(c, c->region_bits, words * 4)) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->region_bytes.p, cells, (size_t)c->n_cells, hipMemcpyHostToDevice, c->stream));
+  c->map_upload_bytes += (uint64_t)c->n_cells;
   HIP_TRY(c, mplx::launch_pack_region((const uint8_t *)c->region_bytes.p, (uint32_t *)c->region_bits.p,
                                       c->n_cells, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -4,6 +4,7 @@
 #define MPLX_CTX_H
 
 #include "../../include/mplx.h"
+#include "../../include/mplx_debug.h"
 #include "mplx_internal.h"
 
 #include <cstdarg>
@@ -41,6 +42,7 @@ struct mplx_ctx {
   double origin[3] = {0, 0, 0};
   double res = 0;
   int64_t n_cells = 0;
+  uint64_t map_upload_bytes = 0;  // host -> device bytes of mplx_set_map / _set_potential / _set_region / _edit_map so far
   mplx_params prm{};
   int32_t nU = 0, udim = 0;
   double u_absmax = 0;  // max |u| over the spatial control entries

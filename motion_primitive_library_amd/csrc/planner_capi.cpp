@@ -1,6 +1,7 @@
 // planner_capi.cpp -- C entry points of the host search (include/mplx.h,
 // "host search" section) on top of host_planner.hpp.
 #include "../../include/mplx.h"
+#include "../../include/mplx_debug.h"
 #include "host_planner.hpp"
 #include "host_lpastar.hpp"
 #include "mplx_ctx.h"
@@ -142,6 +143,17 @@ int mplx_planner_set_map(mplx_planner *p, const int8_t *cells, const int32_t *di
   }
   p->pl.grid.res = res;
   try { p->pl.grid.cells.assign(cells, cells + n); } catch (...) { return fail(p, MPLX_ERR_NOMEM, "mplx_planner_set_map: out of host memory"); }
+  return MPLX_OK;
+}
+
+int mplx_planner_edit_map(mplx_planner *p, const int64_t *cell_index, const int8_t *values, int64_t n) {
+  if (!p) return MPLX_ERR_ARG;
+  if (n < 0 || (n > 0 && (!cell_index || !values))) return fail(p, MPLX_ERR_ARG, "mplx_planner_edit_map: bad arguments");
+  const int64_t n_cells = (int64_t)p->pl.grid.cells.size();
+  if (n_cells == 0 && n > 0) return fail(p, MPLX_ERR_STATE, "mplx_planner_edit_map: set the map first");
+  for (int64_t i = 0; i < n; i++)
+    if (cell_index[i] < 0 || cell_index[i] >= n_cells) return fail(p, MPLX_ERR_ARG, "mplx_planner_edit_map: cell index outside the map");
+  for (int64_t i = 0; i < n; i++) p->pl.grid.cells[(size_t)cell_index[i]] = values[i];  // in order: the last value of a repeated cell stays
   return MPLX_OK;
 }
 

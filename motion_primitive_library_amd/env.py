@@ -396,6 +396,12 @@ class EnvMap:
             raise ValueError("editMap: %d indices, %d values" % (idx.size, val.size))
         _abi.check(self._ctx, _abi.lib().mplx_edit_map(self._ctx, idx.ctypes.data, val.ctypes.data, idx.size))
 
+    def map_upload_bytes(self):
+        """Host -> device bytes the map calls of this context have moved so far (mplx_map_upload_bytes)."""
+        b = C.c_uint64(0)
+        _abi.check(self._ctx, _abi.lib().mplx_map_upload_bytes(self._ctx, C.byref(b)))
+        return int(b.value)
+
     # ---- env_base / env_map setters
     def set_control(self, control):
         """The control flag of the search (Waypoint::control of the start node)."""

@@ -232,14 +232,16 @@ class MapPlanner:
         for i in range(1, self.dim):
             mul *= mu.map_dim[i - 1]
             idx = idx + mul * cells[:, i]
-        mu.cells = mu.cells.copy()
+        # O(edited cells) everywhere: the MapUtil's array in place (copied once, only if it cannot be written), the
+        # planner's host copy (start / goal tests) through mplx_planner_edit_map, the device through mplx_edit_map
+        if not mu.cells.flags.writeable:
+            mu.cells = mu.cells.copy()
         mu.cells[idx] = value
-        # the planner's host copy (start / goal tests) and, on the device, only the edited cells (mplx_edit_map)
-        d = (C.c_int32 * 3)(*(mu.map_dim + [1] * (3 - len(mu.map_dim))))
-        o = (C.c_double * 3)(*(mu.origin + [0.0] * (3 - len(mu.origin))))
-        self._check(self._L.mplx_planner_set_map(self._p, mu.cells.ctypes.data, d, o, mu.res))
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        val = np.full(idx.size, value, dtype=np.int8)
+        self._check(self._L.mplx_planner_edit_map(self._p, idx.ctypes.data, val.ctypes.data, idx.size))
         if self.env is not None:
-            self.env.editMap(idx, value)
+            self.env.editMap(idx, val)
         return cells
 
     def updateBlockedNodes(self, cells, edit_map=True):

@@ -271,6 +271,33 @@ def make(name, scale=1.0, n_nodes=None, potential_fn=None, shell=False):
         return Workload("C5", 3, ACCxYAW, pot, [0, 0, 0], 0.1, U, nodes,
                         {"v_max": 2.0, "yaw_max": 0.5, "potential_weight": 0.5, "gradient_weight": 0.0},
                         potential=pot)
+    # ---- parity-only configurations at BASELINE size (round 6): the controls BASELINE's four do not exercise
+    if name == "C3-SNP":
+        # C3's map, Control::SNP (state pos / vel / acc / jrk), 5^3 snap controls: primitive.h:117-119, 152-193 with
+        # math.h:22-32 (quad) at full size
+        edge = max(16, int(256 * scale))
+        grid = box_map([edge] * 3, 0.1, 0.15, 1003)
+        U = grid_controls([-2, -1, 0, 1, 2], 3)
+        nodes = random_frontier(grid, [0, 0, 0], 0.1, n_nodes or 16384, 2013, SNP, 3.0, 0.5, 2.0, 0.5, 2.0, 1.0)
+        return Workload("C3-SNP", 3, SNP, grid, [0, 0, 0], 0.1, U, nodes, {"v_max": 3.0, "a_max": 2.0, "j_max": 2.0})
+    if name == "C2-VEL":
+        # C2's map, Control::VEL (state = position only), 5^2 velocity controls up to 2 m/s
+        edge = max(32, int(1024 * scale))
+        grid = box_map([edge, edge], 0.1, 0.20, 1002)
+        U = grid_controls([-2, -1, 0, 1, 2], 2)
+        nodes = random_frontier(grid, [0, 0], 0.1, n_nodes or 4096, 2012, VEL, 2.0, 0.5)
+        return Workload("C2-VEL", 2, VEL, grid, [0, 0], 0.1, U, nodes, {"v_max": 2.0})
+    if name == "C2-YAWPOT":
+        # C2's map with a potential field, Control::ACCxYAW, 3^2 x 3 controls: the 2D DistanceMapPlanner of
+        # test/test_distance_map_planner_2d_with_yaw.cpp at C2's size
+        edge = max(32, int(1024 * scale))
+        grid = box_map([edge, edge], 0.1, 0.20, 1002)
+        pot = (potential_field(grid, 0.1, 1.0) if potential_fn is None
+               else np.ascontiguousarray(potential_fn(grid, [0, 0], 0.1, [1.0, 1.0]), dtype=np.int8))
+        U = grid_controls([-1, 0, 1], 2, yaw_rates=[-0.5, 0, 0.5])
+        nodes = random_frontier(pot, [0, 0], 0.1, n_nodes or 4096, 2015, ACCxYAW, 2.0, 0.5)
+        return Workload("C2-YAWPOT", 2, ACCxYAW, pot, [0, 0], 0.1, U, nodes,
+                        {"v_max": 2.0, "yaw_max": 0.5, "potential_weight": 0.5, "gradient_weight": 0.0}, potential=pot)
     raise ValueError("unknown workload %r" % name)
 
 

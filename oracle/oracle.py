@@ -421,7 +421,7 @@ def ref_lpastar(env, start_row, goal_row, use_gpu=False, box_half=3):
     g = np.ascontiguousarray(goal_row, dtype=np.float64)
     out = (RefPlanOut * 3)()
     chk = (C.c_double * 3)()
-    st = (C.c_int64 * 8)()
+    st = (C.c_int64 * 10)()
     ce = env._c()
     rc = lib.mpl_ref_lpastar(C.byref(ce), s.ctypes.data, g.ctypes.data, int(use_gpu), int(box_half), out, chk, st)
     if rc != 0:
@@ -434,5 +434,7 @@ def ref_lpastar(env, start_row, goal_row, use_gpu=False, box_half=3):
                       "wall_ms": o.wall_ms, "traj_checksum": chk[i]})
     lp = np.array([st[4]], dtype=np.int64).view(np.float64)[0]
     table = {"cells": st[0], "entries": st[1], "checksum": st[2], "linked_points": st[3], "points_checksum": float(lp),
-             "edited_cells": st[5], "get_linked_nodes_us": st[6], "update_cleared_us": st[7]}
+             "edited_cells": st[5], "get_linked_nodes_us": st[6], "update_cleared_us": st[7],
+             # GpuMapPlanner only: map bytes moved to the device by (updateBlockedNodes + plan 2), (updateClearedNodes + plan 3)
+             "replan_upload_bytes": [st[8], st[9]]}
     return plans, table

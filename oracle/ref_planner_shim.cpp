@@ -459,9 +459,15 @@ struct PeekPlanner : Base {  // lhm_ is protected
   using Base::lhm_;
 };
 
+// host -> device bytes the planner's env has moved for its maps (MPL::GpuMapPlanner::mapUploadBytes; 0 for the CPU planner)
+template <class P>
+auto upload_bytes(const P &p, int) -> decltype(p.mapUploadBytes()) { return p.mapUploadBytes(); }
+template <class P>
+uint64_t upload_bytes(const P &, long) { return 0; }
+
 template <int D, class PlannerT>
 int run_lpastar(const mpl_oracle_env *e, const double *start_row, const double *goal_row, int box_half,
-                mpl_ref_plan_out *out3, double *checksum3, int64_t *stats /* [8] */) {
+                mpl_ref_plan_out *out3, double *checksum3, int64_t *stats /* [10] */) {
   std::shared_ptr<MPL::MapUtil<D>> mu = std::make_shared<MPL::MapUtil<D>>();
   Vecf<D> ori;
   Veci<D> dim;
@@ -494,7 +500,7 @@ int run_lpastar(const mpl_oracle_env *e, const double *start_row, const double *
   pl.setU(U);
   pl.setLPAstar(true);
   for (int i = 0; i < 3; i++) { out3[i] = mpl_ref_plan_out{}; checksum3[i] = 0; }
-  for (int i = 0; i < 8; i++) stats[i] = 0;
+  for (int i = 0; i < 10; i++) stats[i] = 0;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(now() - t0).count();
@@ -565,20 +571,24 @@ int run_lpastar(const mpl_oracle_env *e, const double *start_row, const double *
   stats[5] = (int64_t)edit.size();
   for (const auto &pn : edit) cells[(size_t)mu->getIndex(pn)] = 100;
   mu->setMap(ori, dim, cells, e->res);
+  const uint64_t up0 = upload_bytes(pl, 0);
   pl.updateBlockedNodes(edit);
   t0 = now();
   ok = pl.plan(start, goal);
   fill_out<D>(pl, ok, ms_since(t0), 0, &out3[1], &checksum3[1]);
+  stats[8] = (int64_t)(upload_bytes(pl, 0) - up0);  // map bytes moved to the device by the edit + the re-plan
   // ---- clear them again
   pl.getLinkedNodes();  // the table of the grown graph
   for (const auto &pn : edit) cells[(size_t)mu->getIndex(pn)] = 0;
   mu->setMap(ori, dim, cells, e->res);
+  const uint64_t up1 = upload_bytes(pl, 0);
   t0 = now();
   pl.updateClearedNodes(edit);
   stats[7] = (int64_t)(ms_since(t0) * 1000.0);
   t0 = now();
   ok = pl.plan(start, goal);
   fill_out<D>(pl, ok, ms_since(t0), 0, &out3[2], &checksum3[2]);
+  stats[9] = (int64_t)(upload_bytes(pl, 0) - up1);
   return 0;
 }
 
@@ -737,7 +747,7 @@ extern "C" int mpl_ref_lpastar_substate(const mpl_oracle_env *env, const double 
 }
 
 extern "C" int mpl_ref_lpastar(const mpl_oracle_env *env, const double *start, const double *goal, int use_gpu,
-                               int box_half, mpl_ref_plan_out *out3, double *checksum3, int64_t *stats8) {
+                               int box_half, mpl_ref_plan_out *out3, double *checksum3, int64_t *stats8 /* [10] */) {
   if (!env || !start || !goal || !out3 || !checksum3 || !stats8) return -1;
   if (env->dim == 2) {
     if (use_gpu) return run_lpastar<2, PeekPlanner<MPL::GpuMapPlanner<2>>>(env, start, goal, box_half, out3, checksum3, stats8);

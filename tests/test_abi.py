@@ -9,10 +9,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "mplx.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mplx_[a-z0-9_]+)\s*\(", text)))
+def _declared_symbols(headers=("mplx.h", "mplx_debug.h")):
+    found = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        found.update(re.findall(r"\b(mplx_[a-z0-9_]+)\s*\(", text))
+    return sorted(found)
 
 
 def test_header_declares_the_documented_entry_points():
@@ -28,7 +31,15 @@ def test_library_exports_every_declared_symbol(engine):
     for s in _declared_symbols():
         assert hasattr(lib, s), "libmplx.so does not export %s" % s
     assert sorted(engine._abi.SYMBOLS) == sorted(set(_declared_symbols()) - {"mplx_status"})
-    assert engine._abi.lib().mplx_abi_version() == 8
+    assert engine._abi.lib().mplx_abi_version() == 9
+
+
+def test_diagnostics_live_in_their_own_header():
+    """The drop-in boundary (mplx.h) carries no self-test / debug entry point; they are declared in mplx_debug.h."""
+    public = _declared_symbols(("mplx.h",))
+    debug = _declared_symbols(("mplx_debug.h",))
+    assert not [s for s in public if "selftest" in s or "debug" in s or s == "mplx_yaw_pin_stats"]
+    assert set(debug) == {"mplx_selftest_forward_state", "mplx_selftest_math", "mplx_yaw_pin_stats", "mplx_debug_store_model"}
 
 
 def test_struct_layouts_match_the_header(engine):

@@ -43,6 +43,8 @@ def full_size_workload(engine, name):
     # reference-semantics MapPlanner::updatePotentialMap on the device (checked against the numpy restatement and the
     # reference's own MapPlanner in test_c5_potential_map_is_made_on_the_device below)
     W = engine.workloads
+    if name in ("C3-SNP", "C2-VEL", "C2-YAWPOT"):  # round 6: SNP, VEL and 2D ACCxYAW + potential at BASELINE size
+        return W.make(name, potential_fn=W.device_potential_fn(0) if name == "C2-YAWPOT" else None)
     wl = W.make(name.split("-")[0], potential_fn=W.device_potential_fn(0) if name.startswith("C5") else None)
     if name == "C5-tunnel":
         # SURVEY 8(d)'s second C5 variant: a search region of radius 0.5 m around a straight start-goal path
@@ -62,7 +64,13 @@ def full_size_workload(engine, name):
 @pytest.mark.parametrize("name,route,kernel", [("C2", "grid", "lex"), ("C3", "grid", "lex"), ("C4", "grid", "lex"),
                                                ("C5", "grid", "grid"), ("C5-tunnel", "grid", "grid"),
                                                ("C2", "grid", "general"), ("C3", "grid", "general"), ("C4", "grid", "general"),
-                                               ("C4", "tile", "none"), ("C3", "dense", "none")])
+                                               ("C4", "tile", "none"), ("C3", "dense", "none"),
+                                               # SNP (quad + the root loops of primitive.h:152-193), VEL and the 2D
+                                               # DistanceMapPlanner's controls at BASELINE size, through the kernels
+                                               # that serve them
+                                               ("C3-SNP", "grid", "grid"), ("C3-SNP", "dense", "none"),
+                                               ("C2-VEL", "grid", "lex"), ("C2-VEL", "grid", "general"),
+                                               ("C2-YAWPOT", "grid", "grid")])
 def test_full_size_every_pair_against_the_reference(engine, oracle_lib, monkeypatch, name, route, kernel):
     use_ref = require_reference_build()
     if kernel == "general":
@@ -98,7 +106,7 @@ def test_full_size_every_pair_against_the_reference(engine, oracle_lib, monkeypa
     assert int(total.sum(dtype=np.int64)) == n_emit
     print("%s full size, %s route: all %d pairs vs %s: %d emitted, %d finite" % (
         name, route, N * nU, "oracle/_ref (the reference's own headers)" if use_ref else "the oracle", n_emit, n_fin))
-    assert n_fin > 0 and n_emit > n_fin and n_dyn > 0  # every outcome occurs
+    assert n_fin > 0 and n_emit > n_fin and (n_dyn > 0 or name == "C2-VEL")  # every outcome occurs (VEL has no limit to fail)
     lists.free()
     fr.free()
     env.close()

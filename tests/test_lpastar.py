@@ -75,6 +75,10 @@ def test_gpu_adapter_lpastar_is_identical(engine, which):
             assert a[k] == b[k], (which, k, a[k], b[k])
     for k in ("cells", "entries", "checksum", "linked_points", "points_checksum", "edited_cells"):
         assert cpu_table[k] == gpu_table[k], (which, k, cpu_table[k], gpu_table[k])
+    # a re-plan after an edit of k cells moves k cells to the device (mplx_edit_map: 9 bytes each), not the map
+    k = gpu_table["edited_cells"]
+    assert gpu_table["replan_upload_bytes"] == [9 * k, 9 * k], (gpu_table["replan_upload_bytes"], k, oenv.map.size)
+    assert cpu_table["replan_upload_bytes"] == [0, 0]
     print("%s: getLinkedNodes %d us on the CPU, %d us through the adapter (%d edges); updateClearedNodes %d / %d us" % (
         which, cpu_table["get_linked_nodes_us"], gpu_table["get_linked_nodes_us"], cpu_table["entries"],
         cpu_table["update_cleared_us"], gpu_table["update_cleared_us"]))
