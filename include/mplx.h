@@ -114,6 +114,9 @@ int mplx_edit_map(mplx_ctx *ctx, const int64_t *cell_index, const int8_t *values
  * _set_region: one byte per cell; mplx_edit_map: 9 bytes per edited cell): what a re-planning loop checks to see that an
  * edit of k cells cost k cells, not the map (tests/test_lpastar.py).                                                   */
 int mplx_map_upload_bytes(mplx_ctx *ctx, uint64_t *bytes);
+/* ABI v9.  The values of a few cells of a map that lives on the device: which = 0 the map, 1 the potential map;
+ * out[i] = cells[cell_index[i]].  Synchronous (one small gather launch + copy).                                         */
+int mplx_read_cells(mplx_ctx *ctx, int which, const int64_t *cell_index, int64_t n, int8_t *out);
 
 /* env_map::set_potential_map, env_map.h:181-183.  NULL clears it.  Same size
  * as the map.                                                                */
@@ -505,9 +508,16 @@ int mplx_planner_timing(const mplx_planner *p, mplx_plan_timing *out);
 /* ABI v8.  PlannerBase::setPriorTrajectory (planner_base.h:249-252; env_map::set_prior_trajectory, env_map.h:189-226): the
  * last trajectory of `from` (another planner, possibly with another control order) guides this planner's search -- a
  * state at time t is drawn to where that trajectory is at t (env_base::get_heur, env_base.h:46-52).  Call it after this
- * planner's map, v_max, w and dt are set, as the reference's programs do.  Occupancy maps (the potential-map terms need
- * the device's map: the drop-in adapter covers those).  from == NULL: no prior trajectory.                            */
+ * planner's map, v_max, w and dt are set, as the reference's programs do.  Occupancy maps (with a potential map: the
+ * _potential variant below).  from == NULL: no prior trajectory.                                                       */
 int mplx_planner_set_prior_trajectory(mplx_planner *p, const mplx_planner *from);
+/* ABI v9.  The same with a potential map installed (env_map::set_prior_trajectory / traverse_trajectory with
+ * potential_map_, env_map.h:197-216, 241-249): the prior's remaining cost carries potential_weight * value +
+ * gradient_weight * |vel| of every cell its samples pass through, and a prior that enters an obstacle's core (value >=
+ * 100) costs +inf.  potential: the host copy of the potential map (same size as the map), or NULL to read the values
+ * of the few hundred cells concerned from the potential map the attached context holds on the device (mplx_read_cells). */
+int mplx_planner_set_prior_trajectory_potential(mplx_planner *p, const mplx_planner *from, const int8_t *potential,
+                                                double potential_weight, double gradient_weight);
 
 /* ---- ABI v8: Lifelong Planning A* (PlannerBase::setLPAstar, planner_base.h:170-176; GraphSearch::LPAstar,
  *      graph_search.h:194-365; StateSpace::updateNode / increaseCost / decreaseCost / getSubStateSpace,

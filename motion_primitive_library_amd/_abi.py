@@ -16,7 +16,7 @@ ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_STATE = -1, -2, -3, -4
 # every symbol include/mplx.h declares, in declaration order
 SYMBOLS = [
     "mplx_create", "mplx_destroy", "mplx_last_error", "mplx_abi_version",
-    "mplx_set_map", "mplx_edit_map", "mplx_map_upload_bytes", "mplx_set_potential", "mplx_set_region", "mplx_set_params", "mplx_set_controls",
+    "mplx_set_map", "mplx_edit_map", "mplx_map_upload_bytes", "mplx_read_cells", "mplx_set_potential", "mplx_set_region", "mplx_set_params", "mplx_set_controls",
     "mplx_update_potential_map", "mplx_set_search_region_path",
     "mplx_expand_device", "mplx_expand", "mplx_expand_lists_device", "mplx_expand_lists", "mplx_get_succ",
     "mplx_set_goal", "mplx_post_lists_device", "mplx_post_packed_device",
@@ -27,7 +27,7 @@ SYMBOLS = [
     "mplx_synchronize", "mplx_timer_begin", "mplx_timer_end",
     "mplx_planner_create", "mplx_planner_destroy", "mplx_planner_attach_ctx", "mplx_planner_set_provider",
     "mplx_planner_set_map", "mplx_planner_edit_map", "mplx_planner_set_controls", "mplx_planner_configure", "mplx_planner_plan",
-    "mplx_planner_trajectory", "mplx_planner_trajectory_end", "mplx_planner_closed_set", "mplx_planner_open_set", "mplx_planner_last_error", "mplx_planner_timing", "mplx_planner_set_prior_trajectory", "mplx_planner_use_device_heuristic", "mplx_planner_set_lpastar", "mplx_planner_reset", "mplx_planner_linked_nodes", "mplx_planner_update_blocked_nodes", "mplx_planner_update_cleared_nodes", "mplx_planner_sub_state_space", "mplx_planner_set_edge_provider",
+    "mplx_planner_trajectory", "mplx_planner_trajectory_end", "mplx_planner_closed_set", "mplx_planner_open_set", "mplx_planner_last_error", "mplx_planner_timing", "mplx_planner_set_prior_trajectory", "mplx_planner_set_prior_trajectory_potential", "mplx_planner_use_device_heuristic", "mplx_planner_set_lpastar", "mplx_planner_reset", "mplx_planner_linked_nodes", "mplx_planner_update_blocked_nodes", "mplx_planner_update_cleared_nodes", "mplx_planner_sub_state_space", "mplx_planner_set_edge_provider",
     "mplx_selftest_math", "mplx_selftest_forward_state", "mplx_set_lists_route", "mplx_last_lists_route", "mplx_last_grid_kernel", "mplx_last_identity_form", "mplx_debug_store_model", "mplx_yaw_pin_stats", "mplx_service", "mplx_device_info",
 ]
 
@@ -150,6 +150,7 @@ def lib():
         "mplx_set_controls": (C.c_int, [vp, vp, i32, i32]),
         "mplx_edit_map": (C.c_int, [vp, vp, vp, i64]),
         "mplx_map_upload_bytes": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+        "mplx_read_cells": (C.c_int, [vp, C.c_int, vp, i64, vp]),
         "mplx_set_goal": (C.c_int, [vp, C.POINTER(GoalSpec)]),
         "mplx_update_potential_map": (C.c_int, [vp, vp, vp, vp, dbl, vp]),
         "mplx_set_search_region_path": (C.c_int, [vp, vp, i32, i32, vp, vp]),
@@ -193,6 +194,7 @@ def lib():
         "mplx_planner_timing": (C.c_int, [vp, C.POINTER(PlanTiming)]),
         "mplx_planner_use_device_heuristic": (C.c_int, [vp, C.c_int]),
         "mplx_planner_set_prior_trajectory": (C.c_int, [vp, vp]),
+        "mplx_planner_set_prior_trajectory_potential": (C.c_int, [vp, vp, vp, dbl, dbl]),
         "mplx_planner_set_lpastar": (C.c_int, [vp, C.c_int]),
         "mplx_planner_reset": (C.c_int, [vp]),
         "mplx_planner_linked_nodes": (C.c_int, [vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),

@@ -583,8 +583,8 @@ class Planner {
 
   // ---- prior trajectory (env_map::set_prior_trajectory, env_map.h:189-226; env_base::get_heur, env_base.h:46-52): a
   // state at time t is guided towards where the prior trajectory is at that time -- h = cal_heur(state, prior(t)) + the
-  // prior's remaining cost -- instead of towards the goal.  Occupancy maps only (the potential-map terms of
-  // env_map.h:201-214 need the potential map, which lives on the device: use the drop-in adapter for those).
+  // prior's remaining cost -- instead of towards the goal.  With a potential map (round 6) the values of the cells the
+  // prior trajectory's samples fall into come through `pot` (the device's potential map, or the caller's host copy).
   std::vector<double> prior_pos;   // [n][D] position of traj.evaluate(k dt)
   std::vector<double> prior_togo;  // [n] total_cost - costs[k]
   double prior_goal[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // traj.evaluate(total_time): THE goal while a prior is set
@@ -598,7 +598,11 @@ class Planner {
   // nodes: [segs][4D+2] segment start states, actions: [segs] rows of `pU` (udim entries each), the prior's control flag
   // and primitive duration.  v_max, w, dt and the grid of THIS planner must be set (the reference's call order,
   // test_planner_2d_with_prior_traj.cpp:60-70).
-  int set_prior_trajectory(const double *nodes, const int32_t *actions, int segs, int pcontrol, const double *pU, int pudim, double pdt) {
+  // pot(user, cell indices, n, values out): the potential map's values at cells inside the map, nullptr = no potential map
+  // (env_map::potential_map_ empty); pot_w / grad_w: env_map::potential_weight_ / gradient_weight_.
+  typedef int (*pot_lookup_fn)(void *user, const int64_t *idx, int64_t n, int8_t *out);
+  int set_prior_trajectory(const double *nodes, const int32_t *actions, int segs, int pcontrol, const double *pU, int pudim, double pdt,
+                           pot_lookup_fn pot = nullptr, void *pot_user = nullptr, double pot_w = 0.0, double grad_w = 0.0) {
     clear_prior();
     if (segs <= 0) return 0;
     if (!(dt > 0) || !(pdt > 0) || !(grid.res > 0)) return -1;  // (the loops below step by dt)
@@ -623,32 +627,83 @@ class Planner {
       auto power = [](double x, int n) { double r = 1; while (n-- > 0) r *= x; return r; };
       return ci[0] / 120 * power(t, 5) + ci[1] / 24 * power(t, 4) + ci[2] / 6 * power(t, 3) + ci[3] / 2 * t * t + ci[4] * t + ci[5];
     };
+    auto v_of = [&](int s, int i, double t) {  // Primitive1D::v, primitive.h:133-137
+      const double *ci = &c[((size_t)s * dim + i) * 6];
+      auto power = [](double x, int n) { double r = 1; while (n-- > 0) r *= x; return r; };
+      return ci[0] / 24 * power(t, 4) + ci[1] / 6 * power(t, 3) + ci[2] / 2 * t * t + ci[3] * t + ci[4];
+    };
     auto clamp = [&](double tau) { if (tau < 0) tau = 0; if (tau > total_time) tau = total_time; return tau; };
-    // env_map::traverse_trajectory (env_map.h:229-255) without a potential map: +inf when a sample is outside or occupied
-    double traverse = 0;
+    // traj.sample(n) (trajectory.h:230-236, 99-131): Command k at time k * total / n -- its time stamp (the unclamped
+    // time), cell, |vel| (Command::vel = pr.v(tau) / lambda with lambda = 1; Eigen's norm over the D components)
+    struct Sample { double t, vnorm; int64_t idx; bool outside, occupied; int8_t pot; };
+    std::vector<Sample> pts;
     {
       const int n = (int)std::ceil(v_max * total_time / grid.res);
       const double sdt = total_time / n;
-      int64_t prev_idx = -1;
-      for (int k = 0; k <= n && n > 0; k++) {  // Trajectory::sample(n): Command at k * dt (trajectory.h:230-236, 99-131)
-        double tau = clamp(k * sdt), pt[3] = {0, 0, 0};
+      for (int k = 0; k <= n && n > 0; k++) {
+        double tau = clamp(k * sdt), pt[3] = {0, 0, 0}, vv = 0;
         for (int s = 0; s < segs; s++)
           if (tau >= taus[(size_t)s] && tau <= taus[(size_t)s + 1]) {
             tau -= taus[(size_t)s];
-            for (int i = 0; i < dim; i++) pt[i] = p_of(s, i, tau);
+            for (int i = 0; i < dim; i++) {
+              pt[i] = p_of(s, i, tau);
+              const double v = v_of(s, i, tau) / 1.0;
+              vv += v * v;
+            }
             break;
           }
         int pn[3] = {0, 0, 0};
         grid.to_cell(pt, pn);
-        const int64_t idx = (int)grid.index(pn);  // (MapUtil::getIndex is int arithmetic, also for cells outside)
-        if (idx == prev_idx) continue;
-        prev_idx = idx;
-        if (grid.outside(pn) || grid.is_occupied(pn)) { traverse = kInf; break; }
+        Sample sm;
+        sm.t = k * sdt;
+        sm.vnorm = std::sqrt(vv);
+        sm.idx = (int)grid.index(pn);  // (MapUtil::getIndex is int arithmetic, also for cells outside)
+        sm.outside = grid.outside(pn);
+        sm.occupied = !sm.outside && grid.is_occupied(pn);
+        sm.pot = 0;
+        pts.push_back(sm);
+      }
+    }
+    if (pot) {  // the potential map's values at the samples' cells, one call
+      std::vector<int64_t> idx;
+      std::vector<size_t> who;
+      for (size_t k = 0; k < pts.size(); k++)
+        if (!pts[k].outside) { idx.push_back(pts[k].idx); who.push_back(k); }
+      std::vector<int8_t> val(idx.size());
+      if (!idx.empty() && pot(pot_user, idx.data(), (int64_t)idx.size(), val.data()) != 0) return -2;
+      for (size_t q = 0; q < who.size(); q++) pts[who[q]].pot = val[q];
+    }
+    // env_map::traverse_trajectory (env_map.h:229-255): +inf when a sample is outside, occupied (no potential map) or
+    // inside an obstacle's core (potential >= 100); the potential + gradient terms of the cells passed through
+    double traverse = 0;
+    {
+      int64_t prev_idx = -1;
+      for (const Sample &sm : pts) {
+        if (sm.idx == prev_idx) continue;
+        prev_idx = sm.idx;
+        if (sm.outside) { traverse = kInf; break; }
+        if (pot) {
+          if (sm.pot < 100 && sm.pot > 0) traverse += pot_w * sm.pot + grad_w * sm.vnorm;
+          else if (sm.pot >= 100) { traverse = kInf; break; }
+        } else if (sm.occupied) { traverse = kInf; break; }
       }
     }
     const double total_cost = traverse + w * total_time;
     std::vector<double> costs;
-    for (double t = 0; t < total_time; t += dt) costs.push_back(w * t);  // (no potential map: potential_cost = 0)
+    for (double t = 0; t < total_time; t += dt) {  // env_map.h:197-216
+      double potential_cost = 0;
+      if (pot) {
+        int64_t prev_idx = -1;
+        for (const Sample &sm : pts) {
+          if (sm.t >= t) break;
+          if (sm.idx == prev_idx) continue;
+          prev_idx = sm.idx;
+          // (the reference reads potential_map_[idx] unchecked here: a sample outside the map is undefined there, 0 here)
+          potential_cost += pot_w * sm.pot + grad_w * sm.vnorm;
+        }
+      }
+      costs.push_back(w * t + potential_cost);
+    }
     for (double t = 0; t < total_time; t += dt) {
       const int id = (int)(t / dt);
       double tau = clamp(t);

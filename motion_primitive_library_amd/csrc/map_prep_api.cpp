@@ -78,6 +78,25 @@ int mplx_edit_map(mplx_ctx *c, const int64_t *cell_index, const int8_t *values, 
   return MPLX_OK;
 }
 
+int mplx_read_cells(mplx_ctx *c, int which, const int64_t *cell_index, int64_t n, int8_t *out) {
+  if (!c) return MPLX_ERR_ARG;
+  if (n < 0 || (n > 0 && (!cell_index || !out)) || (which != 0 && which != 1)) return fail(c, MPLX_ERR_ARG, "mplx_read_cells: bad arguments");
+  if (which == 0 ? !c->has_map : !c->has_pot) return fail(c, MPLX_ERR_STATE, which == 0 ? "mplx_read_cells: no map set" : "mplx_read_cells: no potential map set");
+  for (int64_t i = 0; i < n; i++)
+    if (cell_index[i] < 0 || cell_index[i] >= c->n_cells)
+      return fail(c, MPLX_ERR_ARG, "mplx_read_cells: cell index %lld outside the map of %lld cells", (long long)cell_index[i], (long long)c->n_cells);
+  if (n == 0) return MPLX_OK;
+  if (int rc = bind_device(c)) return rc;
+  const size_t ib = (((size_t)n * 8) + 255) & ~(size_t)255;
+  if (int rc = ensure(c, c->edit_buf, ib + (size_t)n)) return rc;
+  char *d = (char *)c->edit_buf.p;
+  HIP_TRY(c, hipMemcpyAsync(d, cell_index, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, mplx::launch_gather_cells((const int8_t *)(which == 0 ? c->map.p : c->pot.p), (const int64_t *)d, n, (int8_t *)(d + ib), c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out, d + ib, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MPLX_OK;
+}
+
 int mplx_map_upload_bytes(mplx_ctx *c, uint64_t *bytes) {
   if (!c || !bytes) return MPLX_ERR_ARG;
   *bytes = c->map_upload_bytes;

@@ -177,6 +177,19 @@ hipError_t launch_edit_map(const int64_t *idx, const int8_t *val, int64_t n, int
   return hipGetLastError();
 }
 
+// out[i] = cells[idx[i]] (idx checked by the host): a few cells of a map that lives on the device, for host logic
+// that needs their values (the prior trajectory's potential cost, env_map.h:189-255)
+__global__ void gather_cells_kernel(const int8_t *cells, const int64_t *idx, int64_t n, int8_t *out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = cells[idx[i]];
+}
+
+hipError_t launch_gather_cells(const int8_t *cells, const int64_t *idx, int64_t n, int8_t *out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_cells_kernel, dim3(blocks_for(n)), dim3(256), 0, s, cells, idx, n, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_unpack_region(const uint32_t *bits, int64_t n_cells, uint8_t *bytes, hipStream_t s) {
   hipLaunchKernelGGL(unpack_region_kernel, dim3(blocks_for(n_cells)), dim3(256), 0, s, bits, n_cells, bytes);
   return hipGetLastError();

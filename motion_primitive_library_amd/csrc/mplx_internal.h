@@ -252,6 +252,7 @@ hipError_t launch_expand_lex(int dim, int control, const GridArgs &args, hipStre
 // region; (n_cells + 31) / 32 dwords.
 // Summed-area table of the blocked bits: (d0+1)(d1+1)(d2+1) uint32 (2D: (d0+1)(d1+1)*2).
 // mplx_edit_map: cells and (blk != null) their blocked bits patched in place (map_prep_kernel.hip)
+hipError_t launch_gather_cells(const int8_t *cells, const int64_t *idx, int64_t n, int8_t *out, hipStream_t s);
 hipError_t launch_edit_map(const int64_t *idx, const int8_t *val, int64_t n, int64_t n_cells, int8_t *map, uint32_t *blk,
                            const uint32_t *region, hipStream_t s);
 hipError_t launch_build_sat(int dim, const uint32_t *blk, const int32_t *mdim, uint32_t *sat, hipStream_t stream);

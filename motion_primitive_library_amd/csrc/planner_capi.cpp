@@ -262,6 +262,45 @@ int mplx_planner_set_prior_trajectory(mplx_planner *p, const mplx_planner *from)
   return MPLX_OK;
 }
 
+namespace {
+struct PotSource { const int8_t *host; mplx_ctx *ctx; };
+int pot_lookup(void *user, const int64_t *idx, int64_t n, int8_t *out) {
+  const PotSource *s = (const PotSource *)user;
+  if (s->host) {
+    for (int64_t i = 0; i < n; i++) out[i] = s->host[idx[i]];
+    return 0;
+  }
+  return mplx_read_cells(s->ctx, 1, idx, n, out);
+}
+}  // namespace
+
+int mplx_planner_set_prior_trajectory_potential(mplx_planner *p, const mplx_planner *from, const int8_t *potential,
+                                                double potential_weight, double gradient_weight) {
+  if (!p) return MPLX_ERR_ARG;
+  if (!from) { p->pl.clear_prior(); return MPLX_OK; }
+  const mplx::host::PlanResult &r = from->result();
+  if (!r.ok || r.traj_actions.empty()) return fail(p, MPLX_ERR_STATE, "mplx_planner_set_prior_trajectory_potential: the other planner holds no trajectory");
+  if (from->pl.dim != p->pl.dim) return fail(p, MPLX_ERR_ARG, "mplx_planner_set_prior_trajectory_potential: dimensions differ");
+  if (p->pl.grid.cells.empty()) return fail(p, MPLX_ERR_STATE, "mplx_planner_set_prior_trajectory_potential: set the map first");
+  if (!potential && !p->ctx)
+    return fail(p, MPLX_ERR_STATE, "mplx_planner_set_prior_trajectory_potential: no potential map given and no context attached to read it from");
+  PotSource src{potential, p->ctx};
+  try {
+    const int rc = p->pl.set_prior_trajectory(r.traj_nodes.data(), r.traj_actions.data(), (int)r.traj_actions.size(), from->pl.control,
+                                              from->pl.U.data(), from->pl.udim, from->pl.dt, pot_lookup, &src, potential_weight,
+                                              gradient_weight);
+    if (rc == -2) {
+      const std::string why = std::string("mplx_planner_set_prior_trajectory_potential: the potential map could not be read: ") +
+                              (p->ctx ? mplx_last_error(p->ctx) : "no context");
+      return fail(p, MPLX_ERR_STATE, why.c_str());
+    }
+    if (rc != 0) return fail(p, MPLX_ERR_STATE, "mplx_planner_set_prior_trajectory_potential: configure dt (> 0) and the map of this planner first");
+  } catch (...) {
+    return fail(p, MPLX_ERR_NOMEM, "mplx_planner_set_prior_trajectory_potential: out of host memory");
+  }
+  return MPLX_OK;
+}
+
 int mplx_planner_timing(const mplx_planner *p, mplx_plan_timing *out) {
   if (!p || !out) return MPLX_ERR_ARG;
   const mplx::host::PlanResult &r = p->result();

@@ -347,6 +347,7 @@ class EnvMap:
         self._p.dt, self._p.w, self._p.wyaw = 1.0, 10.0, 1.0
         self._p.v_max = self._p.a_max = self._p.j_max = self._p.yaw_max = -1.0
         self._p.potential_weight, self._p.gradient_weight = 0.1, 0.0
+        self.has_potential = False
         self._dirty = True
         self.nU = 0
         self.map_dim = None
@@ -396,6 +397,16 @@ class EnvMap:
             raise ValueError("editMap: %d indices, %d values" % (idx.size, val.size))
         _abi.check(self._ctx, _abi.lib().mplx_edit_map(self._ctx, idx.ctypes.data, val.ctypes.data, idx.size))
 
+    def read_cells(self, cell_index, potential=False):
+        """Values of a few cells of the map (or the potential map) the device holds (mplx_read_cells)."""
+        idx = np.ascontiguousarray(cell_index, dtype=np.int64).ravel()
+        out = np.empty(idx.size, dtype=np.int8)
+        _abi.check(self._ctx, _abi.lib().mplx_read_cells(self._ctx, 1 if potential else 0, idx.ctypes.data, idx.size, out.ctypes.data))
+        return out
+
+    def potential_weights(self):
+        return float(self._p.potential_weight), float(self._p.gradient_weight)
+
     def map_upload_bytes(self):
         """Host -> device bytes the map calls of this context have moved so far (mplx_map_upload_bytes)."""
         b = C.c_uint64(0)
@@ -430,7 +441,8 @@ class EnvMap:
     def set_gradient_weight(self, w): self._setp("gradient_weight", w)
 
     def set_potential_map(self, cells):
-        if cells is None or len(cells) == 0:
+        self.has_potential = not (cells is None or len(cells) == 0)
+        if not self.has_potential:
             _abi.check(self._ctx, _abi.lib().mplx_set_potential(self._ctx, None))
             return
         cells = np.ascontiguousarray(cells, dtype=np.int8).ravel()
@@ -457,6 +469,7 @@ class EnvMap:
         g = None if range_ is None else (C.c_double * 3)(*([float(x) for x in range_] + [0.0] * (3 - D)))
         out = np.empty(self._ncell, dtype=np.int8)
         _abi.check(self._ctx, _abi.lib().mplx_update_potential_map(self._ctx, p, r, g, float(power), out.ctypes.data))
+        self.has_potential = True
         return out
 
     def setSearchRegion(self, path, search_radius, dense=False):

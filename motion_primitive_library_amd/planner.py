@@ -261,10 +261,23 @@ class MapPlanner:
         """Tests: another implementation of the batched edge re-validation (the CPU oracle's)."""
         self._check(self._L.mplx_planner_set_edge_provider(self._p, fn_ptr, user_ptr))
 
-    def setPriorTrajectory(self, other):
+    def setPriorTrajectory(self, other, potential=None, potential_weight=None, gradient_weight=None):
         """PlannerBase::setPriorTrajectory: the last trajectory of another planner (still open) guides this one's
-        search; None clears it.  Set this planner's map, v_max, w and dt first."""
+        search; None clears it.  Set this planner's map, v_max, w and dt first -- and the potential map, if any
+        (env_map::set_prior_trajectory reads potential_map_, env_map.h:197-216): with the engine's own env the values
+        of the cells the prior passes through are read from the device's potential map; a planner on another
+        provider passes its host copy as `potential` with the two weights."""
         self._check(self._L.mplx_planner_configure(self._p, C.byref(self._cfg)))  # (v_max, w, dt reach the search)
+        if other is not None and (potential is not None or (self.env is not None and self.env.has_potential)):
+            if potential is not None:
+                potential = np.ascontiguousarray(potential, dtype=np.int8).ravel()
+                pw, gw = float(potential_weight), float(gradient_weight or 0.0)
+                ptr = potential.ctypes.data
+            else:
+                self.env._flush()
+                (pw, gw), ptr = self.env.potential_weights(), None
+            self._check(self._L.mplx_planner_set_prior_trajectory_potential(self._p, other._p, ptr, C.c_double(pw), C.c_double(gw)))
+            return
         self._check(self._L.mplx_planner_set_prior_trajectory(self._p, other._p if other is not None else None))
 
     def useDeviceHeuristic(self, on=True):

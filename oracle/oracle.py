@@ -268,7 +268,7 @@ def ref_plan(env, start_row, goal_row, use_gpu=False, epsilon=1.0, reps=1):
             "wall_ms": out.wall_ms, "device_launches": out.hm_size}
 
 
-SCENARIOS = {"distance": 0, "distance_yaw": 1, "distance_iterative": 2, "yaw": 3, "prior_traj": 4}
+SCENARIOS = {"distance": 0, "distance_yaw": 1, "distance_iterative": 2, "yaw": 3, "prior_traj": 4, "prior_traj_potential": 5}
 
 
 def ref_scenario(env, start_row, goal_row, scenario, use_gpu=False, via_base=False):

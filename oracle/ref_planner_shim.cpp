@@ -152,7 +152,10 @@ void fill_out(MPL::MapPlanner<D> &pl, bool ok, double ms, int launches, mpl_ref_
 double g_last_prep_ms = 0;  // wall time of the last stage-2 updatePotentialMap (mpl_ref_last_prep_ms)
 
 /* mode: 0 test_distance_map_planner_2d, 1 ..._with_yaw, 2 ..._iterative, 3 test_planner_2d_with_yaw (one stage),
- *       4 test_planner_2d_with_prior_traj (VEL plan, then JRK-state plan guided by it) */
+ *       4 test_planner_2d_with_prior_traj (VEL plan, then JRK-state plan guided by it)
+ *       5 the same with a potential map installed in the second planner BEFORE setPriorTrajectory (updatePotentialMap,
+ *         potential weight 0.5, gradient weight = env->gradient_weight): env_map::set_prior_trajectory /
+ *         traverse_trajectory with potential_map_ (env_map.h:197-216, 241-249) */
 template <int D, class PlannerT>
 int run_scenario(const mpl_oracle_env *e, const double *start_row, const double *goal_row, int mode, int batch,
                  mpl_ref_plan_out *out, double *checksum, int64_t *region_cells, int64_t *potential_sum) {
@@ -210,7 +213,7 @@ int run_scenario(const mpl_oracle_env *e, const double *start_row, const double 
     fill_out<D>(pl, ok, ms_since(t0), planner_launches(pl), &out[0], &checksum[0]);
     return 0;
   }
-  if (mode == 4) {
+  if (mode == 4 || mode == 5) {
     // test_planner_2d_with_prior_traj.cpp:29-102
     Waypoint<D> start = load(start_row, 0x01), goal = load(goal_row, 0x01);
     PlannerT first(false);
@@ -233,6 +236,17 @@ int run_scenario(const mpl_oracle_env *e, const double *start_row, const double 
     second.setW(10);
     second.setU(U);
     second.setTol(0.5);
+    if (mode == 5) {
+      Vecf<D> rad;
+      for (int i = 0; i < D; i++) rad(i) = 1.0;
+      second.setPotentialRadius(rad);
+      second.setPotentialWeight(0.5);
+      second.setGradientWeight(e->gradient_weight);
+      second.updatePotentialMap(start.pos);
+      int64_t ps = 0;
+      for (const auto v : mu->getMap()) ps += v;
+      *potential_sum = ps;
+    }
     second.setPriorTrajectory(prior);
     t0 = now();
     ok = second.plan(start, goal);
@@ -337,7 +351,7 @@ void set_batch(MPL::GpuMapPlanner<D> &p, int b) { p.setBatch(b > 1 ? b : 1); }
 extern "C" int mpl_ref_scenario(const mpl_oracle_env *env, const double *start, const double *goal, int use_gpu,
                                 int mode, mpl_ref_plan_out *out2, double *checksum2, int64_t *region_cells,
                                 int64_t *potential_sum) {
-  if (!env || !start || !goal || !out2 || (env->dim != 2 && env->dim != 3) || mode < 0 || mode > 4) return -1;
+  if (!env || !start || !goal || !out2 || (env->dim != 2 && env->dim != 3) || mode < 0 || mode > 5) return -1;
   if (env->dim == 3) {
     // the same flows on a voxel map (BASELINE config 5's planner: potential map + ACCxYAW, 3^3 x 3 yaw rates = 81 controls)
     if (use_gpu)
@@ -767,7 +781,7 @@ extern "C" double mpl_ref_last_prep_ms(void) { return g_last_prep_ms; }
 extern "C" int mpl_ref_scenario_via_base(const mpl_oracle_env *env, const double *start, const double *goal, int batch,
                                          int mode, mpl_ref_plan_out *out2, double *checksum2, int64_t *region_cells,
                                          int64_t *potential_sum) {
-  if (!env || !start || !goal || !out2 || env->dim != 2 || mode < 0 || mode > 4) return -1;
+  if (!env || !start || !goal || !out2 || env->dim != 2 || mode < 0 || mode > 5) return -1;
   return run_scenario<2, ViaBase<2>>(env, start, goal, mode, batch, out2, checksum2, region_cells, potential_sum);
 }
 

@@ -141,7 +141,8 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(tmp_path, launcher):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, MPLX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    detail = str(tmp_path / "bench_detail.json")
+    env = dict(os.environ, MPLX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MPLX_BENCH_DETAIL=detail)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
@@ -152,7 +153,13 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(tmp_path, launcher):
     proc = subprocess.run(launchers[launcher] + tail, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
     line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
+    short = json.loads(line)
+    # the printed line: numbers only, under 8 KB, every rank's kernel time on it; the long form is in the detail file
+    assert len(line) < 8000 and short["detail"] == detail and short["n_gpus"] == 2 and short["parity_sample_ok"] is True
+    assert len(short["rank_kernel_ms"]) == 2 and min(short["rank_kernel_ms"]) > 0
+    assert short["weak"]["frontier_nodes_per_gpu"] == 6001 and short["allgather"]["merge"]["ok"] is True
+    d = json.load(open(detail))
+    assert d["value"] == pytest.approx(short["value"], rel=1e-5)
     assert "rank 0's map broadcast" in d["config"]["map"] and d["ms_per_step_wall"] >= d["ms_per_step"] > 0
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["parity_sample_ok"] is True
     assert d["config"]["frontier_nodes"] == 6001 and d["config"]["frontier_nodes_per_gpu"] == 3001  # rank 0's block

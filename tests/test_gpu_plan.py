@@ -6,9 +6,11 @@ import time
 import numpy as np
 import pytest
 
+from oracle import oracle as O
 from test_plan_known_answer import corridor, run_c1
 
 pytestmark = pytest.mark.gpu
+needs_ref = pytest.mark.skipif(not os.path.exists(O.REF_PLANNER_SO), reason="oracle/_ref/libmpl_ref_planner.so not built")
 
 
 def _plan_on_gpu(m, batch):
@@ -415,3 +417,52 @@ def test_prior_trajectory_scenario_on_the_engine_planner_with_the_device(engine)
     assert ok and s1["closed"] == 248 and s1["cost"] == 382.0
     assert s2["closed"] == 628 and s2["cost"] == 353.5 and tr.getTotalTime() == 35.0 and s2["J"][2] == 3.5
     assert s3["cost"] == 363.0 and s3["closed"] == 3598
+
+
+@needs_ref
+@pytest.mark.parametrize("gradient_weight", [0.0, 0.25])
+def test_prior_trajectory_with_a_potential_map_on_the_device(engine, gradient_weight):
+    """The prior-trajectory scenario with a potential map in the second planner (env_map.h:197-216, 241-249), everything on
+    the MI355X: updatePotentialMap on the device, setPriorTrajectory reading the potential of the cells the prior passes
+    from the device's map (mplx_read_cells), get_succ from the potential-map kernels.  Cost, closed set and expansions
+    must be the reference's own MapPlanner's (oracle/_ref)."""
+    m = engine
+    c = corridor()
+    U = m.workloads.grid_controls([-0.5, 0.0, 0.5], 2)
+    oref = O.Env(2, O.ACC, U, c["cells"], c["dim"], c["origin"], c["res"], v_max=1.0, a_max=1.0, dt=1.0, gradient_weight=gradient_weight)
+    ref = O.ref_scenario(oref, m.Waypoint(2, m.ACC, pos=c["start"]).to_row(), m.Waypoint(2, m.ACC, pos=c["goal"]).to_row(), "prior_traj_potential")
+
+    def make(table):
+        pl = m.MapPlanner(2, device=0)
+        mu = m.MapUtil(2)
+        mu.setMap(c["origin"], c["dim"], c["cells"].copy(), c["res"])
+        pl.setMapUtil(mu)
+        pl.setVmax(1.0)
+        pl.setAmax(1.0)
+        pl.setDt(1.0)
+        pl.setU(table)
+        pl.setBatch(64)
+        return pl
+
+    first = make(2.0 * U)
+    assert first.plan(m.Waypoint(2, m.VEL, pos=c["start"]), m.Waypoint(2, m.VEL, pos=c["goal"]))
+    second = make(U)
+    second.setEpsilon(1.0)
+    second.setW(10)
+    second.setTol(0.5)
+    second.setPotentialRadius([1.0, 1.0])
+    second.setPotentialWeight(0.5)
+    second.setGradientWeight(gradient_weight)
+    pot = second.updatePotentialMap(c["start"])
+    assert int(np.asarray(pot).astype(np.int64).sum()) == ref[1]["potential_sum"]
+    # a few cells of the device's potential map, read back (mplx_read_cells)
+    probe = np.array([0, 1234, pot.size // 2, pot.size - 1], dtype=np.int64)
+    assert np.array_equal(second.env.read_cells(probe, potential=True), np.asarray(pot).ravel()[probe])
+    second.setPriorTrajectory(first)  # (the env holds a potential map: its values come from the device)
+    ok = second.plan(m.Waypoint(2, m.JRK, pos=c["start"]), m.Waypoint(2, m.VEL, pos=c["goal"]))
+    s2 = second.summary()
+    first.close()
+    second.close()
+    assert ok == ref[1]["ok"]
+    for k in ("closed", "expansions", "opened", "cost", "total_time", "segments", "J"):
+        assert s2[k] == ref[1][k], (k, s2[k], ref[1][k])

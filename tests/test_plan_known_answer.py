@@ -229,3 +229,57 @@ def test_prior_trajectory_heuristic_on_the_engine_planner(engine):
     # without the prior trajectory the search ends in the goal's own region (with one, where the prior ends: env_base.h:295-298):
     # the reference's MapPlanner on that problem (O.ref_plan with the JRK-state start) closes 3 598 nodes for 363.0
     assert s3["cost"] == 363.0 and s3["closed"] == 3598 and s3["total_time"] == 36.0
+
+
+@pytest.mark.skipif(not os.path.exists(O.REF_PLANNER_SO), reason="oracle/_ref/libmpl_ref_planner.so not built")
+@pytest.mark.parametrize("gradient_weight", [0.0, 0.25])
+def test_prior_trajectory_with_a_potential_map_on_the_engine_planner(engine, gradient_weight):
+    """env_map::set_prior_trajectory / traverse_trajectory WITH potential_map_ (env_map.h:197-216, 241-249) in the
+    engine's planner (mplx_planner_set_prior_trajectory_potential, round 6): the scenario of
+    test_planner_2d_with_prior_traj.cpp with updatePotentialMap in the second planner before setPriorTrajectory -- the
+    prior's remaining cost then carries potential_weight * value + gradient_weight * |vel| of the cells it passes.
+    Successors from the CPU oracle; cost, closed set and expansions against the reference's own MapPlanner
+    (the guided search re-opens closed nodes: 224 386 expansions for 147 216 closed at gradient weight 0)."""
+    m = engine
+    c = corridor()
+    U = m.workloads.grid_controls([-0.5, 0.0, 0.5], 2)
+    oref = O.Env(2, O.ACC, U, c["cells"], c["dim"], c["origin"], c["res"], v_max=1.0, a_max=1.0, dt=1.0, gradient_weight=gradient_weight)
+    ref = O.ref_scenario(oref, m.Waypoint(2, m.ACC, pos=c["start"]).to_row(), m.Waypoint(2, m.ACC, pos=c["goal"]).to_row(), "prior_traj_potential")
+    keep = []
+
+    def make(control, table, cells, potential=None):
+        oenv = O.Env(2, control, table, cells, c["dim"], c["origin"], c["res"], v_max=1.0, a_max=1.0, dt=1.0, potential=potential,
+                     potential_weight=0.5, gradient_weight=gradient_weight)
+        prov, ce = provider_from_oracle(oenv)
+        keep.append((oenv, ce))
+        pl = m.MapPlanner(2, provider=prov)
+        mu = m.MapUtil(2)
+        mu.setMap(c["origin"], c["dim"], cells, c["res"])
+        pl.setMapUtil(mu)
+        pl.setVmax(1.0)
+        pl.setAmax(1.0)
+        pl.setDt(1.0)
+        pl.setU(table)
+        return pl
+
+    first = make(m.VEL, 2.0 * U, c["cells"])
+    assert first.plan(m.Waypoint(2, m.VEL, pos=c["start"]), m.Waypoint(2, m.VEL, pos=c["goal"]))
+    s1 = first.summary()
+    # MapPlanner::updatePotentialMap (reference semantics; it rewrites the MapUtil's map, map_planner.cpp:387)
+    pot = O.update_potential_map(c["cells"], c["dim"], c["origin"], c["res"], c["start"], [1.0, 1.0], ref=True)
+    assert int(pot.astype(np.int64).sum()) == ref[1]["potential_sum"]
+    second = make(m.JRK, U, pot, potential=pot)
+    second.setEpsilon(1.0)
+    second.setW(10)
+    second.setTol(0.5)
+    second.setPriorTrajectory(first, potential=pot, potential_weight=0.5, gradient_weight=gradient_weight)
+    ok = second.plan(m.Waypoint(2, m.JRK, pos=c["start"]), m.Waypoint(2, m.VEL, pos=c["goal"]))
+    s2 = second.summary()
+    first.close()
+    second.close()
+    assert s1["closed"] == ref[0]["closed"] and s1["cost"] == ref[0]["cost"]
+    assert ok == ref[1]["ok"]
+    for k in ("closed", "expansions", "opened", "cost", "total_time", "segments", "J"):
+        assert s2[k] == ref[1][k], (k, s2[k], ref[1][k])
+    if gradient_weight == 0.0:
+        assert s2["expansions"] > s2["closed"]  # (the prior's heuristic is inconsistent: closed nodes are re-opened)
