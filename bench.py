@@ -934,6 +934,11 @@ def main():
                          "no layout, skew, stride or allocation flag moves it.  `value` is what a process that allocates its "
                          "output once measures.  > 1: up to this many allocations (held while probing), a 20-launch probe of "
                          "each, the fastest kept -- listed in config.output_placement; never at N > 1")
+    ap.add_argument("--prealloc-cycles", type=int, default=0,
+                    help="DIAGNOSTIC (default 0).  Allocate, touch and free the output lists this many times before the "
+                         "allocation that is timed: a fresh process's first allocation and one that reuses freed memory "
+                         "land in different placement modes about half the time (profiles/README.md) -- "
+                         "profiles/run_round6_modes.sh uses it to get a trace of BOTH modes from the same binary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip e2e / wavefront / other_configs / plan (N = 1 only)")
     ap.add_argument("--frontier", default="random", choices=["random", "wavefront"],
@@ -1051,6 +1056,11 @@ def main():
         stats["map_broadcast_ms"] = (time.perf_counter() - t_map) * 1e3
     alloc = shard.torch_alloc("cuda:%d" % local_rank) if distributed else None  # RCCL moves these very buffers
     frontier = env.upload_frontier(my_nodes)
+    for _ in range(max(0, args.prealloc_cycles)):  # (diagnostic, see --prealloc-cycles)
+        tmp = env.alloc_lists(n_loc, want_state=True, want_iters=False, alloc=alloc)
+        env.expand_lists_resident(frontier, tmp)
+        env.synchronize()
+        tmp.free()
     slots = env.alloc_lists(n_loc, want_state=True, want_iters=False, alloc=alloc)
     launch = lambda: env.expand_lists_resident(frontier, slots)
     dev_name, cus = env.device_info()
