@@ -93,13 +93,16 @@ def committed_counters(workload, kernel):
     """Per-launch counters of this workload's kernel from the committed round-5 PMC passes (profiles/r05_counters.json,
     written by profiles/run_round5_counters.sh on the GPU box: SQ_INSTS_VALU, FETCH_SIZE and WRITE_SIZE, each its own
     rocprofv3 pass): bench.py cannot collect counters itself.  None when nothing is committed for this kernel."""
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r05_counters.json"))).get(workload)
-    except (OSError, ValueError):
-        return None
-    if not rec or rec.get("kernel", "").split("<")[0] not in kernel:
-        return None
-    return rec
+    for fname in ("r06_counters.json", "r05_counters.json"):  # (the kernels of round 6 are round 5's: either file describes them)
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", fname))).get(workload)
+        except (OSError, ValueError):
+            continue
+        if rec and rec.get("kernel", "").split("<")[0] in kernel:
+            rec = dict(rec)
+            rec["file"] = "profiles/" + fname
+            return rec
+    return None
 
 
 N_SIMD, SHADER_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; /opt/skills/guides/MI355X_MICROARCH.md
@@ -121,8 +124,8 @@ def bound_of(rec, kernel_ms, frac_hbm):
             out["bound"] = "valu-issue"
     if rec and rec.get("traffic_bytes"):
         out["traffic"] = rec["traffic_bytes"]
-    out["counters_source"] = ("profiles/r05_counters.json (rocprofv3 --pmc passes of this workload + kernel on an MI355X, committed; "
-                              "not collected in this run)") if rec else None
+    out["counters_source"] = ("%s (rocprofv3 --pmc passes of this workload + kernel on an MI355X, committed; "
+                              "not collected in this run)" % rec.get("file", "profiles/")) if rec else None
     return out
 
 
@@ -1319,8 +1322,10 @@ def main():
                 # two modes per allocation (profiles/README.md, rounds 2 - 4): this run's, and the committed figures of both
                 "placement_modes": ({"this_run_ms": kernel_ms, "this_run_frac": achieved / HBM_PEAK_GBS,
                                      "fast_mode": {"ms": 0.480, "frac": 0.75}, "slow_mode": {"ms": 0.555, "frac": 0.65},
-                                     "source": "profiles/r04_placement_per_box.txt (6 boxes, first allocations: 4 slow, 2 fast); round 5: "
-                                               "profiles/r05_bench_c4_first.json (fast), r05_bench_c4_final.json (slow)"}
+                                     "source": "profiles/r04_placement_per_box.txt (6 boxes, first allocations: 4 slow, 2 fast); round 6, this "
+                                               "binary, one process each under rocprofv3: profiles/r06_bench_c4_fast_under_rocprof.json + "
+                                               "r06_c4_kernel_stats_fast.csv (0.4824 ms; trace 484.5 us), r06_bench_c4_slow_under_rocprof.json + "
+                                               "r06_c4_kernel_stats_slow.csv (0.5567 ms; trace 557.3 us)"}
                                     if args.workload == "C4" and world == 1 and args.scale == 1.0 and args.nodes is None else None),
                 "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_alg,
                 # (the committed instruction count is that of the whole frontier in one launch: N = 1 only)
