@@ -14,8 +14,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmplx.so")
-SOURCES = ["expand_kernel.hip", "expand_tile_kernel.hip", "expand_grid_kernel.hip", "expand_lex_kernel.hip", "map_prep_kernel.hip", "map_prep_api.cpp", "post_kernel.hip", "identity_kernel.hip", "post_api.cpp", "edge_kernel.hip", "edge_api.cpp", "mplx_api.cpp", "planner_capi.cpp", "pack_kernel.hip", "store_model_kernel.hip", "lists_copy_api.cpp", "pack_api.cpp", "comm_api.cpp"]
-HEADERS = ["mplx_internal.h", "mplx_ctx.h", "mplx_device_common.h", "host_planner.hpp", "host_lpastar.hpp", os.path.join("..", "..", "include", "mplx.h"), os.path.join("..", "..", "include", "mplx_debug.h")]
+SOURCES = ["expand_kernel.hip", "expand_tile_kernel.hip", "expand_grid_kernel.hip", "expand_lex_kernel.hip", "expand_pair_kernel.hip", "map_prep_kernel.hip", "map_prep_api.cpp", "post_kernel.hip", "identity_kernel.hip", "post_api.cpp", "edge_kernel.hip", "edge_api.cpp", "mplx_api.cpp", "planner_capi.cpp", "pack_kernel.hip", "store_model_kernel.hip", "lists_copy_api.cpp", "pack_api.cpp", "comm_api.cpp"]
+HEADERS = ["mplx_internal.h", "mplx_ctx.h", "mplx_device_common.h", "mplx_grid_common.h", "host_planner.hpp", "host_lpastar.hpp", os.path.join("..", "..", "include", "mplx.h"), os.path.join("..", "..", "include", "mplx_debug.h")]
 ARCH = "gfx950"
 
 

@@ -133,6 +133,9 @@ int mplx_create(int dim, int device, mplx_ctx **out) {
     c->tune.grid_gather = getenv("MPLX_GRID_GATHER") ? env_int("MPLX_GRID_GATHER") : -1;
     c->tune.grid_sat = getenv("MPLX_GRID_SAT") ? env_int("MPLX_GRID_SAT") : -1;
     c->tune.dbg = env_int("MPLX_TILE_DBG");
+    c->tune.no_pair = getenv("MPLX_GRID_PAIR") && env_int("MPLX_GRID_PAIR") == 0;
+    c->tune.pair_rmax = env_int("MPLX_PAIR_RMAX");
+    c->tune.pair_wg_per_cu = env_int("MPLX_PAIR_WG_PER_CU");
     c->tune.arena_kb = env_int("MPLX_ARENA_KB");
     c->tune.zero_copy = getenv("MPLX_ZERO_COPY") ? env_int("MPLX_ZERO_COPY") : 1;
     c->tune.no_sat = getenv("MPLX_GRID_NOSAT") != nullptr;
@@ -1003,7 +1006,47 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
       a.done.count = (uint32_t *)c->done_count.p;
       a.done.seq = ++c->done_seq;
     }
-    if (int rc = launch_grid(c, &a)) return rc;
+    // Yaw controls on a potential map over a pre-screened frontier (BASELINE config 5): two nodes per wave
+    // (expand_pair_kernel.hip) -- the few thousand survivors then are ONE round of wave tasks instead of two.  Same lists.
+    bool paired = false;
+    if (a.live != nullptr && c->has_pot && a.ulex && !gp.lex && !c->tune.no_pair && a.yaw.tab == nullptr &&
+        mplx::pair_covers(c->dim, c->prm.control) && c->dim * gp.ndp <= 16 && a.ndy <= 16) {
+      mplx::GridArgs b = a;
+      int rm = c->tune.pair_rmax > 0 ? c->tune.pair_rmax : 3, per_cu = 0;
+      size_t lds = 0;
+      for (; rm >= 1 && per_cu < 1; rm--) {  // (rows per pass down to what fits at all)
+        lds = mplx::pair_lds_bytes(c->dim, gp.order, c->nU, gp.ndp, gp.n_max, rm, c->prm.wyaw > 0, a.ndy);
+        if (lds > 160 * 1024) continue;
+        const int key = c->prm.control | 0x200;  // (the occupancy cache's control word: bit 9 = the pair kernel)
+        int nb = -1;
+        for (const auto &e : c->grid_occ)
+          if (e.control == key && e.pot == c->has_pot && e.lds == lds) nb = e.nb;
+        if (nb < 0) {
+          nb = mplx::pair_resident_blocks(c->dim, c->prm.control, lds);
+          if (c->grid_occ.size() >= 8) c->grid_occ.clear();
+          c->grid_occ.push_back({key, c->has_pot, lds, nb});
+          if (getenv("MPLX_GRID_VERBOSE"))
+            fprintf(stderr, "mplx: pair kernel control 0x%x rows/pass %d: LDS %zu B per workgroup, %d workgroups resident per CU\n",
+                    c->prm.control, rm, lds, nb);
+        }
+        const int by_lds = (int)((160 * 1024) / lds);
+        per_cu = (nb > 0 && nb < by_lds) ? nb : by_lds;
+        if (per_cu >= 1) { b.rmax = rm; break; }
+      }
+      if (per_cu >= 1) {
+        const int cap = c->tune.pair_wg_per_cu > 0 ? c->tune.pair_wg_per_cu : 3;  // 3 waves per SIMD: what its registers allow
+        if (per_cu > cap) per_cu = cap;
+        b.grid_limit = c->n_cus * per_cu;
+        b.work = nullptr;
+        b.work_zero = nullptr;
+        const hipError_t e = mplx::launch_expand_pair(c->dim, c->prm.control, b, c->stream);
+        if (e != hipSuccess) return fail(c, MPLX_ERR_HIP, "expand_pair_kernel launch failed: %s", hipGetErrorString(e));
+        c->last_grid_lex = false;
+        paired = true;
+      }
+    }
+    if (!paired)
+      if (int rc = launch_grid(c, &a)) return rc;
     c->done_armed = a.done.flag != nullptr;
     if (a.yaw.amb) {
       mplx_ctx::YawPending p;

@@ -69,6 +69,8 @@ struct mplx_ctx {
     int grid_chunk = 0;                                   // MPLX_GRID_CHUNK: nodes per claim (0 = automatic)
     int grid_blocked = 0;                                 // MPLX_GRID_BLOCKED: contiguous shares per counter (A/B)
     int dbg = 0;                                         // MPLX_TILE_DBG ablation bits
+    bool no_pair = false;                                // MPLX_GRID_PAIR=0: pre-screened yaw + potential launches stay with expand_grid_kernel
+    int pair_rmax = 0, pair_wg_per_cu = 0;               // MPLX_PAIR_RMAX / MPLX_PAIR_WG_PER_CU: rows per pass / resident workgroups of expand_pair_kernel
     int zero_copy = 1;                                   // MPLX_ZERO_COPY=0: small batches through a device arena instead
     int arena_kb = 0;                                    // MPLX_ARENA_KB: largest batch served by the one-copy path
     bool no_sat = false, no_lex = false, no_line_pad = false;  // MPLX_GRID_NOSAT / MPLX_GRID_NOLEX / MPLX_NO_LINE_PAD

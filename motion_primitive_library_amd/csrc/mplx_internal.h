@@ -214,6 +214,14 @@ struct GridArgs {
   const uint32_t *live_n;
   DoneSignal done;      // small synchronous batches: see DoneSignal
 };
+// expand_pair_kernel.hip: yaw controls on a potential map over a pre-screened frontier, two nodes per wave (same
+// arguments as expand_grid_kernel; GridArgs::live / live_n must be set, grid_limit = workgroups to launch)
+size_t pair_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, bool ycost, int ndy);
+int pair_waves_per_block();
+int pair_nodes_per_wave();
+bool pair_covers(int dim, int control);
+hipError_t launch_expand_pair(int dim, int control, const GridArgs &a, hipStream_t s);
+int pair_resident_blocks(int dim, int control, size_t lds);
 constexpr int kWorkCounters = 64;
 // lane-per-node validate_yaw(t = 0) over a whole frontier (expand_grid_kernel.hip); fills live / live_n of `a`'s launch
 // (live_n is zero when the launch begins; the launch zeroes live_zero, the counter of the NEXT pre-screen of the stream)
