@@ -31,6 +31,14 @@ constexpr int kPairGS = 32;                 // lanes per node
 constexpr int kPairNG = 64 / kPairGS;       // nodes per wave
 constexpr int kPairWPB = 4;                 // waves per workgroup
 constexpr int kPairBT = 64 * kPairWPB;
+#ifndef MPLX_PAIR_NY
+#define MPLX_PAIR_NY 4
+#endif
+constexpr int kPairNY = MPLX_PAIR_NY;       // yaw rates a lane carries through its sample loop (host: ndy <= kPairNY)
+#ifndef MPLX_PAIR_UB
+#define MPLX_PAIR_UB 4
+#endif
+constexpr int kPairUB = MPLX_PAIR_UB;       // samples per step of the sample loop (C5: 4 = 8 = 16 in time, 4 is the fewest registers)
 
 typedef const GridArgs __attribute__((address_space(4))) *GridKernargPtr;
 
@@ -346,7 +354,13 @@ void expand_pair_kernel(const GridArgs A_kernarg) {
   int *s_eflag = (int *)(wb + L.w_eflag);
   int *s_misc = (int *)(wb + L.w_misc);
   unsigned short *s_rowmap = (unsigned short *)(wb + L.w_rowmap);
-  unsigned short *s_list = (unsigned short *)(wb + L.w_list);
+  // per emitted pair (list position): the cost and iteration count its combination's lane found; per combination: entries,
+  // sample count, yaw mask, first list position; the list itself (packed entry indices per position)
+  double *s_pc = (double *)(wb + L.w_list);
+  unsigned int *s_cmb = (unsigned int *)(wb + L.w_list + nU * 8);
+  unsigned short *s_ceb = (unsigned short *)(wb + L.w_list + nU * 8 + L.PNC * 4);
+  unsigned short *s_list = (unsigned short *)(wb + L.w_list + nU * 8 + L.PNC * 6 + (L.PNC & 1) * 2);
+  unsigned short *s_pi = s_list + ((nU + 1) & ~1);
   unsigned char *s_cell = wb + L.w_cell;
   double *s_yawT = (double *)(wb + L.w_yaw);
   double *s_ycs = (double *)(wb + L.w_ycs);
@@ -354,7 +368,7 @@ void expand_pair_kernel(const GridArgs A_kernarg) {
   unsigned short *s_hmask = (unsigned short *)(wb + L.w_hmask);
   double *s_uq = (double *)(wb + L.w_uq);
   double *s_ycsr = (double *)(wb + L.w_ycsr);
-  const NodeTabs tabs{s_node, s_est, s_hp, s_eq, s_eflag, s_misc, s_uq, s_yawT, s_ycs, s_yq, s_hmask, s_list};
+  const NodeTabs tabs{s_node, s_est, s_hp, s_eq, s_eflag, s_misc, s_uq, s_yawT, s_ycs, s_yq, s_hmask, nullptr};
 
   const int tts = L.tts, EN = L.EN;
   const int rowcap = RM * tts;
@@ -413,9 +427,67 @@ void expand_pair_kernel(const GridArgs A_kernarg) {
     int base_c[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) base_c[i] = (i < D) ? s_misc[M_BASE + i] : 0;
-    // ---- phase A: every pair; ordered list of the emitted ones; sample counts in use
+    // ---- phase A: every COMBINATION of the entries inside the limits (x, y, z; lexicographic, z fastest): which of its
+    // yaw values are emitted -- the heading mask of its (x, y) entries, and the successor must differ from the node
+    // (env_map.h:158: a hash comparison) -- its sample count, and its first position in the node's list: the emitted
+    // pairs in ascending control order are the combinations in order, each with its emitted yaw values in order.
+    // s_cmb[x] = j0 | j1 << 4 | j2 << 8 | n << 12 | yaw mask << 18 (ndy <= 14), s_ceb[x] = first list position.
+    const int nv0 = s_misc[M_NV + 0], nv1 = s_misc[M_NV + 1], nv2 = (D == 3) ? s_misc[M_NV + 2] : 1;
+    const int n12 = nv1 * nv2, ncomb = nv0 * n12;
+    const unsigned char *vl_ = (const unsigned char *)(s_misc + M_VL);
+    int E = 0;  // emitted successors of the node (uniform over the group)
     unsigned long long nm = 0;
-    const int E = grid_node_pairs<D, K, true, GS>(Ak, tabs, nullptr, vl, gsh, hcur, nm);
+    {
+      const float r_n12 = 1.0f / (float)(n12 > 0 ? n12 : 1), r_n2 = 1.0f / (float)(nv2 > 0 ? nv2 : 1);
+      unsigned int nm_lo = 0, nm_hi = 0;
+      for (int x0 = 0; x0 < ncomb; x0 += GS) {
+        const int x = x0 + vl;
+        unsigned int mask = 0, word = 0;
+        if (x < ncomb) {
+          const int a_ = (int)(((float)x + 0.5f) * r_n12);  // exact: x < 2^12
+          const int ra = x - a_ * n12;
+          const int b_ = (D == 3) ? (int)(((float)ra + 0.5f) * r_n2) : ra;
+          const int j0 = vl_[a_], j1 = vl_[16 + b_], j2 = (D == 3) ? (int)vl_[32 + ra - b_ * nv2] : 0;
+          const int px = (D == 3) ? __umul24(j0, ndp) + j1 : j0;
+          const int eL = (D - 1) * ndp + ((D == 3) ? j2 : j1);
+          uint64_t hc = s_hp[px];
+          fold_entry<K>(hc, s_eq, eL);
+          const unsigned int hm = s_hmask[__umul24(j0, ndp) + j1];
+          const int fl = pair_flags<D>(s_eflag, ndp, j0, j1, j2);  // (valid by construction: fl & 1)
+          const int n = (fl & 2) ? 0 : (fl >> 8);  // unchanged position: not traversed (env_map.h:163)
+          for (int jy = 0; jy < ndy; jy++) {
+            uint64_t h = hc;
+            fold(h, s_yq[jy]);
+            if (((hm >> jy) & 1u) && h != hcur) mask |= 1u << jy;
+          }
+          word = (unsigned)j0 | ((unsigned)j1 << 4) | ((unsigned)j2 << 8) | ((unsigned)n << 12) | (mask << 18);
+          if (mask && n) { if (n < 32) nm_lo |= 1u << n; else nm_hi |= 1u << (n - 32); }
+        }
+        // first list position: the emitted pairs of the combinations before this one (exclusive scan over the group)
+        const int cnt = __popc(mask);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < GS; d <<= 1) {
+          const int o = __shfl_up(incl, d, GS);
+          if (vl >= d) incl += o;
+        }
+        if (x < ncomb) {
+          const int eb = E + incl - cnt;
+          s_cmb[x] = word;
+          s_ceb[x] = (unsigned short)eb;
+          int rank = 0;
+          for (int jy = 0; jy < ndy; jy++)  // the list: packed entry indices of every emitted pair, in order
+            if ((mask >> jy) & 1u) s_list[eb + rank++] = (unsigned short)((word & 0xfffu) | ((unsigned)jy << 12));
+        }
+        E += __shfl(incl, GS - 1, GS);
+      }
+#pragma unroll
+      for (int d = GS >> 1; d > 0; d >>= 1) {
+        nm_lo |= (unsigned int)__shfl_xor((int)nm_lo, d, 64);
+        nm_hi |= (unsigned int)__shfl_xor((int)nm_hi, d, 64);
+      }
+      nm = (unsigned long long)nm_lo | ((unsigned long long)nm_hi << 32);
+    }
     wave_sync();
     if (vl == 0 && real && A.l_count) A.l_count[node] = E;
     if (A.dbg & 1) nm = 0;  // timing ablation: no sampling
@@ -511,7 +583,118 @@ void expand_pair_kernel(const GridArgs A_kernarg) {
       }
       wave_sync();
 
-      // ---- phase D: the list, GS dense lanes at a time
+      // ---- phase D1: the combinations, GS at a time; a lane walks the samples of its combination ONCE for all of its
+      // emitted yaw values (same cells, same potential terms, same unit velocity; the heading term per yaw value) and
+      // leaves cost and iteration count of each in LDS, at the pair's list position
+      for (int x0 = 0; x0 < ncomb; x0 += GS) {
+        const int x = x0 + vl;
+        const unsigned int cw = x < ncomb ? s_cmb[x] : 0u;
+        const int j0 = cw & 15, j1 = (cw >> 4) & 15, j2 = (cw >> 8) & 15;
+        const int n = (int)((cw >> 12) & 63u);
+        const unsigned int ymask = cw >> 18;
+        const int eb = x < ncomb ? (int)s_ceb[x] : 0;
+        const int en[3] = {j0, ndp + j1, 2 * ndp + j2};
+        const bool smp = ymask != 0u && n != 0 && ((sub >> n) & 1ull) != 0ull;
+        const int cntl = smp ? (int)s_tc[n] : 0;  // iterations of `for (t = 0; t < T; t += T/n)`
+        int fb = -1;                              // first blocked sample
+        double csum[kPairNY];                     // traverse_primitive's accumulated cost, per yaw value
+#pragma unroll
+        for (int y = 0; y < kPairNY; y++) csum[y] = 0.0;
+        {
+          const int r = smp ? (int)s_rowmap[n] : 0;  // slot offset of the combination's rows
+          int ptr[3] = {0, 0, 0};
+#pragma unroll
+          for (int i = 0; i < D; i++) ptr[i] = __umul24(en[i], rowcap) + r;
+          bool done = !smp || (A.dbg & 32);
+          const double sdt = smp ? T / n : 0.0;  // env_map.h:96
+          const double *trow = s_tt + (smp ? n : 0) * tts;
+          // Waypoint::vel of a sample (primitive.h:321-331) from its time: the expression the velocity rows of
+          // expand_grid_kernel.hip hold (Ax::vel<false> at the table's accumulated time)
+          Ax<K> qv[D];
+#pragma unroll
+          for (int i = 0; i < D; i++) qv[i].init(s_node[0 * D + i], s_node[1 * D + i], (K >= 3) ? s_node[2 * D + i] : 0.0, 0.0, s_uval[en[i]]);
+          for (int k0 = 0; __ballot(!done) != 0ull; k0 += kPairUB) {
+            int val[kPairUB];
+            bool bad[kPairUB];
+#pragma unroll
+            for (int q = 0; q < kPairUB; q++) {
+              int k = k0 + q;
+              k = k < cntl ? k : (cntl > 0 ? cntl - 1 : 0);
+              bool inside = !done;
+              int64_t cell = 0, mul = 1;
+#pragma unroll
+              for (int i = 0; i < D; i++) {
+                const int c = base_c[i] + (done ? 0 : (int)s_cell[ptr[i] + k]) - half;
+                inside = inside && c >= 0 && c < dims[i];
+                cell += mul * c;
+                mul *= dims[i];
+              }
+              const int64_t ci_ = inside ? cell : 0;
+              const bool in_reg = A.region == nullptr || ((A.region[ci_ >> 5] >> (ci_ & 31)) & 1u);
+              val[q] = A.pot[ci_];
+              bad[q] = !inside || !in_reg;
+            }
+#pragma unroll
+            for (int q = 0; q < kPairUB; q++) {
+              if (!done && k0 + q < cntl) {
+                if (bad[q] || val[q] >= 100) { fb = k0 + q; done = true; }
+                else {
+                  const int k = k0 + q;
+                  if (val[q] > 0) {
+                    double term;
+                    if (gcost) {  // env_map.h:115-116: dt * (potential_weight * value + gradient_weight * vel.norm())
+                      const double tk = trow[k];
+                      double vn = 0;
+#pragma unroll
+                      for (int i = 0; i < D; i++) {
+                        const double vi_ = qv[i].template vel<false>(tk);
+                        vn += vi_ * vi_;
+                      }
+                      term = sdt * (A.pot_w * val[q] + A.grad_w * sqrt(vn));
+                    } else {
+                      term = sdt * (A.pot_w * val[q]);
+                    }
+#pragma unroll
+                    for (int y = 0; y < kPairNY; y++) csum[y] += term;
+                  }
+                  if (ycost) {
+                    // env_map.h:121-129: the heading cost of the sample, after its potential term; v.normalized() once,
+                    // the heading of every yaw value from the rows
+                    const double tk = trow[k];
+                    const double vx = qv[0].template vel<false>(tk), vy = qv[1].template vel<false>(tk);
+                    double ux, uy;
+                    if (heading_unit(vx, vy, ux, uy)) {
+#pragma unroll
+                      for (int y = 0; y < kPairNY; y++) {
+                        if (y < ndy) {
+                          const double *cs = s_ycsr + (__umul24(y, rowcap) + r + k) * 2;
+                          const double v_value = 1 - (ux * cs[0] + uy * cs[1]);
+                          csum[y] += A.wyaw * v_value * sdt;
+                        }
+                      }
+                    }
+                  }
+                }
+              }
+            }
+            if (k0 + kPairUB >= cntl) done = true;
+          }
+        }
+        if (smp) {
+          int rank = 0;
+#pragma unroll
+          for (int y = 0; y < kPairNY; y++) {
+            if (y < ndy && ((ymask >> y) & 1u)) {
+              s_pc[eb + rank] = csum[y];
+              s_pi[eb + rank] = (unsigned short)(fb >= 0 ? 0x8000 | (fb + 1) : cntl);  // bit 15: blocked at that iteration
+              rank++;
+            }
+          }
+        }
+      }
+      wave_sync();
+
+      // ---- phase D2: the list, GS dense lanes at a time: every row of the node's successor list written in whole lines
       for (int e0 = 0; e0 < E; e0 += GS) {
         const int e = e0 + vl;
         const bool act = e < E;
@@ -573,94 +756,21 @@ void expand_pair_kernel(const GridArgs A_kernarg) {
             if (A.post.flags && mine) A.post.flags[idx] = (uint8_t)fv;
           }
         }
-        // ---- the sample loop of traverse_primitive (env_map.h:97-129), potential map
-        const bool smp = mine && n != 0;
-        const int cntl = smp ? (int)s_tc[n] : 0;  // iterations of `for (t = 0; t < T; t += T/n)`
-        int fb = -1;                              // first blocked sample
-        double csum = 0.0;                        // traverse_primitive's accumulated cost
-        {
-          const int r = smp ? (int)s_rowmap[n] : 0;  // slot offset of the pair's row
-          int ptr[3] = {0, 0, 0};
-#pragma unroll
-          for (int i = 0; i < D; i++) ptr[i] = __umul24(en[i], rowcap) + r;
-          bool done = !smp || (A.dbg & 32);
-          const double sdt = smp ? T / n : 0.0;  // env_map.h:96
-          const int pyr = __umul24(jy, rowcap) + r;
-          const double *trow = s_tt + (smp ? n : 0) * tts;
-          // Waypoint::vel of a sample (primitive.h:321-331) from its time: the expression the velocity rows of
-          // expand_grid_kernel.hip hold (Ax::vel<false> at the table's accumulated time)
-          Ax<K> qv[D];
-#pragma unroll
-          for (int i = 0; i < D; i++) qv[i].init(s_node[0 * D + i], s_node[1 * D + i], (K >= 3) ? s_node[2 * D + i] : 0.0, 0.0, s_uval[en[i]]);
-          // env_map.h:121-129: heading cost of sample k (after the potential term of the same sample)
-          auto heading_cost = [&](int k) {
-            const double tk = trow[k];
-            const double vx = qv[0].template vel<false>(tk), vy = qv[1].template vel<false>(tk);
-            double ux, uy;
-            if (heading_unit(vx, vy, ux, uy)) {
-              const double v_value = 1 - (ux * s_ycsr[(pyr + k) * 2] + uy * s_ycsr[(pyr + k) * 2 + 1]);
-              csum += A.wyaw * v_value * sdt;
-            }
-          };
-          for (int k0 = 0; __ballot(!done) != 0ull; k0 += kUB) {
-            int val[kUB];
-            bool bad[kUB];
-#pragma unroll
-            for (int q = 0; q < kUB; q++) {
-              int k = k0 + q;
-              k = k < cntl ? k : (cntl > 0 ? cntl - 1 : 0);
-              bool inside = !done;
-              int64_t cell = 0, mul = 1;
-#pragma unroll
-              for (int i = 0; i < D; i++) {
-                const int c = base_c[i] + (done ? 0 : (int)s_cell[ptr[i] + k]) - half;
-                inside = inside && c >= 0 && c < dims[i];
-                cell += mul * c;
-                mul *= dims[i];
-              }
-              const int64_t ci_ = inside ? cell : 0;
-              const bool in_reg = A.region == nullptr || ((A.region[ci_ >> 5] >> (ci_ & 31)) & 1u);
-              val[q] = A.pot[ci_];
-              bad[q] = !inside || !in_reg;
-            }
-#pragma unroll
-            for (int q = 0; q < kUB; q++) {
-              if (!done && k0 + q < cntl) {
-                if (bad[q] || val[q] >= 100) { fb = k0 + q; done = true; }
-                else {
-                  if (val[q] > 0) {
-                    if (gcost) {  // env_map.h:115-116: dt * (potential_weight * value + gradient_weight * vel.norm())
-                      const double tk = trow[k0 + q];
-                      double vv = 0;
-#pragma unroll
-                      for (int i = 0; i < D; i++) {
-                        const double vi_ = qv[i].template vel<false>(tk);
-                        vv += vi_ * vi_;
-                      }
-                      csum += sdt * (A.pot_w * val[q] + A.grad_w * sqrt(vv));
-                    } else {
-                      csum += sdt * (A.pot_w * val[q]);
-                    }
-                  }
-                  if (ycost) heading_cost(k0 + q);
-                }
-              }
-            }
-            if (k0 + kUB >= cntl) done = true;
-          }
-        }
         // ---- cost (env_map.h:162-169) and iteration count
         if ((mine || pad32) && !(A.dbg & 4)) {
-          const bool blocked = fb >= 0;
+          const bool smp = mine && n != 0;
+          const unsigned int pi = smp ? (unsigned int)s_pi[e] : 0u;
+          const bool blocked = (pi & 0x8000u) != 0u;
           double J = 0;
 #pragma unroll
           for (int i = 0; i < D; i++) {  // Primitive::J of a forward primitive: u*u*T per axis (see expand_kernel.hip)
             const double u = s_uval[en[i]];
             J += u * u * T;
           }
+          const double csum = smp ? s_pc[e] : 0.0;
           const double cost = blocked ? INFINITY : csum + (J + A.w * A.dt);
           if (A.l_cost && (mine || pad16)) st_stream(cost, &A.l_cost[idx]);
-          if (A.l_iters) st_stream(blocked ? fb + 1 : cntl, &A.l_iters[idx]);
+          if (A.l_iters) st_stream((int)(pi & 0x7fffu), &A.l_iters[idx]);
         }
         wave_prio(1);
       }
@@ -720,6 +830,7 @@ size_t pair_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, 
 }
 int pair_waves_per_block() { return kPairWPB; }
 int pair_nodes_per_wave() { return kPairNG; }
+int pair_max_yaw_rates() { return kPairNY; }
 
 // the configurations this kernel has an instantiation for (the host checks the rest of the scope)
 bool pair_covers(int dim, int control) { return (dim == 2 || dim == 3) && (control == 0x13 || control == 0x17); }

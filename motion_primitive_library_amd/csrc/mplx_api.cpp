@@ -1010,7 +1010,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     // (expand_pair_kernel.hip) -- the few thousand survivors then are ONE round of wave tasks instead of two.  Same lists.
     bool paired = false;
     if (a.live != nullptr && c->has_pot && a.ulex && !gp.lex && !c->tune.no_pair && a.yaw.tab == nullptr &&
-        mplx::pair_covers(c->dim, c->prm.control) && c->dim * gp.ndp <= 16 && a.ndy <= 16) {
+        mplx::pair_covers(c->dim, c->prm.control) && c->dim * gp.ndp <= 16 && a.ndy <= mplx::pair_max_yaw_rates()) {
       mplx::GridArgs b = a;
       int rm = c->tune.pair_rmax > 0 ? c->tune.pair_rmax : 3, per_cu = 0;
       size_t lds = 0;

@@ -21,7 +21,7 @@ struct GridLds {
   int w_node, w_est, w_hp, w_eq, w_eflag, w_box, w_misc, w_rowmap, w_list, w_cell, w_uq, wave_bytes;
   int o_uyaw, w_yaw, w_ycs, w_yq, w_hmask, w_vs, w_ycsr;  // yaw controls only
   int total;
-  int F, EN, PN, tts, KQ;
+  int F, EN, PN, PNC, tts, KQ;
   // ym & 3: 0 = no yaw, 1 = yaw, 2 = yaw with the per-sample heading cost (wyaw > 0); ym & 4: per-sample |vel| of a
   // potential map with gradient_weight != 0 (env_map.h:116); ndy = distinct yaw rates
   // ulex: the control table is the nested-loop enumeration of its per-axis values (GridArgs::ulex): the per-control
@@ -60,7 +60,11 @@ struct GridLds {
     w = (w + 15) & ~15;
     w_misc = w; w += 49 * 4;  // M_* below (M_WORDS)
     w_rowmap = w; w += ((n_max + 2) & ~1) * 2;  // per sample count n <= n_max: offset of its row inside an entry's block this pass (0xffff: not this pass)
-    w_list = w; w += ((nU + 1) & ~1) * 2;
+    // (lean layout: per combination of axis entries a word + a list position instead of the list of pairs)
+    PNC = ndp * ndp * (D == 3 ? ndp : 1);
+    // lean: [nU] f64 cost + [PNC] u32 word + [PNC] u16 first position + [nU] u16 list + [nU] u16 iterations
+    w = lean ? ((w + 7) & ~7) : w;
+    w_list = w; w += lean ? ((nU * 8 + PNC * 6 + ((nU + 1) & ~1) * 4 + 7) & ~7) : ((nU + 1) & ~1) * 2;
     w_cell = w; w += EN * rmax * tts + 8;  // + 8: the sample loop reads up to 7 codes past a row
     w = (w + 15) & ~15;
     w_uq = w; w += K >= 3 ? EN * 8 : 0;         // per entry: the top coefficient's quotient (u / 6, u / 24) for the rows

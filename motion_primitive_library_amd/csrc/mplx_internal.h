@@ -219,6 +219,7 @@ struct GridArgs {
 size_t pair_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, bool ycost, int ndy);
 int pair_waves_per_block();
 int pair_nodes_per_wave();
+int pair_max_yaw_rates();   // yaw rates a lane of it carries through its sample loop
 bool pair_covers(int dim, int control);
 hipError_t launch_expand_pair(int dim, int control, const GridArgs &a, hipStream_t s);
 int pair_resident_blocks(int dim, int control, size_t lds);
