@@ -31,10 +31,7 @@ constexpr int kPairGS = 32;                 // lanes per node
 constexpr int kPairNG = 64 / kPairGS;       // nodes per wave
 constexpr int kPairWPB = 4;                 // waves per workgroup
 constexpr int kPairBT = 64 * kPairWPB;
-#ifndef MPLX_PAIR_NY
-#define MPLX_PAIR_NY 4
-#endif
-constexpr int kPairNY = MPLX_PAIR_NY;       // yaw rates a lane carries through its sample loop (host: ndy <= kPairNY)
+constexpr int kPairNYMax = 4;               // yaw rates a lane carries through its sample loop (instantiations NY = 2, 3, 4)
 #ifndef MPLX_PAIR_UB
 #define MPLX_PAIR_UB 4
 #endif
@@ -328,7 +325,7 @@ __device__ __forceinline__ int grid_node_pairs(GridKernargPtr Ak, const NodeTabs
 #undef A
 
 #define A (*Ak)
-template <int D, int K>
+template <int D, int K, int kPairNY>
 __global__ __launch_bounds__(kPairBT) __attribute__((amdgpu_waves_per_eu(3)))
 void expand_pair_kernel(const GridArgs A_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -401,7 +398,16 @@ void expand_pair_kernel(const GridArgs A_kernarg) {
   const int NI = (NN + NG - 1) / NG;        // wave tasks: NG survivors each
   const int wave_id = (int)blockIdx.x * kPairWPB + wv;
   const int wave_stride = (int)gridDim.x * kPairWPB;
-  for (int it = wave_id; it < NI; it += wave_stride) {
+  // Fewer tasks than waves (the usual case: the launch is sized for them): the tasks are SPREAD over the waves -- wave w
+  // takes task floor(w NI / W) if that is a new one -- so that the idle waves are everywhere and every CU carries the same
+  // share, instead of the first NI waves working on three resident workgroups per CU and the last ones on two.
+  int it_first = wave_id, it_step = wave_stride;
+  if (NI <= wave_stride) {
+    const int t0 = (int)(((int64_t)wave_id * NI) / wave_stride), t1 = (int)(((int64_t)(wave_id + 1) * NI) / wave_stride);
+    it_first = t1 > t0 ? t0 : NI;
+    it_step = NI;
+  }
+  for (int it = it_first; it < NI; it += it_step) {
     asm volatile("" : "+s"(Ak));  // (the argument loads stay inside the iteration: expand_grid_kernel.hip)
     const int li = it * NG + grp;
     const bool real = li < NN;  // (an odd survivor count: the last task's second group repeats the first one's node and stores nothing)
@@ -790,37 +796,55 @@ void expand_pair_kernel(const GridArgs A_kernarg) {
 }
 #undef A
 
-template <int D, int K>
+template <int D_, int K_, int NY_>
+struct PairInst {
+  static constexpr int D = D_, K = K_, NY = NY_;
+};
+
+template <int D, int K, int NY>
 hipError_t pair_inst_attr() {
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
   if (!attr_set[dev] || dev == 63) {
-    hipError_t e = hipFuncSetAttribute((const void *)expand_pair_kernel<D, K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void *)expand_pair_kernel<D, K, NY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set[dev] = true;
   }
   return hipSuccess;
 }
 
-template <int D, int K>
+template <int D, int K, int NY>
 hipError_t launch_pair_inst(const GridArgs &a, hipStream_t stream) {
   if (a.n_nodes == 0) return hipSuccess;
   const size_t lds = pair_lds_bytes(D, K, a.nU, a.ndp, a.n_max, a.rmax, a.wyaw > 0, a.ndy);
-  if (hipError_t e = pair_inst_attr<D, K>()) return e;
-  hipLaunchKernelGGL((expand_pair_kernel<D, K>), dim3((unsigned)a.grid_limit), dim3(kPairBT), lds, stream, a);
+  if (hipError_t e = pair_inst_attr<D, K, NY>()) return e;
+  hipLaunchKernelGGL((expand_pair_kernel<D, K, NY>), dim3((unsigned)a.grid_limit), dim3(kPairBT), lds, stream, a);
   return hipGetLastError();
 }
 
-template <int D, int K>
+template <int D, int K, int NY>
 int pair_resident_inst(size_t lds) {
-  if (pair_inst_attr<D, K>() != hipSuccess) return 0;
+  if (pair_inst_attr<D, K, NY>() != hipSuccess) return 0;
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)expand_pair_kernel<D, K>, kPairBT, lds) != hipSuccess) {
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)expand_pair_kernel<D, K, NY>, kPairBT, lds) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
   return nb;
+}
+
+// (dim, control, yaw rates) -> instantiation: the sample loop carries NY = 2, 3 or 4 accumulators per lane
+template <class R, class F>
+R dispatch_pair(int dim, int control, int ndy, R none, F &&f) {
+  const int ny = ndy <= 2 ? 2 : (ndy == 3 ? 3 : 4);
+#define MPLX_PI(D, K) (ny == 2 ? f(PairInst<D, K, 2>{}) : (ny == 3 ? f(PairInst<D, K, 3>{}) : f(PairInst<D, K, 4>{})))
+  if (dim == 2 && control == 0x13) return MPLX_PI(2, 2);
+  if (dim == 2 && control == 0x17) return MPLX_PI(2, 3);
+  if (dim == 3 && control == 0x13) return MPLX_PI(3, 2);
+  if (dim == 3 && control == 0x17) return MPLX_PI(3, 3);
+#undef MPLX_PI
+  return none;
 }
 
 }  // namespace
@@ -830,25 +854,24 @@ size_t pair_lds_bytes(int dim, int order, int nU, int ndp, int n_max, int rmax, 
 }
 int pair_waves_per_block() { return kPairWPB; }
 int pair_nodes_per_wave() { return kPairNG; }
-int pair_max_yaw_rates() { return kPairNY; }
+int pair_max_yaw_rates() { return kPairNYMax; }
 
 // the configurations this kernel has an instantiation for (the host checks the rest of the scope)
 bool pair_covers(int dim, int control) { return (dim == 2 || dim == 3) && (control == 0x13 || control == 0x17); }
 
 hipError_t launch_expand_pair(int dim, int control, const GridArgs &a, hipStream_t s) {
-  if (dim == 2 && control == 0x13) return launch_pair_inst<2, 2>(a, s);
-  if (dim == 2 && control == 0x17) return launch_pair_inst<2, 3>(a, s);
-  if (dim == 3 && control == 0x13) return launch_pair_inst<3, 2>(a, s);
-  if (dim == 3 && control == 0x17) return launch_pair_inst<3, 3>(a, s);
-  return hipErrorInvalidValue;
+  if (a.ndy < 1 || a.ndy > kPairNYMax) return hipErrorInvalidValue;
+  return dispatch_pair<hipError_t>(dim, control, a.ndy, hipErrorInvalidValue, [&](auto t) {
+    using T = decltype(t);
+    return launch_pair_inst<T::D, T::K, T::NY>(a, s);
+  });
 }
 
-int pair_resident_blocks(int dim, int control, size_t lds) {
-  if (dim == 2 && control == 0x13) return pair_resident_inst<2, 2>(lds);
-  if (dim == 2 && control == 0x17) return pair_resident_inst<2, 3>(lds);
-  if (dim == 3 && control == 0x13) return pair_resident_inst<3, 2>(lds);
-  if (dim == 3 && control == 0x17) return pair_resident_inst<3, 3>(lds);
-  return 0;
+int pair_resident_blocks(int dim, int control, int ndy, size_t lds) {
+  return dispatch_pair<int>(dim, control, ndy, 0, [&](auto t) {
+    using T = decltype(t);
+    return pair_resident_inst<T::D, T::K, T::NY>(lds);
+  });
 }
 
 }  // namespace mplx

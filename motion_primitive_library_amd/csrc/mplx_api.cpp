@@ -197,7 +197,7 @@ void mplx_destroy(mplx_ctx *c) {
   release(c->done_count);
   for (DevBuf *b : {&c->map, &c->pot, &c->region_bits, &c->region_bytes, &c->U, &c->s_nodes, &c->s_status,
                     &c->s_cost, &c->s_hash, &c->s_state, &c->s_iters, &c->s_count, &c->s_action, &c->tables,
-                    &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx, &c->blk, &c->sat, &c->prep_lut, &c->prep_a, &c->prep_b, &c->post_keys, &c->post_ws, &c->live_list, &c->live_ctr, &c->e_parents, &c->e_action, &c->e_free, &c->e_cost, &c->e_cells, &c->e_count})
+                    &c->d_status, &c->d_cost, &c->d_hash, &c->d_state, &c->d_iters, &c->uvals, &c->uidx, &c->blk, &c->sat, &c->prep_lut, &c->prep_a, &c->prep_b, &c->post_keys, &c->post_ws, &c->live_list, &c->live_ctr, &c->edit_buf, &c->e_parents, &c->e_action, &c->e_free, &c->e_cost, &c->e_cells, &c->e_count})
     release(*b);
   (void)mplx_comm_destroy(c);
   release(c->comm_meta);
@@ -1017,12 +1017,12 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
       for (; rm >= 1 && per_cu < 1; rm--) {  // (rows per pass down to what fits at all)
         lds = mplx::pair_lds_bytes(c->dim, gp.order, c->nU, gp.ndp, gp.n_max, rm, c->prm.wyaw > 0, a.ndy);
         if (lds > 160 * 1024) continue;
-        const int key = c->prm.control | 0x200;  // (the occupancy cache's control word: bit 9 = the pair kernel)
+        const int key = c->prm.control | 0x200 | (a.ndy << 12);  // (the occupancy cache's control word: bit 9 = the pair kernel, bits 12+ its yaw rates)
         int nb = -1;
         for (const auto &e : c->grid_occ)
           if (e.control == key && e.pot == c->has_pot && e.lds == lds) nb = e.nb;
         if (nb < 0) {
-          nb = mplx::pair_resident_blocks(c->dim, c->prm.control, lds);
+          nb = mplx::pair_resident_blocks(c->dim, c->prm.control, a.ndy, lds);
           if (c->grid_occ.size() >= 8) c->grid_occ.clear();
           c->grid_occ.push_back({key, c->has_pot, lds, nb});
           if (getenv("MPLX_GRID_VERBOSE"))

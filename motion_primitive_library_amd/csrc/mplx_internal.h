@@ -222,7 +222,7 @@ int pair_nodes_per_wave();
 int pair_max_yaw_rates();   // yaw rates a lane of it carries through its sample loop
 bool pair_covers(int dim, int control);
 hipError_t launch_expand_pair(int dim, int control, const GridArgs &a, hipStream_t s);
-int pair_resident_blocks(int dim, int control, size_t lds);
+int pair_resident_blocks(int dim, int control, int ndy, size_t lds);
 constexpr int kWorkCounters = 64;
 // lane-per-node validate_yaw(t = 0) over a whole frontier (expand_grid_kernel.hip); fills live / live_n of `a`'s launch
 // (live_n is zero when the launch begins; the launch zeroes live_zero, the counter of the NEXT pre-screen of the stream)
