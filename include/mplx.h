@@ -572,7 +572,10 @@ int mplx_last_lists_route(const mplx_ctx *ctx);
  * control tables the reference's programs build -- the nested-loop (lexicographic) enumeration of per-axis values,
  * no yaw, occupancy map (expand_lex_kernel.hip; MPLX_GRID_LEX=0 sends those to the general kernel too).  Which one
  * the last mplx_expand_lists* call ran: MPLX_KERNEL_NONE when the route was not GRID.                              */
-enum { MPLX_KERNEL_NONE = 0, MPLX_KERNEL_GRID = 1, MPLX_KERNEL_LEX = 2 };
+enum { MPLX_KERNEL_NONE = 0, MPLX_KERNEL_GRID = 1, MPLX_KERNEL_LEX = 2,
+       /* ABI v9: expand_pair_kernel.hip -- yaw controls on a potential map over a pre-screened frontier, two nodes per
+        * wave (MPLX_GRID_PAIR=0 keeps such launches on the general kernel); identical lists                          */
+       MPLX_KERNEL_PAIR = 3 };
 int mplx_last_grid_kernel(const mplx_ctx *ctx);
 /* ABI v7.  Which form of the node-identity pass the last mplx_post_*_device call with canon ran (all produce the
  * same canon[]): the table in HBM (small batches), the claimed partition (buckets of fixed capacity, one host round

@@ -694,6 +694,7 @@ int launch_grid(mplx_ctx *c, mplx::GridArgs *a) {
   const hipError_t e = a->lex ? mplx::launch_expand_lex(c->dim, c->prm.control, *a, c->stream)
                               : mplx::launch_expand_grid(c->dim, c->prm.control, *a, c->stream);
   c->last_grid_lex = a->lex != 0;
+  c->last_grid_pair = false;
   if (e != hipSuccess) {
     if (a->work) {
       (void)hipStreamSynchronize(c->stream);
@@ -1042,6 +1043,7 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
         const hipError_t e = mplx::launch_expand_pair(c->dim, c->prm.control, b, c->stream);
         if (e != hipSuccess) return fail(c, MPLX_ERR_HIP, "expand_pair_kernel launch failed: %s", hipGetErrorString(e));
         c->last_grid_lex = false;
+        c->last_grid_pair = true;
         paired = true;
       }
     }
@@ -1705,7 +1707,8 @@ int mplx_set_lists_route(mplx_ctx *c, int route) {
 int mplx_last_lists_route(const mplx_ctx *c) { return c ? c->last_route : MPLX_ERR_ARG; }
 int mplx_last_grid_kernel(const mplx_ctx *c) {
   if (!c) return MPLX_ERR_ARG;
-  return c->last_route != MPLX_ROUTE_GRID ? MPLX_KERNEL_NONE : (c->last_grid_lex ? MPLX_KERNEL_LEX : MPLX_KERNEL_GRID);
+  if (c->last_route != MPLX_ROUTE_GRID) return MPLX_KERNEL_NONE;
+  return c->last_grid_pair ? MPLX_KERNEL_PAIR : (c->last_grid_lex ? MPLX_KERNEL_LEX : MPLX_KERNEL_GRID);
 }
 
 int mplx_last_identity_form(const mplx_ctx *c) { return c ? c->last_identity_form : MPLX_ERR_ARG; }

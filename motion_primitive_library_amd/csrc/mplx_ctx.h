@@ -84,6 +84,7 @@ struct mplx_ctx {
   } tune;
   int lists_route = MPLX_ROUTE_AUTO;
   int last_route = MPLX_ROUTE_AUTO;
+  bool last_grid_pair = false;  // ... or to expand_pair_kernel.hip
   bool last_grid_lex = false;  // the last factorised launch went to expand_lex_kernel.hip (mplx_debug_last_kernel)
   int n_cus = 256;
 

@@ -766,8 +766,9 @@ class EnvMap:
 
     def last_grid_kernel(self):
         """Which kernel of the GRID route the last expand_lists* call ran: "lex" (expand_lex_kernel.hip: lexicographic
-        control table, no yaw, occupancy map), "grid" (expand_grid_kernel.hip), "none" (another route)."""
-        return {0: "none", 1: "grid", 2: "lex"}[_abi.lib().mplx_last_grid_kernel(self._ctx)]
+        control table, no yaw, occupancy map), "grid" (expand_grid_kernel.hip), "pair" (expand_pair_kernel.hip: yaw controls on
+        a potential map over a pre-screened frontier, two nodes per wave), "none" (another route)."""
+        return {0: "none", 1: "grid", 2: "lex", 3: "pair"}[_abi.lib().mplx_last_grid_kernel(self._ctx)]
 
     def last_identity_form(self):
         """Which form of the node-identity pass the last post_lists / post_packed call with canon ran: "table" (in HBM, small

@@ -58,11 +58,12 @@ def full_size_workload(engine, name):
     return wl
 
 
-# which kernel serves route "grid": the lexicographic one for C2 / C3 / C4 (asserted, not assumed), the general factorised
-# one for C5 -- and the general one again on C2 / C3 / C4 with the lexicographic kernel switched off (MPLX_GRID_LEX=0): it
+# which kernel serves route "grid": the lexicographic one for C2 / C3 / C4 (asserted, not assumed), the two-nodes-per-wave one
+# for C5 (round 6; and the general factorised one with MPLX_GRID_PAIR=0) -- and the general one again on C2 / C3 / C4 with the lexicographic kernel switched off (MPLX_GRID_LEX=0): it
 # is still the product path of shuffled tables, SNP and > 32 values per axis
 @pytest.mark.parametrize("name,route,kernel", [("C2", "grid", "lex"), ("C3", "grid", "lex"), ("C4", "grid", "lex"),
-                                               ("C5", "grid", "grid"), ("C5-tunnel", "grid", "grid"),
+                                               ("C5", "grid", "pair"), ("C5-tunnel", "grid", "pair"),
+                                               ("C5", "grid", "nopair"), ("C5-tunnel", "grid", "nopair"),
                                                ("C2", "grid", "general"), ("C3", "grid", "general"), ("C4", "grid", "general"),
                                                ("C4", "tile", "none"), ("C3", "dense", "none"),
                                                # SNP (quad + the root loops of primitive.h:152-193), VEL and the 2D
@@ -70,11 +71,14 @@ def full_size_workload(engine, name):
                                                # that serve them
                                                ("C3-SNP", "grid", "grid"), ("C3-SNP", "dense", "none"),
                                                ("C2-VEL", "grid", "lex"), ("C2-VEL", "grid", "general"),
-                                               ("C2-YAWPOT", "grid", "grid")])
+                                               ("C2-YAWPOT", "grid", "grid")])  # (4 096 nodes: no pre-screen, the general kernel)
 def test_full_size_every_pair_against_the_reference(engine, oracle_lib, monkeypatch, name, route, kernel):
     use_ref = require_reference_build()
     if kernel == "general":
         monkeypatch.setenv("MPLX_GRID_LEX", "0")
+        kernel = "grid"
+    if kernel == "nopair":  # yaw + potential over a pre-screened frontier on the general kernel (expand_pair_kernel.hip switched off)
+        monkeypatch.setenv("MPLX_GRID_PAIR", "0")
         kernel = "grid"
     wl = full_size_workload(engine, name)
     nU, N = wl.U.shape[0], wl.n_nodes
