@@ -61,6 +61,8 @@ def kernel_name(env, route):
     """The kernel the last lists launch ran: the GRID route has two (mplx_last_grid_kernel)."""
     if route == "grid" and env.last_grid_kernel() == "lex":
         return "expand_lex_kernel"
+    if route == "grid" and env.last_grid_kernel() == "pair":
+        return "expand_pair_kernel"
     return KERNEL_NAME[route]
 
 

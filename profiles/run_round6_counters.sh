@@ -18,7 +18,7 @@ done
 python - "$OUT" <<'PY'
 import csv, collections, glob, json, sys
 out = sys.argv[1]
-KERNELS = ("expand_lex_kernel", "expand_grid_kernel", "expand_tile_kernel")
+KERNELS = ("expand_lex_kernel", "expand_grid_kernel", "expand_tile_kernel", "expand_pair_kernel")
 res = {}
 for W in ("C2", "C3", "C4", "C5"):
     rec = {}
@@ -60,6 +60,12 @@ for W in ("C2", "C3", "C4", "C5"):
         rec["bench_under_rocprof"] = {"error": str(e)}
     rec["source"] = "profiles/run_round6_counters.sh: rocprofv3 --pmc SQ_INSTS_VALU.. / FETCH_SIZE / WRITE_SIZE, each its own pass; averages of the last 3 dispatches (the timed steps); KiB as reported x 1024"
     res[W] = rec
+import os
+prev = {}
+if os.path.exists("profiles/r06_counters.json"):  # (a partial run -- WL="C5" -- keeps the other configurations' entries)
+    prev = json.load(open("profiles/r06_counters.json"))
+prev.update(res)
+res = prev
 json.dump(res, open(out + "/r06_counters.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
