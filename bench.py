@@ -191,10 +191,10 @@ def run_config(m, wl, steps, warmup, device=0, route=None):
             "pairs": wl.n_pairs, "emitted": n_emit, "finite": n_fin, "map_samples": n_samples, "kernel": kname}
 
 
-def cpu_baseline(wl, rep_seconds=1.5, rep_seconds_1thread=0.4, reps=5):
+def cpu_baseline(wl, rep_seconds=1.5, rep_seconds_1thread=0.4, reps=7):
     """The reference's CPU path (oracle/_ref, "reference"; the restatement, "port", when that build is absent) timed on
     this box's host cores on a bounded sample of the workload, to SURVEY 8(d)'s protocol: one warm-up repetition, then
-    `reps` >= 5 timed repetitions, the MEDIAN reported (min / max beside it); every repetition is one call that runs at
+    `reps` >= 5 timed repetitions (7), the MEDIAN reported (min / max beside it); every repetition is one call that runs at
     least ~0.3 s -- a frontier too small for that is walked several times inside the repetition (the nodes tiled), so
     thread start-up is not what is measured.  All host threads, and one thread."""
     from oracle import oracle as O
@@ -212,7 +212,7 @@ def cpu_baseline(wl, rep_seconds=1.5, rep_seconds_1thread=0.4, reps=5):
         rate = probe / max(sec, 1e-9)  # nodes / s
         want = max(probe, int(rate * want_seconds))
         if want >= wl.n_nodes:
-            loops = int(min(64, max(1, round(want / wl.n_nodes))))
+            loops = int(min(1024, max(1, round(want / wl.n_nodes))))
             nodes = np.ascontiguousarray(np.tile(wl.nodes, (1, loops))) if loops > 1 else wl.nodes
             n_once = wl.n_nodes
         else:
@@ -729,7 +729,7 @@ def extras(m, args, wl, out):
                 # per configuration the reference's CPU path beside the kernel (1 warm-up + 5 repetitions of
                 # >= 0.3 s each, median; the small frontiers are walked several times per repetition)
                 try:
-                    cb, _, _ = cpu_baseline(w, rep_seconds=0.5, rep_seconds_1thread=0.3)
+                    cb, _, _ = cpu_baseline(w, rep_seconds=0.6, rep_seconds_1thread=0.3)
                     r["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "value_1thread", "protocol")}
                     r["speedup_vs_cpu_all_cores"] = r["pairs_per_s"] / cb["value"]
                     r["speedup_vs_cpu_1thread"] = r["pairs_per_s"] / cb["value_1thread"]
@@ -861,6 +861,8 @@ def compact_line(out, detail_path):
     if isinstance(out.get("other_configs"), dict):
         oc = {}
         for name, r in out["other_configs"].items():
+            if name == "leg_seconds":
+                continue
             if not isinstance(r, dict) or "kernel_ms" not in r:
                 oc[name] = r
                 continue
