@@ -78,7 +78,7 @@ def _same_lists(a, b, n_nodes, what):
 
 
 @pytest.mark.parametrize("dim,control", [(2, 0x13), (3, 0x13), (2, 0x17), (3, 0x17)])
-@pytest.mark.parametrize("yaw_rates", [[-0.5, 0.5], [-0.5, 0.0, 0.5], [-0.6, -0.2, 0.2, 0.6]])
+@pytest.mark.parametrize("yaw_rates", [[0.3], [-0.5, 0.5], [-0.5, 0.0, 0.5], [-0.6, -0.2, 0.2, 0.6]])
 @pytest.mark.parametrize("variant", ["heading", "plain", "gradient+region"])
 def test_pair_kernel_equals_reference_and_general_kernel(engine, oracle_lib, monkeypatch, dim, control, yaw_rates, variant):
     wyaw = 0.0 if variant == "plain" else 1.0
