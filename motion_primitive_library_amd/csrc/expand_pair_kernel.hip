@@ -13,7 +13,10 @@
 //     nodes through every phase, so 5.2 k nodes are 2.6 k wave tasks -- ONE round on 3 072 resident waves (3 per SIMD:
 //     the kernel may use 168 VGPRs) -- and the low-lane phases run at twice the utilisation;
 //   * the velocity of a sample is computed where it is used (K = 2: one multiply-add per axis from the sample time)
-//     instead of being staged per (entry, sample) in LDS: a node needs 5.5 KB, 24 nodes fit a CU.
+//     instead of being staged per (entry, sample) in LDS: a node needs 6 KB, 24 nodes fit a CU;
+//   * a lane per COMBINATION of axis entries walks the samples once for all of its yaw rates (same cells, same potential
+//     terms, one v.normalized() per sample; the heading term per yaw rate), the costs wait in LDS at their list positions
+//     and a dense pass writes every row of the list in whole lines.
 // Everything that decides a RESULT is the arithmetic of expand_grid_kernel.hip, expression for expression
 // (mplx_grid_common.h, mplx_device_common.h; -ffp-contract=off): the two kernels write bit-identical lists
 // (tests/test_gpu_fullsize.py runs C5, C5 with a tunnel and the 2D variant through both; tests/test_gpu_lists.py).
