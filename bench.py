@@ -206,24 +206,35 @@ def cpu_baseline(wl, rep_seconds=1.5, rep_seconds_1thread=0.4, reps=7):
     use_ref = os.path.exists(O.REF_SO)
 
     def protocol(threads, want_seconds):
-        # size of one repetition from a probe: whole passes over the frontier when it is small, a prefix when it is large
+        # size of one repetition: whole passes over the frontier when it is small, a prefix when it is large.  Sized from a
+        # probe, then corrected from the repetition it produced (a probe of a few nodes per thread measures thread start-up,
+        # not throughput: C2's first sizing gave repetitions of 0.15 s) -- these sizing runs are the warm-up
+        def sized(want):
+            if want >= wl.n_nodes:
+                loops = int(min(4096, max(1, round(want / wl.n_nodes))))
+                return (np.ascontiguousarray(np.tile(wl.nodes, (1, loops))) if loops > 1 else wl.nodes), loops, wl.n_nodes
+            return np.ascontiguousarray(wl.nodes[:, :want]), 1, want
+
         probe = min(wl.n_nodes, max(threads * 8, 64))
         sec, _ = O.time_expand(oenv, wl.nodes[:, :probe], threads=threads, reps=1, ref=use_ref)
-        rate = probe / max(sec, 1e-9)  # nodes / s
-        want = max(probe, int(rate * want_seconds))
-        if want >= wl.n_nodes:
-            loops = int(min(1024, max(1, round(want / wl.n_nodes))))
-            nodes = np.ascontiguousarray(np.tile(wl.nodes, (1, loops))) if loops > 1 else wl.nodes
-            n_once = wl.n_nodes
-        else:
-            loops, n_once = 1, want
-            nodes = np.ascontiguousarray(wl.nodes[:, :want])
-        n = nodes.shape[1]
-        O.time_expand(oenv, nodes, threads=threads, reps=1, ref=use_ref)  # the warm-up repetition
-        secs, st = [], None
-        for _ in range(reps):
-            sec, st = O.time_expand(oenv, nodes, threads=threads, reps=1, ref=use_ref)
-            secs.append(sec)
+        want = max(probe, int(probe / max(sec, 1e-9) * want_seconds))
+        cap = 64 * 1024 * 1024 // max(1, wl.nodes.shape[0])  # (nodes of a repetition: 512 MiB of frontier at most)
+        for attempt in range(3):
+            for _ in range(4):
+                nodes, loops, n_once = sized(min(want, cap))
+                sec, _ = O.time_expand(oenv, nodes, threads=threads, reps=1, ref=use_ref)  # sizing + warm-up repetition
+                if 0.8 * want_seconds <= sec <= 1.6 * want_seconds or (sec < want_seconds and nodes.shape[1] >= cap):
+                    break
+                want = max(threads, int(nodes.shape[1] * want_seconds / max(sec, 1e-9) * 1.05))  # (either direction)
+            n = nodes.shape[1]
+            secs, st = [], None
+            for _ in range(reps):
+                sec, st = O.time_expand(oenv, nodes, threads=threads, reps=1, ref=use_ref)
+                secs.append(sec)
+            med_s = sorted(secs)[len(secs) // 2]
+            if med_s >= 0.6 * want_seconds or n >= cap:  # (else the sizing run was an outlier: once more with its own figure)
+                break
+            want = int(n * want_seconds / max(med_s, 1e-9) * 1.05)
         rates = sorted(n * nU / t for t in secs)
         med = rates[len(rates) // 2]
         return {"value": med, "min": rates[0], "max": rates[-1], "spread": (rates[-1] - rates[0]) / med, "reps": reps,
@@ -729,7 +740,7 @@ def extras(m, args, wl, out):
                 # per configuration the reference's CPU path beside the kernel (1 warm-up + 5 repetitions of
                 # >= 0.3 s each, median; the small frontiers are walked several times per repetition)
                 try:
-                    cb, _, _ = cpu_baseline(w, rep_seconds=0.6, rep_seconds_1thread=0.3)
+                    cb, _, _ = cpu_baseline(w, rep_seconds=0.8, rep_seconds_1thread=0.3)
                     r["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "value_1thread", "protocol")}
                     r["speedup_vs_cpu_all_cores"] = r["pairs_per_s"] / cb["value"]
                     r["speedup_vs_cpu_1thread"] = r["pairs_per_s"] / cb["value_1thread"]
@@ -986,6 +997,13 @@ def main():
         os.execv(sys.executable, cmd)
     if world != args.gpus:
         args.gpus = world
+
+    # stdout carries the ONE JSON line and nothing else: libraries under the legs print through C stdio (RCCL's version
+    # banner, the reference build's "[PlannerBase] use Lifelong Planning A*" of planner_base.h:173), so descriptor 1 is
+    # pointed at stderr for the duration of the run and the line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -1401,8 +1419,7 @@ def main():
         slots.free()
         frontier.free()
         env.close()
-    # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which (buffered when
-    # stdout is a pipe or a file) would otherwise land after it at exit.  Every rank flushes, then rank 0 prints.
+    # Every rank flushes what C stdio still buffers (to stderr, see the top of main), then rank 0 prints the line.
     sys.stdout.flush()
     try:
         import ctypes
@@ -1421,7 +1438,8 @@ def main():
         except OSError as e:
             detail_path = "not written: %s" % e
         line = compact_line(out, detail_path)
-        print(json.dumps(line, separators=(",", ":")), flush=True)
+        os.write(line_fd, (json.dumps(line, separators=(",", ":")) + "\n").encode())
+    os.close(line_fd)
     if distributed:
         dist.destroy_process_group()
 

@@ -22,7 +22,7 @@
 // (tests/test_gpu_fullsize.py runs C5, C5 with a tunnel and the 2D variant through both; tests/test_gpu_lists.py).
 //
 // Scope: Dim 2 / 3, ACCxYAW / JRKxYAW, potential map (with or without a search region, gradient weight, heading cost),
-// lexicographic control table with D * ndp <= 16 entries and <= 16 yaw rates, a pre-screened frontier (GridArgs::live).
+// lexicographic control table with D * ndp <= 16 entries and <= 4 yaw rates, a pre-screened frontier (GridArgs::live).
 // Everything else -- and the host-libm fix pass of the yaw pinning -- stays with expand_grid_kernel.hip.
 #include "mplx_grid_common.h"
 

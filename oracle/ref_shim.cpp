@@ -143,7 +143,8 @@ struct Gate {
 template <int D>
 void expand_range(const mpl_oracle_env *e, const double *nodes, int64_t n_nodes, int64_t lo, int64_t hi,
                   mpl_oracle_out *out, mpl_oracle_stats *st, bool dense,
-                  std::shared_ptr<MPL::MapUtil<D>> shared_map = nullptr, Gate *gate = nullptr) {
+                  std::shared_ptr<MPL::MapUtil<D>> shared_map = nullptr, Gate *gate = nullptr,
+                  std::atomic<int64_t> *next = nullptr, int64_t chunk = 1) {
   Rig<D> rig(e, shared_map);
   if (gate) gate->arrive_and_wait();
   const int64_t n_slots = n_nodes * e->nU;
@@ -151,6 +152,16 @@ void expand_range(const mpl_oracle_env *e, const double *nodes, int64_t n_nodes,
   std::vector<decimal_t> cost;
   std::vector<int> act;
   mpl_oracle_stats s = {0, 0, 0, 0, 0, 0, 0.0};
+  /* `next`: the threads claim chunks of nodes from a shared counter instead of one fixed range each -- a timed run on
+   * a busy many-core host then ends when the work does, not when the unluckiest thread's range does */
+  for (bool more = true; more;) {
+  if (next) {
+    lo = next->fetch_add(chunk, std::memory_order_relaxed);
+    hi = std::min<int64_t>(n_nodes, lo + chunk);
+    if (lo >= n_nodes) break;
+  } else {
+    more = false;
+  }
   for (int64_t k = lo; k < hi; k++) {
     const Waypoint<D> curr = load_wp<D>(nodes, n_nodes, k, e->control);
     rig.env->expanded_nodes_.clear();
@@ -193,6 +204,7 @@ void expand_range(const mpl_oracle_env *e, const double *nodes, int64_t n_nodes,
       }
     }
   }
+  }
   *st = s;
 }
 
@@ -223,6 +235,10 @@ int run(const mpl_oracle_env *env, const double *nodes, int64_t n_nodes, mpl_ora
   std::shared_ptr<MPL::MapUtil<3>> m3;
   if (env->dim == 2) m2 = Rig<2>::make_map(env); else m3 = Rig<3>::make_map(env);
   Gate gate;
+  /* timed runs: chunks of nodes from a shared counter, about 32 per thread (at least 16 nodes, at most 1024) */
+  std::atomic<int64_t> next{0};
+  const int64_t chunk = std::min<int64_t>(1024, std::max<int64_t>(16, n_nodes / ((int64_t)threads * 32)));
+  std::atomic<int64_t> *claim = (seconds && threads > 1) ? &next : nullptr;
   std::chrono::steady_clock::time_point t0;
   std::thread starter([&] {
     while (gate.ready.load() < threads) std::this_thread::yield();
@@ -230,8 +246,8 @@ int run(const mpl_oracle_env *env, const double *nodes, int64_t n_nodes, mpl_ora
     gate.go.store(true, std::memory_order_release);
   });
   run_threads(n_nodes, threads, [&](int t, int64_t lo, int64_t hi) {
-    if (env->dim == 2) expand_range<2>(env, nodes, n_nodes, lo, hi, out, &per[(size_t)t], dense, m2, &gate);
-    else expand_range<3>(env, nodes, n_nodes, lo, hi, out, &per[(size_t)t], dense, m3, &gate);
+    if (env->dim == 2) expand_range<2>(env, nodes, n_nodes, lo, hi, out, &per[(size_t)t], dense, m2, &gate, claim, chunk);
+    else expand_range<3>(env, nodes, n_nodes, lo, hi, out, &per[(size_t)t], dense, m3, &gate, claim, chunk);
   });
   starter.join();
   if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
