@@ -1,3 +1,6 @@
+"""CPU baselines of two bench runs of one box side by side: python profiles/micro/compare_bench_runs.py DIR with DIR/line_{1,2}.json
+(the stdout of `python bench.py`) and DIR/detail_{1,2}.json (MPLX_BENCH_DETAIL).  Prints, per configuration, the two all-core medians,
+their difference, the repetition lengths and spreads, and the one-thread rates."""
 import json, sys
 d0=sys.argv[1]
 r={}
