@@ -1064,20 +1064,47 @@ def main():
     map_source = "generated and uploaded by every rank" if distributed and world > 1 else "generated and uploaded once"
     if share:
         t_map = time.perf_counter()
+        def all_ranks_ok(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+
+        via_abi = False
         if backend == "nccl":
-            uid = torch.frombuffer(bytearray(m.EnvMap.comm_unique_id() if rank == 0 else bytes(128)), dtype=torch.uint8).cuda()
+            # The C ABI's own communicator (csrc/comm_api.cpp).  Every step is agreed on by all ranks before the next one, and
+            # any failure sends ALL ranks to the torch.distributed copy below: the map broadcast is set-up, not the metric.
+            comm_err = None
+            try:
+                raw = bytearray(m.EnvMap.comm_unique_id()) if rank == 0 else bytearray(128)
+            except Exception as e:  # noqa: BLE001
+                raw, comm_err = bytearray(128), "comm_unique_id: %s" % e
+            uid = torch.frombuffer(raw, dtype=torch.uint8).cuda()
             dist.broadcast(uid, 0)
-            env.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
-            env.comm_broadcast_map(0)  # map (+ potential map / search region when rank 0 has them)
-            map_source = "rank 0's map replicated by mplx_comm_broadcast_map (ncclBroadcast over xGMI, device to device)"
-        else:  # rehearsal backends (several ranks on one GPU): RCCL refuses that, so the copy goes through torch
+            ok = comm_err is None and any(uid.cpu().numpy().tobytes())
+            if all_ranks_ok(ok):
+                try:
+                    env.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+                except Exception as e:  # noqa: BLE001
+                    ok, comm_err = False, "comm_init: %s" % e
+                if all_ranks_ok(ok):
+                    try:
+                        env.comm_broadcast_map(0)  # map (+ potential map / search region when rank 0 has them)
+                    except Exception as e:  # noqa: BLE001
+                        ok, comm_err = False, "comm_broadcast_map: %s" % e
+                    via_abi = all_ranks_ok(ok)
+            if via_abi:
+                map_source = "rank 0's map replicated by mplx_comm_broadcast_map (ncclBroadcast over xGMI, device to device)"
+            elif comm_err:
+                stats["comm_error"] = comm_err
+        if not via_abi:  # rehearsal backends (several ranks on one GPU: RCCL refuses that), or the fallback of the above
             has_pot = int(from_rank0(np.array([wl.potential is not None], np.int64))[0])
             wl.grid = from_rank0(wl.grid)
             env.setMap(wl.origin, wl.map_dim, wl.grid, wl.res)
             if has_pot:
                 wl.potential = from_rank0(wl.potential if rank == 0 else np.zeros_like(wl.grid))
                 env.set_potential_map(wl.potential)
-            map_source = "rank 0's map broadcast through torch.distributed (%s rehearsal)" % backend
+            map_source = "rank 0's map broadcast through torch.distributed (%s%s)" % (backend, " rehearsal" if backend != "nccl" else
+                                                                                       "; the C ABI's communicator failed on a rank")
         stats["map_broadcast_ms"] = (time.perf_counter() - t_map) * 1e3
     alloc = shard.torch_alloc("cuda:%d" % local_rank) if distributed else None  # RCCL moves these very buffers
     frontier = env.upload_frontier(my_nodes)
