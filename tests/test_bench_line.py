@@ -58,3 +58,24 @@ def test_compact_line_survives_failed_legs():
     long_form["plan"]["3D"] = {"error": "y"}
     line = b.compact_line(long_form, "d.json")
     assert line["wavefront"] == {"error": "RuntimeError: boom"} and line["plan"]["3D"] == {"error": "y"}
+
+
+def test_cpu_baseline_protocol_on_a_small_workload():
+    """bench.py::cpu_baseline end to end on the CPU (the reference build or the restatement, whichever is present): the
+    repetition is sized by measurement, one warm-up + `reps` timed repetitions, the median and its spread reported, for all
+    host threads and for one."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import motion_primitive_library_amd as m
+    b = _bench()
+    wl = m.workloads.make("C2", scale=0.125, n_nodes=96)
+    cb, oenv, n = b.cpu_baseline(wl, rep_seconds=0.08, rep_seconds_1thread=0.05, reps=5)
+    assert cb["unit"] == "pairs/s" and cb["value"] > 0 and cb["value_1thread"] > 0
+    assert cb["kind"] in ("reference", "port") and "median" in cb["sample"] and cb["cores"] >= 1
+    for leg in ("all_cores", "one_thread"):
+        p = cb["protocol"][leg]
+        assert p["reps"] == 5 and p["min"] <= p["value"] <= p["max"]
+        assert p["rep_seconds"] > 0.02, p                          # sized up from the 96-node frontier ...
+        assert p["frontier_passes_per_rep"] > 1 and p["frontier_nodes_per_pass"] == 96   # ... by walking it many times
+        assert p["nodes_per_rep"] == p["frontier_passes_per_rep"] * 96
+    assert n == cb["protocol"]["all_cores"]["nodes_per_rep"] and oenv is not None
