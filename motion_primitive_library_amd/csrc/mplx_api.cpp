@@ -971,7 +971,10 @@ int lists_device(mplx_ctx *c, const double *d_nodes, int64_t n_nodes, int64_t no
     a.l_count = o->count; a.l_action = o->action; a.l_cost = o->cost; a.l_hash = o->hash;
     a.l_state = o->state; a.l_stride = o->state_stride; a.l_iters = o->iters;
     a.l_nstride = o->node_stride ? o->node_stride : c->nU;
-    a.l_pad = (a.l_nstride % 32 == 0 && !c->tune.no_line_pad) ? 1 : 0;  // see expand_grid_kernel.hip
+    // Line padding (expand_grid_kernel.hip) pays where a launch is bound by its stores -- the large control tables (C4: 729,
+    // 17^3).  With short lists it only adds bytes: C5 (81 controls, 24 successors per live node) writes 23.1 MB padded and
+    // 18.8 MB unpadded in the same 46.5 us, C3 and C2 likewise (profiles/r06_line_pad_small_lists.txt).
+    a.l_pad = (a.l_nstride % 32 == 0 && !c->tune.no_line_pad && c->nU >= mplx::kLinePadMinControls) ? 1 : 0;
     a.post = post_of(c, o);
     if (int rc = yaw_slot(c, &a.yaw)) return rc;
     // Yaw controls with a heading limit on a frontier of several nodes per wave: validate_yaw(t = 0) of every node

@@ -224,6 +224,8 @@ bool pair_covers(int dim, int control);
 hipError_t launch_expand_pair(int dim, int control, const GridArgs &a, hipStream_t s);
 int pair_resident_blocks(int dim, int control, int ndy, size_t lds);
 constexpr int kWorkCounters = 64;
+// list rows are completed to whole 128-byte lines only for control tables of at least this many entries (mplx_api.cpp)
+constexpr int kLinePadMinControls = 256;
 // lane-per-node validate_yaw(t = 0) over a whole frontier (expand_grid_kernel.hip); fills live / live_n of `a`'s launch
 // (live_n is zero when the launch begins; the launch zeroes live_zero, the counter of the NEXT pre-screen of the stream)
 hipError_t launch_grid_prescreen(int dim, int control, const GridArgs &a, int32_t *live, uint32_t *live_n, uint32_t *live_zero,

@@ -68,7 +68,7 @@ extern "C" int mplx_debug_store_model(mplx_ctx *c, const mplx_succ_lists *L, int
   if (int rc = bind_device(c)) return rc;
   if (int rc = resolve_pending(c)) return rc;
   const int64_t S = L->node_stride ? L->node_stride : c->nU;
-  const int pad = (S % 32 == 0 && !c->tune.no_line_pad) ? 1 : 0;
+  const int pad = (S % 32 == 0 && !c->tune.no_line_pad && c->nU >= mplx::kLinePadMinControls) ? 1 : 0;  // (the expansion's own rule)
   // (experiments: MPLX_STORE_MODEL_MODE / _WGS vary the order inside a node, the nodes per chunk and the workgroups per CU)
   const char *em = getenv("MPLX_STORE_MODEL_MODE"), *ew = getenv("MPLX_STORE_MODEL_WGS");
   const int mode = em ? atoi(em) : 0, wgs = ew && atoi(ew) > 0 ? atoi(ew) : 5;
