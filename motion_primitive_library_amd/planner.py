@@ -133,6 +133,12 @@ class MapPlanner:
     def setEpsilon(self, eps): self._cfg.epsilon = float(eps)
     def setMaxNum(self, n): self._cfg.max_expand = int(n)
 
+    def setTmax(self, t):
+        """PlannerBase::setTmax (planner_base.h:203-205).  Kept and, as in the reference's MapPlanner, without effect on the
+        search: t_max is only read by env_base::is_goal (env_base.h:24), which env_map::is_goal (env_map.h:25-45) overrides
+        without it."""
+        self._t_max = float(t)
+
     def setTol(self, tol_pos, tol_vel=-1.0, tol_acc=-1.0):
         self._cfg.tol_pos, self._cfg.tol_vel, self._cfg.tol_acc = float(tol_pos), float(tol_vel), float(tol_acc)
 

@@ -39,7 +39,7 @@ def provider_from_oracle(oenv, ref=False):
     return (single, batched, user), ce  # keep `ce` alive as long as the planner
 
 
-def run_c1(engine, ref=False, batch=1):
+def run_c1(engine, ref=False, batch=1, t_max=None):
     m = engine
     c = corridor()
     U = m.workloads.grid_controls([-0.5, 0.0, 0.5], 2)  # test_planner_2d.cpp:49-53
@@ -54,6 +54,8 @@ def run_c1(engine, ref=False, batch=1):
     planner.setDt(1.0)
     planner.setU(U)
     planner.setBatch(batch)
+    if t_max is not None:
+        planner.setTmax(t_max)
     start = m.Waypoint(2, m.ACC, pos=c["start"])
     goal = m.Waypoint(2, m.ACC, pos=c["goal"])
     ok = planner.plan(start, goal)
@@ -82,6 +84,13 @@ def test_c1_known_answer_with_oracle(engine):
     assert traj.J(engine.JRK) == 0.0 and traj.J(engine.SNP) == 0.0
     assert s["cost"] == 351.5 and s["segments"] == 35         # g = w*T + J(ACC) = 10*35 + 1.5
     assert s["device_launches"] == s["expansions"] and s["pairs"] == 9 * s["expansions"]
+
+
+def test_c1_t_max_is_kept_and_ignored_like_the_reference_map_planner_does(engine):
+    """PlannerBase::setTmax only reaches env_base::is_goal (env_base.h:24); env_map::is_goal (env_map.h:25-45) overrides it
+    without the test, so a horizon shorter than the plan changes nothing in the reference's MapPlanner -- nor here."""
+    ok, s, traj, _ = run_c1(engine, batch=16, t_max=3.0)
+    assert ok and s["closed"] == 615 and traj.getTotalTime() == 35.0 and s["cost"] == 351.5
 
 
 def test_c1_batched_expansion_gives_the_same_plan(engine):
