@@ -51,8 +51,6 @@ __device__ __forceinline__ unsigned long long gballot(int gsh, bool p) {  // bal
   if (GS == 64) return b;
   return (b >> gsh) & ((1ull << GS) - 1ull);
 }
-template <int GS>
-__device__ __forceinline__ int guni(int x) { return GS == 64 ? __builtin_amdgcn_readfirstlane(x) : x; }  // group-uniform value
 
 struct NodeTabs {  // where one node's tables live (LDS)
   double *node, *est;
@@ -60,7 +58,7 @@ struct NodeTabs {  // where one node's tables live (LDS)
   int *eq, *eflag, *misc;
   double *uq, *yawT, *ycs;
   int *yq;
-  unsigned short *hmask, *list;
+  unsigned short *hmask;
 };
 
 #define A (*Ak)
@@ -240,91 +238,6 @@ __device__ __forceinline__ int grid_node_setup(GridKernargPtr Ak, const NodeTabs
   return flag;
 }
 
-// Phase A: every pair; the ordered list of the emitted ones (t.list); returns their number, nm = the set of sample
-// counts in use.
-template <int D, int K, bool YAW, int GS>
-__device__ __forceinline__ int grid_node_pairs(GridKernargPtr Ak, const NodeTabs &t, const unsigned short *s_uidx, int vl, int gsh,
-                                               uint64_t hcur, unsigned long long &nm) {
-  const int ndp = A.ndp, nU = A.nU;
-  const int ndy = YAW ? A.ndy : 0;
-  const int nd[3] = {A.nd0, A.nd1, A.nd2};
-    // ---- phase A: every pair; ordered list of the emitted ones; sample counts in use.
-    // When the control table enumerates its per-axis values in lexicographic order (A.ulex: the nested loops every
-    // reference test builds U with, test/test_planner_2d.cpp:52-53), only the combinations of entries that pass
-    // the limits are enumerated, in the same ascending control order: 43 % of C4's pairs instead of all of them.
-    int E = 0;  // emitted successors of the node (uniform over the group)
-    unsigned int nm_lo = 0, nm_hi = 0;  // this lane's share of the set of sample counts in use (OR-reduced after the loop)
-    const int ny_ = YAW ? ndy : 1;
-    const int nv0 = guni<GS>(t.misc[M_NV + 0]), nv1 = guni<GS>(t.misc[M_NV + 1]);
-    const int nv2 = (D == 3) ? guni<GS>(t.misc[M_NV + 2]) : 1;
-    const int in1 = nv2 * ny_, in0 = nv1 * in1;  // combinations per step of the second / first axis
-    const int nA = A.ulex ? nv0 * in0 : nU;
-    const float r_in0 = 1.0f / (float)(in0 > 0 ? in0 : 1), r_in1 = 1.0f / (float)(in1 > 0 ? in1 : 1), r_ny = 1.0f / (float)ny_;
-    const unsigned char *vl_ = (const unsigned char *)(t.misc + M_VL);
-    for (int base = 0; base < nA; base += GS) {
-      const int x = base + vl;
-      int ci = x;
-      unsigned int lpk = 0;  // what the list holds: the control index, or (ulex) the packed entry indices it follows from
-      bool emit = false;
-      int n = 0;
-      if (x < nA) {
-        int j0, j1, j2 = 0, jy = 0;
-        if (A.ulex) {
-          const int a = (int)(((float)x + 0.5f) * r_in0);  // exact: x < 2^12
-          const int ra = x - a * in0;
-          const int b = (int)(((float)ra + 0.5f) * r_in1);
-          int rb = ra - b * in1;
-          if (YAW) {
-            const int c = (int)(((float)rb + 0.5f) * r_ny);
-            jy = rb - c * ny_;
-            rb = c;
-          }
-          j0 = vl_[a];
-          j1 = vl_[16 + b];
-          if (D == 3) j2 = vl_[32 + rb];
-          ci = (D == 3) ? (j0 * nd[1] + j1) * nd[2] + j2 : j0 * nd[1] + j1;
-          if (YAW) ci = ci * ny_ + jy;
-          lpk = (unsigned)j0 | ((unsigned)j1 << 4) | ((unsigned)j2 << 8) | ((unsigned)jy << 12);
-        } else {
-          const unsigned int pk = s_uidx[x];
-          j0 = pk & 15, j1 = (pk >> 4) & 15, j2 = (pk >> 8) & 15;
-          if (YAW) jy = (pk >> 12) & 15;
-          lpk = (unsigned)ci;
-        }
-        const int px = (D == 3) ? __umul24(j0, ndp) + j1 : j0;
-        const int eL = (D - 1) * ndp + ((D == 3) ? j2 : j1);
-        uint64_t h = t.hp[px];
-        fold_entry<K>(h, t.eq, eL);
-        bool head = true;
-        if (YAW) {
-          fold(h, t.yq[jy]);
-          head = (t.hmask[__umul24(j0, ndp) + j1] >> jy) & 1;
-        }
-        const int fl = pair_flags<D>(t.eflag, ndp, j0, j1, j2);
-        n = (fl & 2) ? 0 : (fl >> 8);  // unchanged position: not traversed (env_map.h:163)
-        emit = (fl & 1) && head && (h != hcur);  // env_map.h:158: `tn == curr` is a hash comparison
-      }
-      const unsigned long long m = gballot<GS>(gsh, emit);
-      if (emit) {
-        t.list[E + __popcll(m & ((1ull << vl) - 1ull))] = (unsigned short)lpk;
-        // (an LDS atomicOr per emitting lane here -- the first version -- is processed lane by lane: five 64-lane
-        // atomics per C4 node; the set is OR-ed in registers and reduced once per node instead)
-        if (n) { if (n < 32) nm_lo |= 1u << n; else nm_hi |= 1u << (n - 32); }
-      }
-      E += __popcll(m);
-    }
-  if (GS == 64) {
-    nm = (unsigned long long)wave_reduce_or(nm_lo) | ((unsigned long long)wave_reduce_or(nm_hi) << 32);
-  } else {
-#pragma unroll
-    for (int d = GS >> 1; d > 0; d >>= 1) {
-      nm_lo |= (unsigned int)__shfl_xor((int)nm_lo, d, 64);
-      nm_hi |= (unsigned int)__shfl_xor((int)nm_hi, d, 64);
-    }
-    nm = (unsigned long long)nm_lo | ((unsigned long long)nm_hi << 32);
-  }
-  return E;
-}
 #undef A
 
 #define A (*Ak)
@@ -368,7 +281,7 @@ void expand_pair_kernel(const GridArgs A_kernarg) {
   unsigned short *s_hmask = (unsigned short *)(wb + L.w_hmask);
   double *s_uq = (double *)(wb + L.w_uq);
   double *s_ycsr = (double *)(wb + L.w_ycsr);
-  const NodeTabs tabs{s_node, s_est, s_hp, s_eq, s_eflag, s_misc, s_uq, s_yawT, s_ycs, s_yq, s_hmask, nullptr};
+  const NodeTabs tabs{s_node, s_est, s_hp, s_eq, s_eflag, s_misc, s_uq, s_yawT, s_ycs, s_yq, s_hmask};
 
   const int tts = L.tts, EN = L.EN;
   const int rowcap = RM * tts;
